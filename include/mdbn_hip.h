@@ -1,0 +1,163 @@
+/* libmdbn_hip.so -- C-ABI of the MI355X (gfx950) CD-k engine.
+ *
+ * The reference (glgerard/MDBN, pure Python on Theano) has no FFI: its device boundary is
+ * the call of a Theano-compiled step function built from RBM.get_cost_updates
+ * (src/rbm.py:258-376, compiled at src/dbn.py:302-312 and src/rbm.py:533-544).  Each entry
+ * point below replaces the piece of that compiled graph named in its comment; the Python
+ * classes in mdbn_amd/ (same names and signatures as src/rbm.py, src/dbn.py, src/mlp.py)
+ * are the only callers, through ctypes (mdbn_amd/_lib.py).
+ *
+ * Conventions
+ *  - every function returns 0 (MDBN_OK) or a negative MDBN_E* code; text via mdbn_last_error
+ *  - device buffers are owned by the caller (torch tensors): raw pointers, float32, row-major,
+ *    leading dimensions `ld*` counted in floats, ld % 4 == 0 and 16-byte aligned bases
+ *  - `stream` is a hipStream_t passed as void*; calls enqueue work and never synchronise
+ *  - W is [V, ldh] (n_visible rows, n_hidden columns), as src/rbm.py:104
+ *  - random matrices are addressed by (seed, stream_id, step, draw, row_offset): see
+ *    mdbn_amd/csrc/philox.h (Philox4x32-10; CPU twins in oracle/philox_np.py, philox_ref.c)
+ */
+#ifndef MDBN_HIP_H
+#define MDBN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDBN_OK       0
+#define MDBN_EINVAL  (-1)   /* bad argument (shape, alignment, null pointer) */
+#define MDBN_EHIP    (-2)   /* a HIP runtime call failed */
+#define MDBN_ENOSPC  (-3)   /* workspace too small */
+
+#define MDBN_VERSION 1
+
+typedef struct mdbn_ctx mdbn_ctx;
+
+/* Addresses one random matrix (uniform or normal) of one step. */
+typedef struct mdbn_rng {
+    uint64_t seed;        /* Philox key low/high words                                  */
+    uint32_t stream_id;   /* one per RBM layer, xor-ed into the key's high word          */
+    uint32_t step;        /* counter of step-function / sampling calls                   */
+    uint32_t draw;        /* which random matrix inside the step (0 = U_h0, 2t-1, 2t)    */
+    uint32_t reserved;
+    uint64_t row_offset;  /* global row of local row 0 (data-parallel shard offset)      */
+} mdbn_rng;
+
+/* Everything one CD-k / PCD-k step needs: the compiled step function of
+ * src/rbm.py:258-376 (+ the minibatch gather of src/dbn.py:307 / src/rbm.py:538). */
+typedef struct mdbn_cd_args {
+    /* data */
+    const float *data;        /* [n_data, ldv] training matrix (train_set_x)                    */
+    int64_t      n_data;
+    const void  *indexes;     /* [B] minibatch row indices (device), or NULL: rows 0..B-1 of data */
+    int32_t      index_is_64; /* 1 = int64 (dbn.py:271), 0 = int32 (rbm.py:528)                  */
+    int32_t      gauss;       /* 1 = GRBM (rbm.py:631-699), 0 = Bernoulli RBM                    */
+    int32_t      add_noise;   /* GRBM only: 1 = error_free False (rbm.py:652-658)                */
+    int32_t      k;           /* Gibbs steps                                                     */
+    int64_t      B, V, H;     /* local minibatch rows, n_visible, n_hidden                       */
+    int64_t      ldv, ldh;    /* leading dims of [.,V] and [.,H] matrices (W uses ldh)           */
+    /* parameters */
+    const float *W, *hbias, *vbias;
+    /* PCD: persistent chain [B, ldh] read as chain start and overwritten with nh_sample
+     * (rbm.py:308-311,369); NULL = CD */
+    float       *persistent;
+    /* scratch owned by the caller */
+    float       *V2;          /* [2B, ldv]: rows 0..B-1 = v0, rows B..2B-1 = nv_mean (last step) */
+    float       *P2;          /* [2B, ldh]: rows 0..B-1 = ph_mean, rows B..2B-1 = -nh_mean       */
+    float       *hs;          /* [B, ldh] hidden chain state                                     */
+    float       *vs;          /* [B, ldv] visible sample (RBM; GRBM with noise), may be NULL     */
+    float       *stats;       /* packed [V*ldh | ldh | ldv | 4]: S, s_h, s_v, cost_sum           */
+    void        *workspace;   /* >= mdbn_workspace_bytes(B, V, H)                                */
+    int64_t      workspace_bytes;
+    mdbn_rng     rng;         /* .draw is ignored (the step numbers its own draws)               */
+} mdbn_cd_args;
+
+/* Parameter update of src/rbm.py:347-365 from (all-reduced) statistics. */
+typedef struct mdbn_update_args {
+    float *W, *W_speed;             /* [V, ldh] */
+    const float *W0;                /* frozen weight-cost snapshot (rbm.py:415) or NULL = live W */
+    float *hbias, *hbias_speed;     /* [H] */
+    float *vbias, *vbias_speed;     /* [V] */
+    int64_t V, H, ldv, ldh;
+    const float *stats;             /* packed as mdbn_cd_args.stats (summed over ranks)          */
+    float lr, lambda_1, lambda_2, weightcost, momentum;
+    float batch_size;               /* divisor of S: the batch_size ARGUMENT (rbm.py:413)        */
+    float n_rows;                   /* divisor of s_h, s_v: rows actually present (rbm.py:416-417) */
+    float cost_scale;               /* monitoring cost = stats.cost_sum * cost_scale ...          */
+    float *cost_out;                /* ... written here (device scalar) if not NULL               */
+} mdbn_update_args;
+
+int  mdbn_version(void);
+int  mdbn_last_error(char *buf, size_t n);
+
+int  mdbn_ctx_create(mdbn_ctx **out, int device);
+int  mdbn_ctx_destroy(mdbn_ctx *ctx);
+
+/* Measurement hook (bench.py): while enabled, every GEMM launch (the dominant kernel) is
+ * bracketed by HIP events on its stream; _read synchronises on them and returns the number
+ * of launches recorded since enabling and the sum of their durations. */
+int  mdbn_kernel_timing(mdbn_ctx *ctx, int enable);
+int  mdbn_kernel_timing_read(mdbn_ctx *ctx, int64_t *n_launches, double *total_ms);
+
+/* bytes of split-K / reduction scratch the calls below need for shapes up to (B, V, H) */
+int  mdbn_workspace_bytes(int64_t B, int64_t V, int64_t H, int64_t *bytes);
+/* floats in the packed statistics buffer */
+int  mdbn_stats_floats(int64_t V, int64_t H, int64_t *n);
+
+/* minibatch gather: train_set_x[indexes]  (src/dbn.py:307, src/rbm.py:538) */
+int  mdbn_gather_rows(mdbn_ctx *ctx, void *stream, const float *src, int64_t n_rows,
+                      int64_t cols, int64_t ld_src, const void *indexes, int index_is_64,
+                      int64_t n_idx, float *dst, int64_t ld_dst);
+
+/* propup + sample_h_given_v (src/rbm.py:187-213), also HiddenLayer.output (src/mlp.py:103-107):
+ * pre = v W + hbias ; mean = sigmoid(pre) ; sample = (u < mean).
+ * pre / mean / sample may each be NULL; mean is stored multiplied by mean_scale. */
+int  mdbn_propup_sample(mdbn_ctx *ctx, void *stream, const float *v, int64_t B, int64_t ldv,
+                        const float *W, int64_t V, int64_t H, int64_t ldh, const float *hbias,
+                        float *pre, float *mean, float mean_scale, float *sample,
+                        const mdbn_rng *rng, void *workspace, int64_t workspace_bytes);
+
+/* propdown + sample_v_given_h: RBM src/rbm.py:215-240 (gauss=0: sigmoid + Bernoulli),
+ * GRBM src/rbm.py:647-660 (gauss=1: linear mean, sample = mean [+ N(0,1) if add_noise]).
+ * If v0 != NULL the un-normalised reconstruction cost of src/rbm.py:479-480 / :697 is
+ * written to cost_sum[0] (sum over all elements; caller divides). */
+int  mdbn_propdown_sample(mdbn_ctx *ctx, void *stream, const float *h, int64_t B, int64_t ldh,
+                          const float *W, int64_t V, int64_t H, int64_t ldv, const float *vbias,
+                          int gauss, int add_noise, float *pre, float *mean, float *sample,
+                          const mdbn_rng *rng, const float *v0, float *cost_sum,
+                          void *workspace, int64_t workspace_bytes);
+
+/* compute_rbm_grad's products (src/rbm.py:411-417) from the stacked buffers of mdbn_cd_args:
+ * stats = [S = v0'ph - nv'nh | s_h | s_v | (cost untouched)] */
+int  mdbn_cd_stats(mdbn_ctx *ctx, void *stream, const float *V2, const float *P2, int64_t B,
+                   int64_t V, int64_t H, int64_t ldv, int64_t ldh, float *stats,
+                   void *workspace, int64_t workspace_bytes);
+
+/* update rule of src/rbm.py:347-365 */
+int  mdbn_apply_update(mdbn_ctx *ctx, void *stream, const mdbn_update_args *a);
+
+/* gather + positive phase + k x gibbs_hvh + statistics (src/rbm.py:303-345, 374);
+ * leaves the packed statistics in a->stats; follow with mdbn_apply_update (after the
+ * all-reduce in data-parallel runs). */
+int  mdbn_cd_step(mdbn_ctx *ctx, void *stream, const mdbn_cd_args *a);
+
+/* free energy: RBM src/rbm.py:166-171, GRBM src/rbm.py:684-688;  out[N] */
+int  mdbn_free_energy(mdbn_ctx *ctx, void *stream, const float *x, int64_t N, int64_t ldv,
+                      const float *W, int64_t V, int64_t H, int64_t ldh, const float *hbias,
+                      const float *vbias, int gauss, float *out,
+                      void *workspace, int64_t workspace_bytes);
+
+/* the random matrices themselves (tests, and sampling utilities) */
+int  mdbn_rng_uniform(mdbn_ctx *ctx, void *stream, float *out, int64_t rows, int64_t cols,
+                      int64_t ld, const mdbn_rng *rng);
+int  mdbn_rng_normal(mdbn_ctx *ctx, void *stream, float *out, int64_t rows, int64_t cols,
+                     int64_t ld, const mdbn_rng *rng);
+/* host-side twin of mdbn_rng_uniform (no GPU needed) */
+int  mdbn_philox_host(float *out, int64_t rows, int64_t cols, int64_t ld, const mdbn_rng *rng);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDBN_HIP_H */

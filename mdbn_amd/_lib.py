@@ -1,0 +1,104 @@
+"""ctypes binding of libmdbn_hip.so (include/mdbn_hip.h).  No torch types cross this line:
+callers pass tensor.data_ptr() and the raw hipStream_t."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmdbn_hip.so")
+
+
+class MdbnError(RuntimeError):
+    pass
+
+
+class Rng(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("stream_id", C.c_uint32), ("step", C.c_uint32),
+                ("draw", C.c_uint32), ("reserved", C.c_uint32), ("row_offset", C.c_uint64)]
+
+
+class CdArgs(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("n_data", C.c_int64), ("indexes", C.c_void_p),
+                ("index_is_64", C.c_int32), ("gauss", C.c_int32), ("add_noise", C.c_int32),
+                ("k", C.c_int32), ("B", C.c_int64), ("V", C.c_int64), ("H", C.c_int64),
+                ("ldv", C.c_int64), ("ldh", C.c_int64),
+                ("W", C.c_void_p), ("hbias", C.c_void_p), ("vbias", C.c_void_p),
+                ("persistent", C.c_void_p),
+                ("V2", C.c_void_p), ("P2", C.c_void_p), ("hs", C.c_void_p), ("vs", C.c_void_p),
+                ("stats", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("rng", Rng)]
+
+
+class UpdateArgs(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("W_speed", C.c_void_p), ("W0", C.c_void_p),
+                ("hbias", C.c_void_p), ("hbias_speed", C.c_void_p),
+                ("vbias", C.c_void_p), ("vbias_speed", C.c_void_p),
+                ("V", C.c_int64), ("H", C.c_int64), ("ldv", C.c_int64), ("ldh", C.c_int64),
+                ("stats", C.c_void_p),
+                ("lr", C.c_float), ("lambda_1", C.c_float), ("lambda_2", C.c_float),
+                ("weightcost", C.c_float), ("momentum", C.c_float),
+                ("batch_size", C.c_float), ("n_rows", C.c_float),
+                ("cost_scale", C.c_float), ("cost_out", C.c_void_p)]
+
+
+_i64, _i32, _f32, _vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
+_rngp = C.POINTER(Rng)
+
+# name -> argtypes; every function returns int.  Keep in step with include/mdbn_hip.h
+# (tests/test_capi_symbols.py parses the header and checks both directions).
+SIGNATURES = {
+    "mdbn_version": [],
+    "mdbn_last_error": [C.c_char_p, C.c_size_t],
+    "mdbn_ctx_create": [C.POINTER(_vp), _i32],
+    "mdbn_ctx_destroy": [_vp],
+    "mdbn_kernel_timing": [_vp, _i32],
+    "mdbn_kernel_timing_read": [_vp, C.POINTER(_i64), C.POINTER(C.c_double)],
+    "mdbn_workspace_bytes": [_i64, _i64, _i64, C.POINTER(_i64)],
+    "mdbn_stats_floats": [_i64, _i64, C.POINTER(_i64)],
+    "mdbn_gather_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _i64, _vp, _i64],
+    "mdbn_propup_sample": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp,
+                           _vp, _vp, _f32, _vp, _rngp, _vp, _i64],
+    "mdbn_propdown_sample": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i32, _i32,
+                             _vp, _vp, _vp, _rngp, _vp, _vp, _vp, _i64],
+    "mdbn_cd_stats": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _i64],
+    "mdbn_apply_update": [_vp, _vp, C.POINTER(UpdateArgs)],
+    "mdbn_cd_step": [_vp, _vp, C.POINTER(CdArgs)],
+    "mdbn_free_energy": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i32, _vp,
+                         _vp, _i64],
+    "mdbn_rng_uniform": [_vp, _vp, _vp, _i64, _i64, _i64, _rngp],
+    "mdbn_rng_normal": [_vp, _vp, _vp, _i64, _i64, _i64, _rngp],
+    "mdbn_philox_host": [_vp, _i64, _i64, _i64, _rngp],
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library; raises MdbnError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MdbnError(
+            "%s is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or python -m mdbn_amd.build). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if lib.mdbn_version() != 1:
+        raise MdbnError("libmdbn_hip.so version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    load().mdbn_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MdbnError("%s failed (%d): %s" % (what, rc, last_error()))

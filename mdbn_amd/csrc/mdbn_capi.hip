@@ -1,0 +1,592 @@
+// C-ABI of libmdbn_hip.so (declared in include/mdbn_hip.h): argument validation, split-K
+// planning, workspace carving and the launch sequence of one CD-k step.  No allocation,
+// no synchronisation: every entry point only enqueues kernels on the caller's stream.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+#include "mdbn_kernels.h"
+
+using namespace mdbn;
+
+struct mdbn_ctx {
+    int device;
+    int num_cu;
+};
+
+// Optional HIP-event timing of the GEMM launches (the dominant kernel), used by bench.py to
+// quote the roofline from the kernel's own average duration on the stream it runs on.
+struct GemmTiming {
+    bool enabled = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    size_t used = 0;
+};
+static GemmTiming g_timing;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_OK(expr)                                                                    \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess)                                                           \
+            return fail(MDBN_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                            \
+    } while (0)
+
+#define REQUIRE(cond, ...)                                 \
+    do {                                                   \
+        if (!(cond)) return fail(MDBN_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+constexpr int kTargetBlocks = 256;     // one 128x128 tile job per CU (MI355X: 256 CUs)
+constexpr int kMinSplitK = 128;        // >= 4 slices of BK = 32 per split
+
+inline int64_t ru4(int64_t x) { return (x + 3) & ~int64_t(3); }
+inline int64_t ru64(int64_t x) { return (x + 63) & ~int64_t(63); }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+struct Plan {
+    int tiles_m, tiles_n, splitk, kchunk;
+    int64_t slab_floats(int64_t M, int64_t ldc) const { return (int64_t)splitk * M * ldc; }
+};
+
+Plan plan_gemm(int64_t M, int64_t N, int64_t K)
+{
+    Plan p;
+    p.tiles_m = (int)((M + 127) / 128);
+    p.tiles_n = (int)((N + 127) / 128);
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
+    int64_t want = std::max<int64_t>(1, kTargetBlocks / std::max<int64_t>(tiles, 1));
+    int64_t maxsplit = std::max<int64_t>(1, K / kMinSplitK);
+    int64_t sk = std::min(want, maxsplit);
+    int64_t kchunk = ((K + sk - 1) / sk + 31) / 32 * 32;
+    if (kchunk < 32) kchunk = 32;
+    sk = std::max<int64_t>(1, (K + kchunk - 1) / kchunk);
+    p.splitk = (int)sk;
+    p.kchunk = (int)kchunk;
+    return p;
+}
+
+hipError_t timed_gemm(int la, int lb, const GemmArgs& g, hipStream_t s)
+{
+    if (!g_timing.enabled || g_timing.used >= 8192) return launch_gemm(la, lb, g, s);
+    if (g_timing.used == g_timing.pool.size()) {
+        hipEvent_t a, b;
+        hipError_t e = hipEventCreate(&a);
+        if (e != hipSuccess) return e;
+        e = hipEventCreate(&b);
+        if (e != hipSuccess) return e;
+        g_timing.pool.emplace_back(a, b);
+    }
+    auto& ev = g_timing.pool[g_timing.used++];
+    hipError_t e = hipEventRecord(ev.first, s);
+    if (e != hipSuccess) return e;
+    e = launch_gemm(la, lb, g, s);
+    if (e != hipSuccess) return e;
+    return hipEventRecord(ev.second, s);
+}
+
+PhiloxKey make_key(const mdbn_rng& r, uint32_t draw)
+{
+    PhiloxKey k;
+    k.k0 = (uint32_t)r.seed;
+    k.k1 = (uint32_t)(r.seed >> 32) ^ r.stream_id;
+    k.step = r.step;
+    k.draw = draw;
+    k.row_offset = r.row_offset;
+    return k;
+}
+
+// carve-up of the caller's workspace
+struct Workspace {
+    float* slabs;
+    int64_t slab_floats;
+    float* cost_partials;
+    int64_t cost_floats;
+    float* colP;      // [2 * nch][ldh]
+    float* colV;      // [2 * nch][ldv]
+};
+
+struct WsSizes {
+    int64_t slab, cost, colP, colV;
+    int64_t total_bytes() const { return 4 * (ru64(slab) + ru64(cost) + ru64(colP) + ru64(colV)); }
+};
+
+WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
+{
+    const int64_t ldv = ru4(V), ldh = ru4(H);
+    WsSizes s;
+    const Plan up = plan_gemm(B, H, V), down = plan_gemm(B, V, H), st = plan_gemm(V, H, 2 * B);
+    s.slab = std::max(up.slab_floats(B, ldh), down.slab_floats(B, ldv));
+    if (st.splitk > 1) s.slab = std::max(s.slab, st.slab_floats(V, ldh));
+    s.slab = std::max<int64_t>(s.slab, 4 * std::max(ldv, ldh) * 8);
+    s.cost = std::max(epilogue_blocks(B, ldv), epilogue_blocks(B, ldh)) + 64;
+    const int nch = colsum_chunks(B);
+    s.colP = 2 * (int64_t)nch * ldh;
+    s.colV = 2 * (int64_t)nch * ldv;
+    return s;
+}
+
+int carve(void* ws, int64_t bytes, int64_t B, int64_t V, int64_t H, Workspace& out, bool need_stats)
+{
+    REQUIRE(ws != nullptr && aligned16(ws), "workspace must be a 16-byte aligned device pointer");
+    const WsSizes s = ws_sizes(B, V, H);
+    float* p = reinterpret_cast<float*>(ws);
+    if (need_stats) {
+        if (bytes < s.total_bytes())
+            return fail(MDBN_ENOSPC, "workspace %lld bytes < %lld needed for B=%lld V=%lld H=%lld",
+                        (long long)bytes, (long long)s.total_bytes(), (long long)B, (long long)V, (long long)H);
+        out.slabs = p;            out.slab_floats = s.slab;  p += ru64(s.slab);
+        out.cost_partials = p;    out.cost_floats = s.cost;  p += ru64(s.cost);
+        out.colP = p;             p += ru64(s.colP);
+        out.colV = p;
+    } else {
+        // propagation only: a fixed cost region at the end, everything else is slabs
+        const int64_t floats = bytes / 4;
+        const int64_t cost = 1 << 16;
+        if (floats < cost + 4096)
+            return fail(MDBN_ENOSPC, "workspace %lld bytes is too small", (long long)bytes);
+        out.slabs = p;
+        out.slab_floats = (floats - cost) & ~int64_t(63);
+        out.cost_partials = p + out.slab_floats;
+        out.cost_floats = cost;
+        out.colP = out.colV = nullptr;
+    }
+    return MDBN_OK;
+}
+
+// One affine map + activation over `rows` rows, chunked so the split-K slabs fit.
+//   up   (dir 0): x[rows, V] * W        -> [rows, H]   (bias = hbias)
+//   down (dir 1): x[rows, H] * W^T      -> [rows, V]   (bias = vbias)
+struct Affine {
+    const float* x; int64_t rows, ldx;
+    const float* W; int64_t V, H, ldw;
+    int dir;
+    const float* bias;
+    float* pre; float* mean; float* sample; int64_t ldo;
+    float mean_scale; int gauss;
+    const float* target; int64_t ld_target;
+    bool want_cost;
+    const mdbn_rng* rng; uint32_t draw;
+};
+
+int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_out)
+{
+    const int64_t Kdim = a.dir == 0 ? a.V : a.H;
+    const int64_t Ndim = a.dir == 0 ? a.H : a.V;
+    int n_cost = 0;
+    int64_t r0 = 0;
+    while (r0 < a.rows) {
+        int64_t R = a.rows - r0;
+        Plan p = plan_gemm(R, Ndim, Kdim);
+        while (p.slab_floats(R, a.ldo) > ws.slab_floats) {
+            if (R <= 4) return fail(MDBN_ENOSPC, "workspace cannot hold one 4-row slab");
+            R = std::max<int64_t>(4, (R / 2 + 3) & ~int64_t(3));
+            p = plan_gemm(R, Ndim, Kdim);
+        }
+        GemmArgs g;
+        g.A = a.x + r0 * a.ldx;  g.lda = a.ldx;
+        g.B = a.W;               g.ldb = a.ldw;
+        g.C = ws.slabs;          g.ldc = a.ldo;
+        g.slab_stride = R * a.ldo;
+        g.M = (int)R; g.N = (int)Ndim; g.K = (int)Kdim; g.Nst = (int)a.ldo;
+        g.kchunk = p.kchunk; g.splitk = p.splitk; g.tiles_m = p.tiles_m; g.tiles_n = p.tiles_n;
+        g.inner_m = p.tiles_m <= p.tiles_n;
+        HIP_OK(timed_gemm(LAY_K, a.dir == 0 ? LAY_MN : LAY_K, g, s));
+
+        EpiArgs e;
+        e.slabs = ws.slabs; e.slab_stride = g.slab_stride; e.nsplit = p.splitk;
+        e.rows = (int)R; e.cols = (int)Ndim; e.ld = a.ldo;
+        e.bias = a.bias;
+        e.pre = a.pre ? a.pre + r0 * a.ldo : nullptr;
+        e.mean = a.mean ? a.mean + r0 * a.ldo : nullptr;
+        e.sample = a.sample ? a.sample + r0 * a.ldo : nullptr;
+        e.mean_scale = a.mean_scale; e.gauss = a.gauss;
+        e.target = a.target ? a.target + r0 * a.ld_target : nullptr;
+        e.ld_target = a.ld_target;
+        const int nb = epilogue_blocks(R, a.ldo);
+        e.cost_partials = nullptr;
+        if (a.want_cost) {
+            if (n_cost + nb > ws.cost_floats) return fail(MDBN_ENOSPC, "cost scratch exhausted");
+            e.cost_partials = ws.cost_partials + n_cost;
+            n_cost += nb;
+        }
+        mdbn_rng zero;
+        memset(&zero, 0, sizeof zero);
+        const mdbn_rng& rr = a.rng ? *a.rng : zero;
+        e.rng = make_key(rr, a.draw);
+        e.rng.row_offset = rr.row_offset + (uint64_t)r0;
+        HIP_OK(launch_act_epilogue(e, s));
+        r0 += R;
+    }
+    if (n_cost_out) *n_cost_out = n_cost;
+    return MDBN_OK;
+}
+
+int check_mat(const void* p, int64_t ld, int64_t cols, const char* name)
+{
+    REQUIRE(p != nullptr, "%s is NULL", name);
+    REQUIRE(aligned16(p), "%s is not 16-byte aligned", name);
+    REQUIRE(ld % 4 == 0 && ld >= cols, "%s: leading dimension %lld must be a multiple of 4 and >= %lld",
+            name, (long long)ld, (long long)cols);
+    return MDBN_OK;
+}
+
+#define CHECK(expr) do { int _rc = (expr); if (_rc != MDBN_OK) return _rc; } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int mdbn_version(void) { return MDBN_VERSION; }
+
+int mdbn_last_error(char* buf, size_t n)
+{
+    if (!buf || n == 0) return MDBN_EINVAL;
+    snprintf(buf, n, "%s", g_err.c_str());
+    return MDBN_OK;
+}
+
+int mdbn_ctx_create(mdbn_ctx** out, int device)
+{
+    REQUIRE(out != nullptr, "out is NULL");
+    int count = 0;
+    HIP_OK(hipGetDeviceCount(&count));
+    REQUIRE(device >= 0 && device < count, "device %d out of range (%d visible)", device, count);
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MDBN_EHIP, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    mdbn_ctx* c = new mdbn_ctx;
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    *out = c;
+    return MDBN_OK;
+}
+
+int mdbn_ctx_destroy(mdbn_ctx* ctx)
+{
+    delete ctx;
+    return MDBN_OK;
+}
+
+int mdbn_kernel_timing(mdbn_ctx* ctx, int enable)
+{
+    REQUIRE(ctx != nullptr, "ctx is NULL");
+    g_timing.enabled = enable != 0;
+    g_timing.used = 0;
+    return MDBN_OK;
+}
+
+int mdbn_kernel_timing_read(mdbn_ctx* ctx, int64_t* n_launches, double* total_ms)
+{
+    REQUIRE(ctx && n_launches && total_ms, "NULL argument");
+    double tot = 0.0;
+    for (size_t i = 0; i < g_timing.used; ++i) {
+        HIP_OK(hipEventSynchronize(g_timing.pool[i].second));
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, g_timing.pool[i].first, g_timing.pool[i].second));
+        tot += ms;
+    }
+    *n_launches = (int64_t)g_timing.used;
+    *total_ms = tot;
+    return MDBN_OK;
+}
+
+int mdbn_workspace_bytes(int64_t B, int64_t V, int64_t H, int64_t* bytes)
+{
+    REQUIRE(bytes != nullptr && B > 0 && V > 0 && H > 0, "bad arguments");
+    *bytes = ws_sizes(B, V, H).total_bytes();
+    return MDBN_OK;
+}
+
+int mdbn_stats_floats(int64_t V, int64_t H, int64_t* n)
+{
+    REQUIRE(n != nullptr && V > 0 && H > 0, "bad arguments");
+    *n = V * ru4(H) + ru4(H) + ru4(V) + 4;
+    return MDBN_OK;
+}
+
+int mdbn_gather_rows(mdbn_ctx* ctx, void* stream, const float* src, int64_t n_rows, int64_t cols,
+                     int64_t ld_src, const void* indexes, int index_is_64, int64_t n_idx, float* dst,
+                     int64_t ld_dst)
+{
+    REQUIRE(ctx != nullptr, "ctx is NULL");
+    CHECK(check_mat(src, ld_src, cols, "src"));
+    CHECK(check_mat(dst, ld_dst, cols, "dst"));
+    REQUIRE(n_rows > 0 && n_idx >= 0, "bad row counts");
+    REQUIRE(indexes != nullptr || n_idx <= n_rows, "identity gather longer than the source");
+    HIP_OK(launch_gather(src, n_rows, ru4(cols), ld_src, indexes, index_is_64, n_idx, dst, ld_dst,
+                         (hipStream_t)stream));
+    return MDBN_OK;
+}
+
+int mdbn_propup_sample(mdbn_ctx* ctx, void* stream, const float* v, int64_t B, int64_t ldv, const float* W,
+                       int64_t V, int64_t H, int64_t ldh, const float* hbias, float* pre, float* mean,
+                       float mean_scale, float* sample, const mdbn_rng* rng, void* workspace,
+                       int64_t workspace_bytes)
+{
+    REQUIRE(ctx != nullptr, "ctx is NULL");
+    REQUIRE(B > 0 && V > 0 && H > 0, "bad shape");
+    CHECK(check_mat(v, ldv, V, "v"));
+    CHECK(check_mat(W, ldh, H, "W"));
+    REQUIRE(hbias != nullptr, "hbias is NULL");
+    REQUIRE(sample == nullptr || rng != nullptr, "sampling needs rng");
+    for (const float* p : {(const float*)pre, (const float*)mean, (const float*)sample})
+        REQUIRE(p == nullptr || aligned16(p), "output not 16-byte aligned");
+    Workspace ws;
+    CHECK(carve(workspace, workspace_bytes, B, V, H, ws, false));
+    Affine a{v, B, ldv, W, V, H, ldh, 0, hbias, pre, mean, sample, ldh, mean_scale, 0,
+             nullptr, 0, false, rng, rng ? rng->draw : 0u};
+    return run_affine(a, ws, (hipStream_t)stream, nullptr);
+}
+
+int mdbn_propdown_sample(mdbn_ctx* ctx, void* stream, const float* h, int64_t B, int64_t ldh, const float* W,
+                         int64_t V, int64_t H, int64_t ldv, const float* vbias, int gauss, int add_noise,
+                         float* pre, float* mean, float* sample, const mdbn_rng* rng, const float* v0,
+                         float* cost_sum, void* workspace, int64_t workspace_bytes)
+{
+    REQUIRE(ctx != nullptr, "ctx is NULL");
+    REQUIRE(B > 0 && V > 0 && H > 0, "bad shape");
+    CHECK(check_mat(h, ldh, H, "h"));
+    CHECK(check_mat(W, ldh, H, "W"));
+    REQUIRE(vbias != nullptr, "vbias is NULL");
+    REQUIRE(ldv % 4 == 0 && ldv >= V, "bad ldv");
+    const bool draws = sample != nullptr && (!gauss || add_noise);
+    REQUIRE(!draws || rng != nullptr, "sampling needs rng");
+    REQUIRE((v0 == nullptr) == (cost_sum == nullptr), "v0 and cost_sum go together");
+    Workspace ws;
+    CHECK(carve(workspace, workspace_bytes, B, V, H, ws, false));
+    hipStream_t s = (hipStream_t)stream;
+    // GRBM without noise: sample == mean (rbm.py:652-653): write the mean twice, no draw
+    Affine a{h, B, ldh, W, V, H, ldh, 1, vbias, pre, mean, draws ? sample : nullptr, ldv, 1.0f, gauss,
+             v0, ldv, v0 != nullptr, rng, rng ? rng->draw : 0u};
+    int n_cost = 0;
+    CHECK(run_affine(a, ws, s, &n_cost));
+    if (sample && !draws) {
+        REQUIRE(mean != nullptr || pre != nullptr, "noise-free GRBM sample needs mean or pre");
+        if (sample != mean)
+            HIP_OK(hipMemcpyAsync(sample, mean ? mean : pre, sizeof(float) * B * ldv, hipMemcpyDeviceToDevice, s));
+    }
+    if (cost_sum)
+        HIP_OK(launch_finalize_stats(nullptr, nullptr, 0, 0, 0, ws.cost_partials, n_cost, nullptr, nullptr,
+                                     cost_sum, s));
+    return MDBN_OK;
+}
+
+int mdbn_cd_stats(mdbn_ctx* ctx, void* stream, const float* V2, const float* P2, int64_t B, int64_t V,
+                  int64_t H, int64_t ldv, int64_t ldh, float* stats, void* workspace, int64_t workspace_bytes)
+{
+    REQUIRE(ctx != nullptr, "ctx is NULL");
+    REQUIRE(B > 0 && V > 0 && H > 0, "bad shape");
+    CHECK(check_mat(V2, ldv, V, "V2"));
+    CHECK(check_mat(P2, ldh, H, "P2"));
+    REQUIRE(stats != nullptr && aligned16(stats), "stats must be 16-byte aligned");
+    Workspace ws;
+    CHECK(carve(workspace, workspace_bytes, B, V, H, ws, true));
+    hipStream_t s = (hipStream_t)stream;
+    float* S = stats;
+    float* s_h = stats + V * ldh;
+    float* s_v = s_h + ldh;
+    float* cost = s_v + ldv;
+
+    HIP_OK(launch_colsum_partial(P2, (int)B, ldh, ws.colP, s));
+    HIP_OK(launch_colsum_partial(V2, (int)B, ldv, ws.colV, s));
+    HIP_OK(launch_finalize_stats(ws.colP, ws.colV, (int)B, ldh, ldv, nullptr, 0, s_h, s_v, cost, s));
+
+    // S = [v0 ; nv]^T [ph ; -nh]  : one GEMM over the stacked batch dimension (K = 2B)
+    const Plan p = plan_gemm(V, H, 2 * B);
+    GemmArgs g;
+    g.A = V2; g.lda = ldv; g.B = P2; g.ldb = ldh;
+    g.ldc = ldh; g.slab_stride = V * ldh;
+    g.M = (int)V; g.N = (int)H; g.K = (int)(2 * B); g.Nst = (int)ldh;
+    g.kchunk = p.kchunk; g.splitk = p.splitk; g.tiles_m = p.tiles_m; g.tiles_n = p.tiles_n;
+    g.inner_m = p.tiles_m <= p.tiles_n;
+    if (p.splitk == 1) {
+        g.C = S;
+        HIP_OK(timed_gemm(LAY_MN, LAY_MN, g, s));
+    } else {
+        REQUIRE(p.slab_floats(V, ldh) <= ws.slab_floats, "internal: statistic slabs exceed workspace");
+        g.C = ws.slabs;
+        HIP_OK(timed_gemm(LAY_MN, LAY_MN, g, s));
+        HIP_OK(launch_sum_slabs(ws.slabs, p.splitk, g.slab_stride, V * ldh, S, s));
+    }
+    return MDBN_OK;
+}
+
+int mdbn_apply_update(mdbn_ctx* ctx, void* stream, const mdbn_update_args* a)
+{
+    REQUIRE(ctx != nullptr && a != nullptr, "NULL argument");
+    REQUIRE(a->V > 0 && a->H > 0 && a->ldh == ru4(a->H) && a->ldv == ru4(a->V), "bad shape / leading dims");
+    CHECK(check_mat(a->W, a->ldh, a->H, "W"));
+    CHECK(check_mat(a->W_speed, a->ldh, a->H, "W_speed"));
+    REQUIRE(a->W0 == nullptr || aligned16(a->W0), "W0 not aligned");
+    REQUIRE(a->stats != nullptr && aligned16(a->stats), "stats not aligned");
+    REQUIRE(a->hbias && a->hbias_speed && a->vbias && a->vbias_speed, "bias pointers are NULL");
+    REQUIRE(a->batch_size > 0.f && a->n_rows > 0.f, "bad divisors");
+    HIP_OK(launch_update(*a, (hipStream_t)stream));
+    return MDBN_OK;
+}
+
+int mdbn_cd_step(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a)
+{
+    REQUIRE(ctx != nullptr && a != nullptr, "NULL argument");
+    const int64_t B = a->B, V = a->V, H = a->H, ldv = a->ldv, ldh = a->ldh;
+    REQUIRE(B > 0 && V > 0 && H > 0 && a->k >= 1, "bad shape / k");
+    REQUIRE(ldv == ru4(V) && ldh == ru4(H), "leading dims must be round_up(V,4), round_up(H,4)");
+    CHECK(check_mat(a->data, ldv, V, "data"));
+    CHECK(check_mat(a->W, ldh, H, "W"));
+    CHECK(check_mat(a->V2, ldv, V, "V2"));
+    CHECK(check_mat(a->P2, ldh, H, "P2"));
+    CHECK(check_mat(a->hs, ldh, H, "hs"));
+    REQUIRE(a->hbias && a->vbias, "bias pointers are NULL");
+    REQUIRE(a->stats != nullptr && aligned16(a->stats), "stats not aligned");
+    REQUIRE(a->gauss || a->vs != nullptr, "Bernoulli RBM needs the vs buffer");
+    REQUIRE(a->vs == nullptr || aligned16(a->vs), "vs not aligned");
+    REQUIRE(a->persistent == nullptr || aligned16(a->persistent), "persistent not aligned");
+    REQUIRE(a->indexes != nullptr || B <= a->n_data, "identity minibatch longer than data");
+    Workspace ws;
+    CHECK(carve(a->workspace, a->workspace_bytes, B, V, H, ws, true));
+    hipStream_t s = (hipStream_t)stream;
+
+    float* v0 = a->V2;
+    float* nv = a->V2 + B * ldv;
+    float* ph = a->P2;
+    float* nh = a->P2 + B * ldh;
+
+    // x = train_set_x[indexes]                                        (dbn.py:307)
+    HIP_OK(launch_gather(a->data, a->n_data, ldv, ldv, a->indexes, a->index_is_64, B, v0, ldv, s));
+
+    // positive phase: ph_mean, ph_sample                              (rbm.py:303)
+    {
+        Affine up{v0, B, ldv, a->W, V, H, ldh, 0, a->hbias, nullptr, ph, a->hs, ldh, 1.0f, 0,
+                  nullptr, 0, false, &a->rng, 0u};
+        CHECK(run_affine(up, ws, s, nullptr));
+    }
+    int n_cost = 0;
+    for (int t = 1; t <= a->k; ++t) {                                  // gibbs_hvh x k (rbm.py:318-336)
+        const bool last = t == a->k;
+        const float* chain = (t == 1 && a->persistent) ? a->persistent : a->hs;   // rbm.py:308-311
+        // v_t | h_{t-1}: RBM sigmoid + Bernoulli (rbm.py:229-240); GRBM linear mean (rbm.py:647-660;
+        // its noisy sample never feeds the chain, rbm.py:669, so it is not materialised here)
+        Affine down{chain, B, ldh, a->W, V, H, ldh, 1, a->vbias, nullptr, nv, a->gauss ? nullptr : a->vs,
+                    ldv, 1.0f, a->gauss, last ? v0 : nullptr, ldv, last, &a->rng, (uint32_t)(2 * t - 1)};
+        CHECK(run_affine(down, ws, s, last ? &n_cost : nullptr));
+        // h_t | v_t: from the mean for GRBM (rbm.py:669), from the sample for RBM (rbm.py:246)
+        const bool need_sample = !last || a->persistent != nullptr;
+        float* hdst = (last && a->persistent) ? a->persistent : a->hs;            // rbm.py:369
+        Affine up{a->gauss ? nv : a->vs, B, ldv, a->W, V, H, ldh, 0, a->hbias, nullptr, nh,
+                  need_sample ? hdst : nullptr, ldh, -1.0f, 0, nullptr, 0, false, &a->rng, (uint32_t)(2 * t)};
+        CHECK(run_affine(up, ws, s, nullptr));
+    }
+
+    float* S = a->stats;
+    float* s_h = a->stats + V * ldh;
+    float* s_v = s_h + ldh;
+    float* cost = s_v + ldv;
+    HIP_OK(launch_colsum_partial(a->P2, (int)B, ldh, ws.colP, s));
+    HIP_OK(launch_colsum_partial(a->V2, (int)B, ldv, ws.colV, s));
+    HIP_OK(launch_finalize_stats(ws.colP, ws.colV, (int)B, ldh, ldv, ws.cost_partials, n_cost, s_h, s_v,
+                                 cost, s));
+    const Plan p = plan_gemm(V, H, 2 * B);
+    GemmArgs g;
+    g.A = a->V2; g.lda = ldv; g.B = a->P2; g.ldb = ldh;
+    g.ldc = ldh; g.slab_stride = V * ldh;
+    g.M = (int)V; g.N = (int)H; g.K = (int)(2 * B); g.Nst = (int)ldh;
+    g.kchunk = p.kchunk; g.splitk = p.splitk; g.tiles_m = p.tiles_m; g.tiles_n = p.tiles_n;
+    g.inner_m = p.tiles_m <= p.tiles_n;
+    if (p.splitk == 1) {
+        g.C = S;
+        HIP_OK(timed_gemm(LAY_MN, LAY_MN, g, s));
+    } else {
+        g.C = ws.slabs;
+        HIP_OK(timed_gemm(LAY_MN, LAY_MN, g, s));
+        HIP_OK(launch_sum_slabs(ws.slabs, p.splitk, g.slab_stride, V * ldh, S, s));
+    }
+    return MDBN_OK;
+}
+
+int mdbn_free_energy(mdbn_ctx* ctx, void* stream, const float* x, int64_t N, int64_t ldv, const float* W,
+                     int64_t V, int64_t H, int64_t ldh, const float* hbias, const float* vbias, int gauss,
+                     float* out, void* workspace, int64_t workspace_bytes)
+{
+    REQUIRE(ctx != nullptr, "ctx is NULL");
+    REQUIRE(N > 0 && V > 0 && H > 0, "bad shape");
+    CHECK(check_mat(x, ldv, V, "x"));
+    CHECK(check_mat(W, ldh, H, "W"));
+    REQUIRE(hbias && vbias && out, "NULL pointer");
+    Workspace ws;
+    CHECK(carve(workspace, workspace_bytes, N, V, H, ws, false));
+    hipStream_t s = (hipStream_t)stream;
+    int64_t r0 = 0;
+    while (r0 < N) {
+        int64_t R = N - r0;
+        Plan p = plan_gemm(R, H, V);
+        while (p.slab_floats(R, ldh) > ws.slab_floats) {
+            if (R <= 4) return fail(MDBN_ENOSPC, "workspace cannot hold one 4-row slab");
+            R = std::max<int64_t>(4, (R / 2 + 3) & ~int64_t(3));
+            p = plan_gemm(R, H, V);
+        }
+        GemmArgs g;
+        g.A = x + r0 * ldv; g.lda = ldv; g.B = W; g.ldb = ldh; g.C = ws.slabs; g.ldc = ldh;
+        g.slab_stride = R * ldh;
+        g.M = (int)R; g.N = (int)H; g.K = (int)V; g.Nst = (int)ldh;
+        g.kchunk = p.kchunk; g.splitk = p.splitk; g.tiles_m = p.tiles_m; g.tiles_n = p.tiles_n;
+        g.inner_m = p.tiles_m <= p.tiles_n;
+        HIP_OK(timed_gemm(LAY_K, LAY_MN, g, s));
+        HIP_OK(launch_free_energy(ws.slabs, p.splitk, g.slab_stride, ldh, (int)H, hbias, x + r0 * ldv, ldv,
+                                  (int)V, vbias, gauss, R, out + r0, s));
+        r0 += R;
+    }
+    return MDBN_OK;
+}
+
+int mdbn_rng_uniform(mdbn_ctx* ctx, void* stream, float* out, int64_t rows, int64_t cols, int64_t ld,
+                     const mdbn_rng* rng)
+{
+    REQUIRE(ctx && out && rng && rows >= 0 && cols >= 0 && ld >= cols, "bad arguments");
+    HIP_OK(launch_rng_fill(out, rows, cols, ld, make_key(*rng, rng->draw), 0, (hipStream_t)stream));
+    return MDBN_OK;
+}
+
+int mdbn_rng_normal(mdbn_ctx* ctx, void* stream, float* out, int64_t rows, int64_t cols, int64_t ld,
+                    const mdbn_rng* rng)
+{
+    REQUIRE(ctx && out && rng && rows >= 0 && cols >= 0 && ld >= cols, "bad arguments");
+    HIP_OK(launch_rng_fill(out, rows, cols, ld, make_key(*rng, rng->draw), 1, (hipStream_t)stream));
+    return MDBN_OK;
+}
+
+int mdbn_philox_host(float* out, int64_t rows, int64_t cols, int64_t ld, const mdbn_rng* rng)
+{
+    REQUIRE(out && rng && rows >= 0 && cols >= 0 && ld >= cols, "bad arguments");
+    const PhiloxKey k = make_key(*rng, rng->draw);
+    for (int64_t r = 0; r < rows; ++r) {
+        const uint64_t g = k.row_offset + (uint64_t)r;
+        for (int64_t c = 0; c < cols; ++c) {
+            uint32_t w[4];
+            philox4x32_10((uint32_t)c, (uint32_t)(g >> 2), k.draw, k.step, k.k0, k.k1, w);
+            out[r * ld + c] = philox_u01(w[g & 3]);
+        }
+    }
+    return MDBN_OK;
+}
+
+}  // extern "C"

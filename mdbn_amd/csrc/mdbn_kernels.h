@@ -1,0 +1,68 @@
+// Internal launch interface between the C-ABI (mdbn_capi.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "philox.h"
+#include "../../include/mdbn_hip.h"
+
+namespace mdbn {
+
+enum { LAY_K = 0, LAY_MN = 1 };   // operand's fastest dimension: reduction index / output index
+
+struct GemmArgs {
+    const float* A;        // LAY_K: [M][lda] ; LAY_MN: [K][lda]
+    const float* B;        // LAY_K: [N][ldb] ; LAY_MN: [K][ldb]
+    float* C;              // slabs: [splitk][M][ldc]
+    int64_t lda, ldb, ldc;
+    int64_t slab_stride;   // floats between consecutive split-K slabs
+    int M, N, K;           // logical extents (loads beyond them read as zero)
+    int Nst;               // columns stored (>= N; pad columns receive exact zeros)
+    int kchunk;            // reduction extent per split, multiple of 32
+    int splitk, tiles_m, tiles_n;
+    int inner_m;           // work-list order inside one split: 1 = tile_m fastest
+};
+
+struct EpiArgs {
+    const float* slabs;
+    int64_t slab_stride;
+    int nsplit;
+    int rows, cols;        // logical extent of the output
+    int64_t ld;            // leading dim of slabs and of pre/mean/sample
+    const float* bias;
+    float* pre;            // nullable
+    float* mean;           // nullable; stored * mean_scale
+    float* sample;         // nullable
+    float mean_scale;
+    int gauss;             // 0: sigmoid + Bernoulli ; 1: linear + N(0,1)
+    const float* target;   // nullable: reconstruction-cost target (v0)
+    int64_t ld_target;
+    float* cost_partials;  // nullable: one float per block
+    PhiloxKey rng;
+};
+
+inline int epilogue_blocks(int64_t rows, int64_t ld)
+{
+    const int64_t n = ((rows + 3) / 4) * (ld / 4);
+    return (int)((n + 255) / 256);
+}
+inline int colsum_chunks(int64_t B) { return (int)((B + 63) / 64); }
+
+hipError_t launch_gemm(int la, int lb, const GemmArgs& g, hipStream_t s);
+hipError_t launch_act_epilogue(const EpiArgs& e, hipStream_t s);
+hipError_t launch_sum_slabs(const float* slabs, int nsplit, int64_t slab_stride, int64_t n,
+                            float* out, hipStream_t s);
+hipError_t launch_gather(const float* src, int64_t n_rows, int64_t cols_ld, int64_t ld_src,
+                         const void* idx, int idx64, int64_t n_idx, float* dst, int64_t ld_dst,
+                         hipStream_t s);
+hipError_t launch_colsum_partial(const float* X, int B, int64_t ld, float* partial, hipStream_t s);
+hipError_t launch_finalize_stats(const float* partP, const float* partV, int B, int64_t ldh, int64_t ldv,
+                                 const float* cost_partials, int n_cost, float* s_h, float* s_v,
+                                 float* cost, hipStream_t s);
+hipError_t launch_update(const mdbn_update_args& a, hipStream_t s);
+hipError_t launch_free_energy(const float* slabs, int nsplit, int64_t slab_stride, int64_t ldh, int H,
+                              const float* hbias, const float* x, int64_t ldv, int V, const float* vbias,
+                              int gauss, int64_t rows, float* out, hipStream_t s);
+hipError_t launch_rng_fill(float* out, int64_t rows, int64_t cols, int64_t ld, const PhiloxKey& k,
+                           int normal, hipStream_t s);
+
+}  // namespace mdbn

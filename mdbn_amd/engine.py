@@ -1,0 +1,314 @@
+"""HipEngine: the device side of the RBM/DBN classes.
+
+Owns nothing but a context handle and scratch tensors; every method enqueues work on
+torch's current HIP stream through the C-ABI (mdbn_amd/_lib.py) and returns device
+tensors.  PyTorch is used only as the device-array container (allocation, views,
+H2D/D2H copies, streams).  There is no CPU fallback: constructing the engine without
+the built library or without a gfx950 GPU raises.
+
+Matrix convention: a device matrix is a torch view [rows, cols] over storage
+[rows, ld] with ld = round_up(cols, 4) and zero padding (``alloc_matrix``).
+"""
+import ctypes as C
+
+import numpy
+import torch
+
+from . import _lib
+
+
+def round_up4(n):
+    return (int(n) + 3) & ~3
+
+
+_default_engine = None
+
+
+def get_engine():
+    """Process-wide default engine (cuda:current device); created on first use."""
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = HipEngine()
+    return _default_engine
+
+
+def set_engine(engine):
+    """Install ``engine`` as the default (tests install a CPU checker here)."""
+    global _default_engine
+    _default_engine = engine
+    return engine
+
+
+class RngAddr(object):
+    """Address of one random matrix: see csrc/philox.h."""
+    __slots__ = ("seed", "stream_id", "step", "draw", "row_offset")
+
+    def __init__(self, seed, stream_id, step, draw=0, row_offset=0):
+        self.seed, self.stream_id, self.step = int(seed), int(stream_id), int(step)
+        self.draw, self.row_offset = int(draw), int(row_offset)
+
+    def c(self):
+        return _lib.Rng(self.seed & 0xFFFFFFFFFFFFFFFF, self.stream_id & 0xFFFFFFFF,
+                        self.step & 0xFFFFFFFF, self.draw & 0xFFFFFFFF, 0, self.row_offset)
+
+
+class CDScratch(object):
+    """Per-(B, V, H) buffers of one CD step; see mdbn_cd_args in include/mdbn_hip.h."""
+
+    def __init__(self, engine, B, V, H, need_vs):
+        self.B, self.V, self.H = B, V, H
+        self.V2 = engine.alloc_matrix(2 * B, V)
+        self.P2 = engine.alloc_matrix(2 * B, H)
+        self.hs = engine.alloc_matrix(B, H)
+        self.vs = engine.alloc_matrix(B, V) if need_vs else None
+
+
+class HipEngine(object):
+    name = "hip"
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()                      # raises if the extension is not built
+        if not torch.cuda.is_available():
+            raise _lib.MdbnError("no HIP device visible: mdbn_amd has no CPU fallback")
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        ctx = C.c_void_p()
+        _lib.check(self.lib.mdbn_ctx_create(C.byref(ctx), self.device.index or 0), "mdbn_ctx_create")
+        self.ctx = ctx
+        self._workspace = None
+        self._ws_key = (0, 0, 0)
+        self._stats = {}
+        self._scratch = {}
+        self._cost_ring = torch.zeros(1024, dtype=torch.float32, device=self.device)
+        self._cost_slot = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.mdbn_ctx_destroy(self.ctx)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ arrays
+    def alloc_matrix(self, rows, cols):
+        ld = round_up4(cols)
+        return torch.zeros((rows, ld), dtype=torch.float32, device=self.device)[:, :cols]
+
+    def alloc_vector(self, n):
+        return torch.zeros(int(n), dtype=torch.float32, device=self.device)
+
+    def to_device(self, value):
+        """numpy / tensor -> padded device matrix (2-D) or vector (1-D), float32."""
+        if isinstance(value, torch.Tensor):
+            t = value.to(device=self.device, dtype=torch.float32)
+        else:
+            t = torch.from_numpy(numpy.ascontiguousarray(value, dtype=numpy.float32)).to(self.device)
+        if t.dim() == 2:
+            if t.device == self.device and self.is_matrix(t) and t is value:
+                return t
+            out = self.alloc_matrix(t.shape[0], t.shape[1])
+            out.copy_(t)
+            return out
+        return t.contiguous()
+
+    @staticmethod
+    def is_matrix(t):
+        return (t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1
+                and t.stride(0) % 4 == 0 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0)
+
+    def as_matrix(self, x):
+        """Accept numpy arrays, tensors or SharedArray-likes; return a device matrix."""
+        t = getattr(x, "tensor", x)
+        if isinstance(t, torch.Tensor) and t.device == self.device and self.is_matrix(t):
+            return t
+        return self.to_device(t)
+
+    def to_numpy(self, t):
+        return t.detach().cpu().numpy()
+
+    def index_tensor(self, indexes):
+        """Minibatch indices -> device int32/int64 tensor (no copy if already there)."""
+        if isinstance(indexes, torch.Tensor):
+            if indexes.dtype not in (torch.int32, torch.int64):
+                indexes = indexes.to(torch.int64)
+            return indexes.to(self.device).contiguous()
+        a = numpy.asarray(indexes)
+        if a.dtype not in (numpy.int32, numpy.int64):
+            a = a.astype(numpy.int64)
+        return torch.from_numpy(numpy.ascontiguousarray(a)).to(self.device)
+
+    # ------------------------------------------------------------------ scratch
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace(self, B, V, H):
+        """One shared workspace, grown to the largest (B, V, H) seen."""
+        kB, kV, kH = self._ws_key
+        if self._workspace is None or B > kB or V > kV or H > kH:
+            B, V, H = max(B, kB), max(V, kV), max(H, kH)
+            n = C.c_int64()
+            _lib.check(self.lib.mdbn_workspace_bytes(B, V, H, C.byref(n)), "mdbn_workspace_bytes")
+            nbytes = max(n.value, 8 << 20)
+            self._workspace = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.device)
+            self._ws_key = (B, V, H)
+        return self._workspace
+
+    def stats_buffer(self, V, H):
+        key = (V, H)
+        if key not in self._stats:
+            n = C.c_int64()
+            _lib.check(self.lib.mdbn_stats_floats(V, H, C.byref(n)), "mdbn_stats_floats")
+            self._stats[key] = torch.zeros(n.value, dtype=torch.float32, device=self.device)
+        return self._stats[key]
+
+    def cd_scratch(self, B, V, H, need_vs):
+        key = (B, V, H, bool(need_vs))
+        if key not in self._scratch:
+            if len(self._scratch) > 8:
+                self._scratch.clear()
+            self._scratch[key] = CDScratch(self, B, V, H, need_vs)
+        return self._scratch[key]
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    # ------------------------------------------------------------------ propagation
+    def propup(self, v, W, hbias, rng=None, want_pre=True, want_mean=True, want_sample=True):
+        """[pre, mean, sample] of rbm.py:187-213; entries not wanted are None."""
+        v = self.as_matrix(v)
+        B, V = v.shape
+        H = W.shape[1]
+        assert W.shape[0] == V, "visible size mismatch: %d vs %d" % (V, W.shape[0])
+        pre = self.alloc_matrix(B, H) if want_pre else None
+        mean = self.alloc_matrix(B, H) if want_mean else None
+        sample = self.alloc_matrix(B, H) if want_sample else None
+        ws = self.workspace(min(B, 4096), V, H)
+        r = rng.c() if rng is not None else None
+        _lib.check(self.lib.mdbn_propup_sample(
+            self.ctx, self._stream(), self._p(v), B, v.stride(0), self._p(W), V, H, W.stride(0),
+            self._p(hbias), self._p(pre), self._p(mean), 1.0, self._p(sample),
+            C.byref(r) if r is not None else None, self._p(ws), ws.numel() * 4), "mdbn_propup_sample")
+        return pre, mean, sample
+
+    def propdown(self, h, W, vbias, gauss=False, add_noise=False, rng=None, v0=None):
+        """[pre, mean, sample] of rbm.py:215-240 (RBM) / rbm.py:647-660 (GRBM).
+        With ``v0`` also returns the un-normalised reconstruction-cost sum (device scalar)."""
+        h = self.as_matrix(h)
+        B, H = h.shape
+        V = W.shape[0]
+        assert W.shape[1] == H, "hidden size mismatch"
+        mean = self.alloc_matrix(B, V)
+        sample = self.alloc_matrix(B, V)
+        pre = mean if gauss else self.alloc_matrix(B, V)     # GRBM: "pre" is the mean (rbm.py:660)
+        ws = self.workspace(min(B, 4096), V, H)
+        r = rng.c() if rng is not None else None
+        cost = None
+        if v0 is not None:
+            v0 = self.as_matrix(v0)
+            cost = torch.zeros(4, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mdbn_propdown_sample(
+            self.ctx, self._stream(), self._p(h), B, h.stride(0), self._p(W), V, H, mean.stride(0),
+            self._p(vbias), int(bool(gauss)), int(bool(add_noise)),
+            None if gauss else self._p(pre), self._p(mean), self._p(sample),
+            C.byref(r) if r is not None else None, self._p(v0), self._p(cost),
+            self._p(ws), ws.numel() * 4), "mdbn_propdown_sample")
+        if cost is not None:
+            return pre, mean, sample, cost[0]
+        return pre, mean, sample
+
+    def free_energy(self, x, W, hbias, vbias, gauss):
+        x = self.as_matrix(x)
+        N, V = x.shape
+        H = W.shape[1]
+        out = self.alloc_vector(N)
+        ws = self.workspace(min(N, 4096), V, H)
+        _lib.check(self.lib.mdbn_free_energy(
+            self.ctx, self._stream(), self._p(x), N, x.stride(0), self._p(W), V, H, W.stride(0),
+            self._p(hbias), self._p(vbias), int(bool(gauss)), self._p(out),
+            self._p(ws), ws.numel() * 4), "mdbn_free_energy")
+        return out
+
+    def gather_rows(self, src, indexes):
+        src = self.as_matrix(src)
+        idx = self.index_tensor(indexes)
+        out = self.alloc_matrix(idx.numel(), src.shape[1])
+        _lib.check(self.lib.mdbn_gather_rows(
+            self.ctx, self._stream(), self._p(src), src.shape[0], src.shape[1], src.stride(0),
+            self._p(idx), int(idx.dtype == torch.int64), idx.numel(), self._p(out), out.stride(0)),
+            "mdbn_gather_rows")
+        return out
+
+    # ------------------------------------------------------------------ CD-k
+    def cd_step(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent=None, add_noise=False):
+        """gather + positive phase + k Gibbs steps + statistics (rbm.py:303-345,374).
+        Returns (stats, scratch): the packed [S | s_h | s_v | cost_sum] buffer and the
+        CDScratch holding ph_mean / nv_mean / nh_mean for inspection."""
+        data = self.as_matrix(data)
+        V, H = W.shape
+        assert data.shape[1] == V, "data has %d columns, RBM has %d visibles" % (data.shape[1], V)
+        idx = self.index_tensor(indexes) if indexes is not None else None
+        B = idx.numel() if idx is not None else data.shape[0]
+        sc = self.cd_scratch(B, V, H, need_vs=not gauss)
+        stats = self.stats_buffer(V, H)
+        ws = self.workspace(B, V, H)
+        a = _lib.CdArgs()
+        a.data, a.n_data = data.data_ptr(), data.shape[0]
+        a.indexes = idx.data_ptr() if idx is not None else None
+        a.index_is_64 = int(idx is not None and idx.dtype == torch.int64)
+        a.gauss, a.add_noise, a.k = int(bool(gauss)), int(bool(add_noise)), int(k)
+        a.B, a.V, a.H = B, V, H
+        a.ldv, a.ldh = data.stride(0), W.stride(0)
+        a.W, a.hbias, a.vbias = W.data_ptr(), hbias.data_ptr(), vbias.data_ptr()
+        a.persistent = persistent.data_ptr() if persistent is not None else None
+        a.V2, a.P2, a.hs = sc.V2.data_ptr(), sc.P2.data_ptr(), sc.hs.data_ptr()
+        a.vs = sc.vs.data_ptr() if sc.vs is not None else None
+        a.stats = stats.data_ptr()
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        a.rng = rng.c()
+        _lib.check(self.lib.mdbn_cd_step(self.ctx, self._stream(), C.byref(a)), "mdbn_cd_step")
+        return stats, sc
+
+    def apply_update(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats,
+                     lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale):
+        """rbm.py:347-365; returns the monitoring cost as a 0-d device tensor."""
+        V, H = W.shape
+        slot = self._cost_slot
+        self._cost_slot = (slot + 1) % self._cost_ring.numel()
+        cost = self._cost_ring[slot]
+        u = _lib.UpdateArgs()
+        u.W, u.W_speed = W.data_ptr(), W_speed.data_ptr()
+        u.W0 = W0.data_ptr() if W0 is not None else None
+        u.hbias, u.hbias_speed = hbias.data_ptr(), hbias_speed.data_ptr()
+        u.vbias, u.vbias_speed = vbias.data_ptr(), vbias_speed.data_ptr()
+        u.V, u.H, u.ldv, u.ldh = V, H, round_up4(V), W.stride(0)
+        u.stats = stats.data_ptr()
+        u.lr, u.lambda_1, u.lambda_2 = float(lr), float(lambda_1), float(lambda_2)
+        u.weightcost, u.momentum = float(weightcost), float(momentum)
+        u.batch_size, u.n_rows, u.cost_scale = float(batch_size), float(n_rows), float(cost_scale)
+        u.cost_out = cost.data_ptr()
+        _lib.check(self.lib.mdbn_apply_update(self.ctx, self._stream(), C.byref(u)), "mdbn_apply_update")
+        return cost
+
+    # ------------------------------------------------------------------ RNG (tests / utilities)
+    def rng_uniform(self, rows, cols, rng, normal=False):
+        out = self.alloc_matrix(rows, cols)
+        r = rng.c()
+        fn = self.lib.mdbn_rng_normal if normal else self.lib.mdbn_rng_uniform
+        _lib.check(fn(self.ctx, self._stream(), self._p(out), rows, cols, out.stride(0), C.byref(r)),
+                   "mdbn_rng_*")
+        return out
+
+    def kernel_timing(self, enable):
+        """Bracket every GEMM launch with HIP events (measurement only; bench.py)."""
+        _lib.check(self.lib.mdbn_kernel_timing(self.ctx, int(bool(enable))), "mdbn_kernel_timing")
+
+    def kernel_timing_read(self):
+        n, ms = C.c_int64(), C.c_double()
+        _lib.check(self.lib.mdbn_kernel_timing_read(self.ctx, C.byref(n), C.byref(ms)),
+                   "mdbn_kernel_timing_read")
+        return n.value, ms.value
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)

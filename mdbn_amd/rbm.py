@@ -1,0 +1,427 @@
+"""RBM / GRBM with the class surface of the reference's src/rbm.py, executed eagerly on
+MI355X through the HIP engine (no Theano graphs).
+
+Where the reference returns symbolic expressions these methods return device arrays
+(``SharedArray``; ``numpy.asarray`` / ``.get_value()`` bring them to the host).  The
+compiled step function of the reference -- ``theano.function(..., updates=updates,
+givens={input: train_set_x[indexes], momentum: m})`` (rbm.py:533-544, dbn.py:302-312) --
+is ``mdbn_amd.function(updates, train_set_x)``, called as ``fn(indexes=, momentum=, lr=)``.
+
+Randomness: Philox streams addressed by (seed, stream, step, draw, global row); every
+sampling call and every step-function call consumes one ``step`` (see csrc/philox.h).
+"""
+from __future__ import print_function
+
+import timeit
+
+import numpy
+import torch
+
+from . import dist as _dist
+from .engine import RngAddr, get_engine
+from .rng import RandomStreams
+from .shared import SharedArray, as_tensor, shared
+from .utils import get_minibatches_idx
+
+
+class Scalar(object):
+    """A symbolic scalar input of a step function (``tensor.scalar('lr')``, dbn.py:272)."""
+
+    def __init__(self, name):
+        self.name = name
+
+
+class CostHandle(object):
+    """What ``get_cost_updates`` returns as the monitoring cost: the value itself is
+    produced by each call of the step function (rbm.py:367-374)."""
+
+    def __init__(self, kind):
+        self.kind = kind      # 'reconstruction' | 'pseudo_likelihood'
+
+
+class UpdatePlan(object):
+    """The ``updates`` dictionary of rbm.py:353-371 in closed form: everything one
+    CD-k / PCD-k step needs, bound when ``get_cost_updates`` is called."""
+
+    def __init__(self, rbm, lr, k, lambda_1, lambda_2, weightcost, batch_size, persistent, W0):
+        self.rbm, self.lr, self.k = rbm, lr, int(k)
+        self.lambda_1, self.lambda_2, self.weightcost = lambda_1, lambda_2, weightcost
+        self.batch_size, self.persistent, self.W0 = batch_size, persistent, W0
+
+
+class StepFunction(object):
+    """One compiled training step: ``fn(indexes=, momentum=, lr=)`` -> monitoring cost
+    (0-d device tensor; ``float(cost)`` synchronises).
+
+    Data-parallel: with an initialised ``torch.distributed`` group of N ranks
+    each rank computes the statistics of its contiguous slice of the minibatch, the packed
+    [S | s_h | s_v | cost] buffer is sum-all-reduced (RCCL over xGMI), and every rank applies
+    the same update; ``batch_size`` is the global minibatch size (rbm.py:413)."""
+
+    def __init__(self, updates, train_set_x, input_fn=None, name=None, data_parallel="auto"):
+        self.plan = updates
+        self.rbm = updates.rbm
+        self.engine = self.rbm.engine
+        self.train_set_x = train_set_x
+        self.input_fn = input_fn            # maps the DBN's data matrix to this layer's input
+        self.name = name
+        self.group = _dist.default_group() if data_parallel == "auto" else data_parallel
+        self._pending = None
+
+    def _data(self):
+        if self.input_fn is not None:
+            return self.input_fn()
+        return self.engine.as_matrix(self.train_set_x)
+
+    def __call__(self, indexes=None, momentum=0.0, lr=None):
+        p, rbm, eng = self.plan, self.rbm, self.engine
+        if lr is None:
+            lr = p.lr
+        if isinstance(lr, Scalar):
+            raise TypeError("step function needs lr= (learning rate is a symbolic input)")
+        data = self._data()
+        n_global = data.shape[0] if indexes is None else len(indexes)
+        batch_size = p.batch_size if p.batch_size is not None else n_global
+
+        # data-parallel shard of the minibatch: contiguous rows [lo, hi) of `indexes`
+        lo, hi = 0, n_global
+        if self.group is not None:
+            lo, hi = self.group.shard(n_global)
+        if indexes is None:
+            idx = None if (lo == 0 and hi == data.shape[0]) else \
+                torch.arange(lo, hi, dtype=torch.int64, device=data.device)
+        else:
+            idx = eng.index_tensor(indexes)[lo:hi]
+        step = rbm._take_step()
+        persistent = None
+        if p.persistent is not None:
+            if self.group is not None and self.group.world_size > 1:
+                raise NotImplementedError("PCD chains are not sharded across ranks yet")
+            persistent = p.persistent.tensor
+            if persistent.shape[0] != n_global:
+                raise ValueError("persistent chain has %d rows but the minibatch has %d "
+                                 "(the reference fails the same way, rbm.py:416)"
+                                 % (persistent.shape[0], n_global))
+        if hi > lo:
+            stats, _ = eng.cd_step(data, idx, rbm.W.tensor, rbm.hbias.tensor, rbm.vbias.tensor,
+                                   rbm.gauss, p.k,
+                                   RngAddr(rbm.theano_rng.seed, rbm.stream_id, step, 0, lo),
+                                   persistent=persistent)
+        else:                                  # this rank holds no row of a short minibatch
+            stats = eng.stats_buffer(rbm.n_visible, rbm.n_hidden)
+            stats.zero_()
+        if self.group is not None and self.group.world_size > 1:
+            self.group.all_reduce_sum(stats)
+
+        if p.persistent is not None:
+            # PCD monitors the pseudo-likelihood (rbm.py:371) with pre-update parameters
+            cost = rbm._pseudo_likelihood_value(eng.gather_rows(data, idx) if idx is not None else data)
+            cost_scale = 0.0
+        else:
+            cost = None
+            # rbm.py:480 (sum over units, mean over rows) / rbm.py:697 (mean over everything)
+            cost_scale = 1.0 / (n_global * rbm.n_visible) if rbm.gauss else 1.0 / n_global
+        out = eng.apply_update(rbm.W.tensor, rbm.W_speed.tensor,
+                               p.W0.tensor if p.W0 is not None else None,
+                               rbm.hbias.tensor, rbm.hbias_speed.tensor,
+                               rbm.vbias.tensor, rbm.vbias_speed.tensor, stats,
+                               lr, p.lambda_1, p.lambda_2, p.weightcost, momentum,
+                               batch_size, n_global, cost_scale)
+        rbm._n_updates += 1
+        return cost if cost is not None else out
+
+
+def function(updates, train_set_x=None, input_fn=None, name=None, data_parallel="auto"):
+    """Stand-in for ``theano.function([indexes, momentum, lr], cost, updates=updates,
+    givens={x: train_set_x[indexes], rbm.momentum: momentum})`` (dbn.py:302-312)."""
+    return StepFunction(updates, train_set_x, input_fn=input_fn, name=name,
+                        data_parallel=data_parallel)
+
+
+class RBM(object):
+    """Restricted Boltzmann Machine (RBM) -- Bernoulli visible and hidden units."""
+
+    gauss = False
+
+    def __init__(self, input=None, n_visible=784, n_hidden=500, W=None, hbias=None,
+                 vbias=None, numpy_rng=None, theano_rng=None, engine=None):
+        """Same arguments as reference rbm.py:49-59.  ``W`` / ``hbias`` / ``vbias`` may be
+        ``SharedArray`` objects shared with another network (a DBN's HiddenLayer),
+        ndarrays, or None (initialised as rbm.py:100-131).  ``theano_rng`` is a
+        ``mdbn_amd.RandomStreams``."""
+        self.engine = engine if engine is not None else get_engine()
+        self.n_visible = n_visible
+        self.n_hidden = n_hidden
+
+        if numpy_rng is None:
+            numpy_rng = numpy.random.RandomState(1234)             # rbm.py:87-89
+        if theano_rng is None:
+            theano_rng = RandomStreams(numpy_rng.randint(2 ** 30))  # rbm.py:91-92
+
+        if W is None:
+            bound = 4 * numpy.sqrt(6. / (n_hidden + n_visible))     # rbm.py:100-107
+            initial_W = numpy.asarray(numpy_rng.uniform(low=-bound, high=bound,
+                                                        size=(n_visible, n_hidden)),
+                                      dtype=numpy.float32)
+            W = shared(initial_W, name='W', engine=self.engine)
+        if hbias is None:
+            hbias = shared(numpy.zeros(n_hidden, dtype=numpy.float32), name='hbias', engine=self.engine)
+        if vbias is None:
+            vbias = shared(numpy.zeros(n_visible, dtype=numpy.float32), name='vbias', engine=self.engine)
+
+        self.input = input                     # None: the data rows themselves
+        self.W = shared(W, name='W', engine=self.engine)
+        self.hbias = shared(hbias, name='hbias', engine=self.engine)
+        self.vbias = shared(vbias, name='vbias', engine=self.engine)
+        if self.W.shape != (n_visible, n_hidden):
+            raise ValueError("W has shape %r, expected %r" % (self.W.shape, (n_visible, n_hidden)))
+        self.theano_rng = theano_rng
+        self.stream_id = theano_rng.new_stream()
+        self.params = [self.W, self.hbias, self.vbias]
+
+        self.momentum = 0.0                    # rbm.py:151; supplied per step-function call
+
+        z = numpy.zeros
+        self.W_speed = shared(z((n_visible, n_hidden), numpy.float32), name='W_speed', engine=self.engine)
+        self.hbias_speed = shared(z(n_hidden, numpy.float32), name='hbias_speed', engine=self.engine)
+        self.vbias_speed = shared(z(n_visible, numpy.float32), name='vbias_speed', engine=self.engine)
+        self.params_speed = [self.W_speed, self.hbias_speed, self.vbias_speed]
+
+        # rbm.py:415 captures W.get_value() when the update graph is built: a frozen
+        # snapshot.  strict_reference=False uses the live W instead.
+        self.strict_reference = True
+        self.bit_i_idx = 0                     # rbm.py:425
+        self._rng_step = 0
+        self._n_updates = 0
+
+    @property
+    def Wt(self):
+        """rbm.py:139: a transposed view; the kernels read W transposed in place."""
+        return self.W.tensor.t()
+
+    # ------------------------------------------------------------------ helpers
+    def _take_step(self):
+        s = self._rng_step
+        self._rng_step += 1
+        return s
+
+    def _rng(self, draw=0):
+        return RngAddr(self.theano_rng.seed, self.stream_id, self._take_step(), draw, 0)
+
+    def _wrap(self, t):
+        return None if t is None else SharedArray(None, engine=self.engine, _tensor=t)
+
+    # ------------------------------------------------------------------ energies
+    def free_energy(self, v_sample):
+        ''' Function to compute the free energy (rbm.py:166-171) '''
+        return self._wrap(self.engine.free_energy(as_tensor(v_sample, self.engine), self.W.tensor,
+                                                  self.hbias.tensor, self.vbias.tensor, self.gauss))
+
+    def free_energy_gap(self, train, test):
+        """mean F(test) - mean F(train) (rbm.py:173-180); returns a Python float."""
+        ft, fs = self.free_energy(train).tensor, self.free_energy(test).tensor
+        return float(fs.mean() - ft.mean())
+
+    def free_energies(self, train, test):
+        """rbm.py:182-185, evaluated: two host vectors (as dbn.py:498-501 consumes them)."""
+        return self.free_energy(train).get_value(), self.free_energy(test).get_value()
+
+    # ------------------------------------------------------------------ propagation
+    def propup(self, vis):
+        '''[pre_sigmoid_activation, sigmoid(pre)] (rbm.py:187-199)'''
+        pre, mean, _ = self.engine.propup(as_tensor(vis, self.engine), self.W.tensor, self.hbias.tensor,
+                                          want_sample=False)
+        return [self._wrap(pre), self._wrap(mean)]
+
+    def sample_h_given_v(self, v0_sample):
+        ''' [pre_sigmoid_h1, h1_mean, h1_sample] (rbm.py:201-213) '''
+        pre, mean, sample = self.engine.propup(as_tensor(v0_sample, self.engine), self.W.tensor,
+                                               self.hbias.tensor, rng=self._rng())
+        return [self._wrap(pre), self._wrap(mean), self._wrap(sample)]
+
+    def propdown(self, hid):
+        '''[pre_sigmoid_activation, sigmoid(pre)] (rbm.py:215-227)'''
+        pre, mean, _ = self.engine.propdown(as_tensor(hid, self.engine), self.W.tensor, self.vbias.tensor,
+                                            gauss=False, rng=self._rng())
+        return [self._wrap(pre), self._wrap(mean)]
+
+    def sample_v_given_h(self, h0_sample):
+        ''' [pre_sigmoid_v1, v1_mean, v1_sample] (rbm.py:229-240) '''
+        pre, mean, sample = self.engine.propdown(as_tensor(h0_sample, self.engine), self.W.tensor,
+                                                 self.vbias.tensor, gauss=False, rng=self._rng())
+        return [self._wrap(pre), self._wrap(mean), self._wrap(sample)]
+
+    def gibbs_hvh(self, h0_sample):
+        ''' One Gibbs step starting from the hidden state (rbm.py:242-248) '''
+        pre_sigmoid_v1, v1_mean, v1_sample = self.sample_v_given_h(h0_sample)
+        pre_sigmoid_h1, h1_mean, h1_sample = self.sample_h_given_v(v1_sample)
+        return [pre_sigmoid_v1, v1_mean, v1_sample,
+                pre_sigmoid_h1, h1_mean, h1_sample]
+
+    def gibbs_vhv(self, v0_sample):
+        ''' One Gibbs step starting from the visible state (rbm.py:250-256) '''
+        pre_sigmoid_h1, h1_mean, h1_sample = self.sample_h_given_v(v0_sample)
+        pre_sigmoid_v1, v1_mean, v1_sample = self.sample_v_given_h(h1_sample)
+        return [pre_sigmoid_h1, h1_mean, h1_sample,
+                pre_sigmoid_v1, v1_mean, v1_sample]
+
+    # ------------------------------------------------------------------ CD-k / PCD-k
+    def get_cost_updates(self, lr=0.1, k=1, lambda_1=0.0, lambda_2=0.0, weightcost=0.0,
+                         batch_size=None, persistent=None, symbolic_grad=False):
+        """One step of CD-k or PCD-k (rbm.py:258-376).  Returns ``(cost, updates)``; pass
+        ``updates`` to ``mdbn_amd.function`` to obtain the step function.
+
+        ``lr`` may be a float or a ``Scalar`` (then the step function takes ``lr=``).
+        ``persistent``: None for CD, a SharedArray [batch_size, n_hidden] for PCD."""
+        if symbolic_grad:
+            raise NotImplementedError(
+                "symbolic_grad=True (rbm.py:378-390) is never selected by the reference's callers "
+                "and has no device kernel; the RBM-specific gradient (rbm.py:392-419) is used")
+        W0 = None
+        if weightcost != 0.0 and self.strict_reference:
+            W0 = SharedArray(None, engine=self.engine, _tensor=self.W.tensor.clone())   # rbm.py:415
+        if persistent is not None:
+            persistent = shared(persistent, engine=self.engine)
+        updates = UpdatePlan(self, lr, k, lambda_1, lambda_2, weightcost, batch_size, persistent, W0)
+        cost = CostHandle('pseudo_likelihood' if persistent is not None else 'reconstruction')
+        return cost, updates
+
+    def _pseudo_likelihood_value(self, x):
+        """rbm.py:421-447 on the current minibatch; advances bit_i_idx (rbm.py:445)."""
+        xi = torch.sign(x) * torch.floor(torch.abs(x) + 0.5)          # tensor.round, SURVEY 8c
+        xi = self.engine.as_matrix(xi)
+        fe_xi = self.engine.free_energy(xi, self.W.tensor, self.hbias.tensor, self.vbias.tensor, self.gauss)
+        xi_flip = xi.clone()
+        xi_flip[:, self.bit_i_idx] = 1 - xi[:, self.bit_i_idx]
+        fe_flip = self.engine.free_energy(self.engine.as_matrix(xi_flip), self.W.tensor, self.hbias.tensor,
+                                          self.vbias.tensor, self.gauss)
+        cost = -torch.mean(self.n_visible * torch.nn.functional.softplus(fe_xi - fe_flip))
+        self.bit_i_idx = (self.bit_i_idx + 1) % self.n_visible
+        return cost
+
+    def get_pseudo_likelihood_cost(self, v):
+        """Stochastic approximation to the pseudo-likelihood (rbm.py:421-447) of rows ``v``."""
+        return float(self._pseudo_likelihood_value(as_tensor(v, self.engine)))
+
+    def get_reconstruction_cost(self, pre_sigmoid_nv, v0):
+        """rbm.py:449-482 evaluated on given arrays (monitoring helper; the step function
+        computes the same quantity fused into the last propdown)."""
+        x = as_tensor(pre_sigmoid_nv, self.engine)
+        t = as_tensor(v0, self.engine)
+        sp = torch.nn.functional.softplus
+        return float((t * sp(-x) + (1 - t) * sp(x)).sum(dim=1).mean())
+
+    # ------------------------------------------------------------------ stand-alone trainer
+    def training(self, train_set_x, validation_set_x, training_epochs, batch_size=10,
+                 learning_rate=0.1, k=1, initial_momentum=0.0, final_momentum=0.0,
+                 weightcost=0.0, lambda_2=0.0, persistent=True, display_fn=None, graph_output=False):
+        """rbm.py:484-520 (note: like the reference, ``lambda_2`` is accepted but not used)."""
+        if persistent:
+            persistent_chain = shared(numpy.zeros((batch_size, self.n_hidden), dtype=numpy.float32),
+                                      engine=self.engine)               # rbm.py:496-498
+        else:
+            persistent_chain = None
+        cost, updates = self.get_cost_updates(lr=learning_rate, k=k, weightcost=weightcost,
+                                              batch_size=batch_size, persistent=persistent_chain)
+        return self.learn_model(train_set_x=train_set_x, validation_set_x=validation_set_x,
+                                training_epochs=training_epochs, batch_size=batch_size,
+                                initial_momentum=initial_momentum, final_momentum=final_momentum,
+                                cost=cost, updates=updates, display_fn=display_fn,
+                                graph_output=graph_output)
+
+    def learn_model(self, train_set_x, validation_set_x, training_epochs, batch_size,
+                    initial_momentum, final_momentum, cost, updates, display_fn, graph_output,
+                    verbose=True, shuffle_rng=None):
+        """Epoch loop of rbm.py:522-629.  ``display_fn`` / ``graph_output`` are accepted and
+        ignored (plotting is outside the engine).  Returns the per-epoch (cost, gap) list."""
+        train_set_x = shared(train_set_x, engine=self.engine)
+        validation_set_x = shared(validation_set_x, engine=self.engine) if validation_set_x is not None else None
+        train_rbm = function(updates, train_set_x, name='train_rbm')
+        n_train_data = train_set_x.shape[0]
+        n_val = validation_set_x.shape[0] if validation_set_x is not None else 0
+        history = []
+        start_time = timeit.default_timer()
+        momentum = initial_momentum
+        for epoch in range(training_epochs):
+            if epoch == 6:                                               # rbm.py:584-585
+                momentum = final_momentum
+            _, minibatches = get_minibatches_idx(n_train_data, batch_size, shuffle=True, rng=shuffle_rng)
+            dev_idx = self.engine.index_tensor(numpy.concatenate(minibatches))
+            # costs are views into the engine's ring of device scalars: fold them into a
+            # running sum well before the ring wraps, without synchronising
+            costs, start, total = [], 0, 0.0
+            for batch_indexes in minibatches:
+                n = len(batch_indexes)
+                costs.append(train_rbm(dev_idx[start:start + n], momentum).reshape(()))
+                start += n
+                if len(costs) >= 256:
+                    total = total + torch.stack(costs).sum()
+                    costs = []
+            if costs:
+                total = total + torch.stack(costs).sum()
+            mean_cost = float(total) / len(minibatches)
+            feg = None
+            if n_val:
+                # rbm.py:597: gap between the first n_val training rows and the validation set
+                feg = self.free_energy_gap(train_set_x[numpy.arange(n_val)], validation_set_x)
+            if verbose:
+                print('Training epoch %d, cost is ' % epoch, mean_cost)
+                print('Free energy gap is ', feg)
+            history.append((mean_cost, feg))
+        end_time = timeit.default_timer()
+        if verbose:
+            print('Training took %f minutes' % ((end_time - start_time) / 60.))
+        return history
+
+
+class GRBM(RBM):
+    """Gaussian-Bernoulli RBM, unit variance, mean-field visibles (rbm.py:631-728)."""
+
+    gauss = True
+
+    def __init__(self, input=None, n_visible=784, n_hidden=500, W=None, hbias=None, vbias=None,
+                 numpy_rng=None, theano_rng=None, error_free=True, engine=None):
+        super(GRBM, self).__init__(input, n_visible, n_hidden, W, hbias, vbias, numpy_rng,
+                                   theano_rng, engine=engine)
+        self.error_free = error_free
+
+    def sample_v_given_h(self, h0_sample):
+        ''' [v1_mean, v1_mean, v1_sample]; linear mean, optional N(0,1) noise (rbm.py:647-660) '''
+        pre, mean, sample = self.engine.propdown(as_tensor(h0_sample, self.engine), self.W.tensor,
+                                                 self.vbias.tensor, gauss=True,
+                                                 add_noise=not self.error_free, rng=self._rng())
+        return [self._wrap(mean), self._wrap(mean), self._wrap(sample)]
+
+    def gibbs_hvh(self, h0_sample):
+        ''' Gibbs step from the hidden state; h1 from the visible MEAN (rbm.py:662-671) '''
+        pre_sigmoid_v1, v1_mean, v1_sample = self.sample_v_given_h(h0_sample)
+        pre_sigmoid_h1, h1_mean, h1_sample = self.sample_h_given_v(v1_mean)
+        return [pre_sigmoid_v1, v1_mean, v1_sample,
+                pre_sigmoid_h1, h1_mean, h1_sample]
+
+    def gibbs_vhv(self, v0_sample):
+        ''' Gibbs step from the visible state; v1 from the hidden MEAN (rbm.py:673-682) '''
+        pre_sigmoid_h1, h1_mean, h1_sample = self.sample_h_given_v(v0_sample)
+        pre_sigmoid_v1, v1_mean, v1_sample = self.sample_v_given_h(h1_mean)
+        return [pre_sigmoid_h1, h1_mean, h1_sample,
+                pre_sigmoid_v1, v1_mean, v1_sample]
+
+    def get_reconstruction_cost(self, pre_sigmoid_nv, v0):
+        """mean((sigmoid(v1_mean) - v0)^2) over samples and features (rbm.py:690-699)."""
+        x = as_tensor(pre_sigmoid_nv, self.engine)
+        t = as_tensor(v0, self.engine)
+        return float(((torch.sigmoid(x) - t) ** 2).mean())
+
+    def training(self, train_set_x, validation_set_x, training_epochs, batch_size=10,
+                 learning_rate=0.01, k=1, initial_momentum=0.0, final_momentum=0.0,
+                 weightcost=0.0, lambda_1=0.0, lambda_2=0.1, persistent=False,
+                 display_fn=None, graph_output=False):
+        """rbm.py:701-728: always CD (``persistent`` is ignored, as in the reference)."""
+        cost, updates = self.get_cost_updates(lr=learning_rate, k=k, lambda_1=lambda_1,
+                                              lambda_2=lambda_2, weightcost=weightcost,
+                                              batch_size=batch_size)
+        return self.learn_model(train_set_x=train_set_x, validation_set_x=validation_set_x,
+                                training_epochs=training_epochs, batch_size=batch_size,
+                                initial_momentum=initial_momentum, final_momentum=final_momentum,
+                                cost=cost, updates=updates, display_fn=display_fn,
+                                graph_output=graph_output)

@@ -1,0 +1,40 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """The in-tree libmdbn_hip.so (built on demand; hipcc cross-compiles without a GPU)."""
+    from mdbn_amd.build import build_lib
+    return build_lib()
+
+
+@pytest.fixture(scope="session")
+def hip_engine(built_lib):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import mdbn_amd
+    return mdbn_amd.set_engine(mdbn_amd.HipEngine())
+
+
+@pytest.fixture()
+def oracle_engine():
+    """CPU checker engine (tests/_oracle_engine.py) installed as the default engine."""
+    import mdbn_amd
+    from _oracle_engine import OracleEngine
+    import mdbn_amd.engine as E
+    prev = E._default_engine
+    eng = mdbn_amd.set_engine(OracleEngine())
+    yield eng
+    E._default_engine = prev

@@ -1,0 +1,78 @@
+"""Committed golden vectors (tests/golden/cd_cases.npz, made by tests/golden/make_golden.py):
+CPU leg -- the oracle still reproduces them; GPU leg -- the HIP path, driven through the
+RBM/GRBM classes and the C-ABI, matches them to the tolerances of SURVEY 8d."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+mg = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(mg)
+
+GOLD = np.load(os.path.join(HERE, "golden", "cd_cases.npz"))
+IDS = [c[0] for c in mg.CASES]
+
+
+@pytest.mark.parametrize("case", mg.CASES, ids=IDS)
+def test_oracle_reproduces_golden(case):
+    name, V, H, B, k, gauss, hp = case
+    out = mg.run_case(V, H, B, k, gauss, hp)
+    for key, val in out.items():
+        np.testing.assert_allclose(val, GOLD["%s/%s" % (name, key)], rtol=1e-12, atol=1e-14, err_msg=key)
+
+
+def _run_device(engine, case):
+    import mdbn_amd
+    name, V, H, B, k, gauss, hp = case
+    W, data, idx = mg.make_inputs(V, H, B, gauss)
+    cls = mdbn_amd.GRBM if gauss else mdbn_amd.RBM
+    rbm = cls(n_visible=V, n_hidden=H, W=W, theano_rng=mdbn_amd.RandomStreams(mg.SEED), engine=engine)
+    hp = dict(hp)
+    momentum = hp.pop("momentum")
+    _, updates = rbm.get_cost_updates(k=k, batch_size=B, **hp)
+    fn = mdbn_amd.function(updates, mdbn_amd.shared(data, engine=engine), data_parallel=None)
+    out = {}
+    for t in range(mg.N_STEPS):
+        out["cost_%d" % t] = float(fn(indexes=idx[t], momentum=momentum))
+        if t == 0:
+            sc = engine.cd_scratch(B, V, H, need_vs=not gauss)
+            st = engine.stats_buffer(V, H).cpu().numpy()
+            ldh = (H + 3) // 4 * 4
+            out["ph_mean"] = mg.sub(sc.P2[:B].cpu().numpy())
+            out["nh_mean"] = mg.sub(-sc.P2[B:].cpu().numpy())
+            out["nv_mean"] = mg.sub(sc.V2[B:].cpu().numpy())
+            out["ph_sample"] = mg.sub(sc.hs.cpu().numpy()) if k == 1 else None
+            out["S"] = mg.sub(st[:V * ldh].reshape(V, ldh)[:, :H])
+            out["s_h"] = mg.sub(st[V * ldh:V * ldh + H])
+            out["s_v"] = mg.sub(st[V * ldh + ldh:V * ldh + ldh + V])
+    for key in ("W", "hbias", "vbias", "W_speed", "hbias_speed", "vbias_speed"):
+        out[key] = mg.sub(getattr(rbm, key).get_value())
+    out["free_energy"] = rbm.free_energy(data[:B]).get_value()
+    return out
+
+
+# absolute tolerances, fp32 device vs f64 golden; S and the speeds scale with B
+TOL = dict(ph_mean=2e-6, nh_mean=5e-6, nv_mean=2e-5, s_h=2e-5, s_v=2e-4, W=2e-6, hbias=2e-6,
+           vbias=2e-6, W_speed=5e-6, hbias_speed=5e-6, vbias_speed=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", mg.CASES, ids=IDS)
+def test_device_matches_golden(hip_engine, case):
+    name = case[0]
+    out = _run_device(hip_engine, case)
+    g = lambda k: GOLD["%s/%s" % (name, k)]
+    if out["ph_sample"] is not None:
+        assert np.array_equal(out["ph_sample"], g("ph_sample")), "Bernoulli samples differ"
+    for key, tol in TOL.items():
+        np.testing.assert_allclose(out[key], g(key), rtol=0, atol=tol * max(1.0, np.abs(g(key)).max()), err_msg=key)
+    S = g("S")
+    np.testing.assert_allclose(out["S"], S, rtol=0, atol=1e-5 * max(1.0, np.abs(S).max()), err_msg="S")
+    for t in range(mg.N_STEPS):
+        assert abs(out["cost_%d" % t] - g("cost_%d" % t)) <= 1e-5 * abs(g("cost_%d" % t)) + 1e-7
+    F = g("free_energy")
+    np.testing.assert_allclose(out["free_energy"], F, rtol=1e-4, atol=1e-4)   # north star: 1e-4 relative
+    assert np.abs(out["free_energy"] - F).max() <= 1e-5 * np.abs(F).max() + 1e-5

@@ -1,0 +1,277 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the oracle on the same
+seeded inputs, plus size-independent properties at BASELINE's full size.  Tolerances are
+fp32-device vs float64-oracle: probabilities 2e-6 abs, free energy 1e-4 rel
+(north star), Bernoulli samples exact outside the near-tie mask |u - p| < 1e-6."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox_np, rbm_np
+from oracle.philox_np import PhiloxDraws
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(6, 4, 3), (64, 32, 8), (130, 70, 37), (784, 500, 20), (1000, 333, 129), (4096, 1024, 512)]
+
+
+def make(V, H, B, gauss, seed=0, dtype=np.float32):
+    rs = np.random.RandomState(seed)
+    W = rbm_np.init_W(rs, V, H, dtype)
+    hb = rs.normal(0, 0.2, H).astype(dtype)
+    vb = rs.normal(0, 0.2, V).astype(dtype)
+    x = rs.normal(size=(B, V)).astype(dtype) if gauss else (rs.uniform(size=(B, V)) < 0.3).astype(dtype)
+    return W, hb, vb, x
+
+
+def state64(W, hb, vb, gauss):
+    return rbm_np.RBMState(W.shape[0], W.shape[1], W=W, hbias=hb, vbias=vb, dtype=np.float64, gauss=gauss)
+
+
+def dev(eng, *arrays):
+    return [eng.to_device(a) for a in arrays]
+
+
+@pytest.mark.parametrize("rows,cols,off", [(1, 1, 0), (7, 5, 0), (9, 6, 3), (64, 33, 1022), (512, 1024, 512)])
+def test_device_rng_is_bit_exact(hip_engine, rows, cols, off):
+    from mdbn_amd import RngAddr
+    addr = RngAddr(0x1234ABCD5678, 3, 41, 2, off)
+    got = hip_engine.rng_uniform(rows, cols, addr).cpu().numpy()
+    assert np.array_equal(got, philox_np.uniform(rows, cols, addr.seed, 3, 41, 2, off))
+    z = hip_engine.rng_uniform(rows, cols, addr, normal=True).cpu().numpy()
+    np.testing.assert_allclose(z, philox_np.normal(rows, cols, addr.seed, 3, 41, 2, off), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("V,H,B", SHAPES)
+def test_propup_sample(hip_engine, V, H, B):
+    from mdbn_amd import RngAddr
+    W, hb, vb, x = make(V, H, B, True, seed=V)
+    dW, dhb, dx = dev(hip_engine, W, hb, x)
+    addr = RngAddr(77, 1, 5, 0, 8)
+    pre, mean, sample = [t.cpu().numpy() for t in hip_engine.propup(dx, dW, dhb, rng=addr)]
+    s = state64(W, hb, vb, True)
+    pre_o, mean_o = rbm_np.propup(s, x.astype(np.float64))
+    assert np.abs(mean - mean_o).max() <= 2e-6
+    assert np.abs(pre - pre_o).max() <= 2e-6 * max(1.0, np.abs(pre_o).max()) * 4
+    u = philox_np.uniform(B, H, 77, 1, 5, 0, 8).astype(np.float64)
+    want = (u < mean_o).astype(np.float32)
+    bad = sample != want
+    assert np.all(np.abs(u - mean_o)[bad] < 1e-6), "sample mismatch outside the near-tie mask"
+    assert bad.sum() <= 2
+    assert set(np.unique(sample)) <= {0.0, 1.0}
+
+
+@pytest.mark.parametrize("V,H,B", SHAPES)
+@pytest.mark.parametrize("gauss", [False, True])
+def test_propdown_sample(hip_engine, V, H, B, gauss):
+    from mdbn_amd import RngAddr
+    W, hb, vb, x = make(V, H, B, gauss, seed=H)
+    h = (np.random.RandomState(1).uniform(size=(B, H)) < 0.5).astype(np.float32)
+    dW, dvb, dh, dx = dev(hip_engine, W, vb, h, x)
+    addr = RngAddr(78, 2, 6, 3, 0)
+    pre, mean, sample, cost = hip_engine.propdown(dh, dW, dvb, gauss=gauss, add_noise=gauss, rng=addr, v0=dx)
+    pre, mean, sample, cost = pre.cpu().numpy(), mean.cpu().numpy(), sample.cpu().numpy(), float(cost)
+    s = state64(W, hb, vb, gauss)
+    s.error_free = False
+    h64 = h.astype(np.float64)
+    if gauss:
+        z = philox_np.normal(B, V, 78, 2, 6, 3, 0)
+        pre_o, mean_o, samp_o = rbm_np.sample_v_given_h(s, h64, z)
+        assert np.abs(mean - mean_o).max() <= 4e-6 * max(1.0, np.abs(mean_o).max())
+        assert np.abs(sample - samp_o).max() <= 5e-5
+        want_cost = ((rbm_np.sigmoid(mean_o) - x) ** 2).sum()
+    else:
+        u = philox_np.uniform(B, V, 78, 2, 6, 3, 0).astype(np.float64)
+        pre_o, mean_o, samp_o = rbm_np.sample_v_given_h(s, h64, u)
+        assert np.abs(mean - mean_o).max() <= 2e-6
+        bad = sample != samp_o
+        assert np.all(np.abs(u - mean_o)[bad] < 1e-6) and bad.sum() <= 2
+        want_cost = (x * rbm_np.softplus(-pre_o) + (1 - x) * rbm_np.softplus(pre_o)).sum()
+    assert abs(cost - want_cost) <= 2e-5 * abs(want_cost) + 1e-6
+
+
+@pytest.mark.parametrize("V,H,B", SHAPES)
+@pytest.mark.parametrize("gauss", [False, True])
+def test_free_energy(hip_engine, V, H, B, gauss):
+    W, hb, vb, x = make(V, H, B, gauss, seed=B)
+    dW, dhb, dvb, dx = dev(hip_engine, W, hb, vb, x)
+    F = hip_engine.free_energy(dx, dW, dhb, dvb, gauss).cpu().numpy()
+    F_o = rbm_np.free_energy(state64(W, hb, vb, gauss), x.astype(np.float64))
+    rel = np.abs(F - F_o) / np.maximum(np.abs(F_o), 1.0)
+    assert rel.max() <= 1e-4, rel.max()            # north-star bound
+    assert rel.max() <= 2e-6, rel.max()            # what fp32 MFMA accumulation actually gives
+
+
+@pytest.mark.parametrize("V,H,B,k", [(6, 4, 3, 1), (64, 32, 8, 3), (130, 70, 37, 2), (784, 500, 20, 1),
+                                     (4096, 1024, 512, 1)])
+@pytest.mark.parametrize("gauss", [False, True])
+def test_cd_step_statistics(hip_engine, V, H, B, k, gauss):
+    """Chain + statistics of one CD-k step vs the oracle.  The oracle's chain is started
+    from the DEVICE's positive-phase sample (checked against the twin first) so that a
+    near-tie flip cannot fork the two chains (teacher forcing)."""
+    from mdbn_amd import RngAddr
+    W, hb, vb, x = make(V, H, B, gauss, seed=V + k)
+    N = 3 * B
+    data = np.concatenate([x, x[::-1], x])[:N]
+    idx = np.random.RandomState(2).permutation(N)[:B].astype(np.int64)
+    dW, dhb, dvb, ddata = dev(hip_engine, W, hb, vb, data)
+    addr = RngAddr(4242, 1, 9, 0, 0)
+    stats, sc = hip_engine.cd_step(ddata, idx, dW, dhb, dvb, gauss, k, addr)
+    hip_engine.synchronize()
+    ldh, ldv = sc.P2.stride(0), sc.V2.stride(0)
+    st = stats.cpu().numpy()
+    S = st[:V * ldh].reshape(V, ldh)
+    assert not S[:, H:].any(), "pad columns of S must stay zero"
+    S = S[:, :H]
+    s_h, s_v = st[V * ldh:V * ldh + H], st[V * ldh + ldh:V * ldh + ldh + V]
+    cost = st[V * ldh + ldh + ldv]
+    v0_d = sc.V2[:B].cpu().numpy()
+    assert np.array_equal(v0_d, data[idx]), "gather"
+
+    s = state64(W, hb, vb, gauss)
+    v0 = data[idx].astype(np.float64)
+    draws = PhiloxDraws(4242, 1, 9, 0)
+    ph_mean, ph_sample, out = rbm_np.cd_chain(s, v0, draws, k)
+    assert np.abs(sc.P2[:B].cpu().numpy() - ph_mean).max() <= 2e-6
+    if k == 1:
+        hs = sc.hs.cpu().numpy()
+        bad = hs != ph_sample
+        assert np.all(np.abs(draws.u(0, B, H) - ph_mean)[bad] < 1e-6)
+        if bad.any():                       # re-run the oracle chain from the device's sample
+            dv = None if gauss else draws.u(1, B, V)
+            out = rbm_np.gibbs_hvh(s, hs.astype(np.float64), dv, draws.u(2, B, H))
+    pre_nv, nv_mean, nv_sample, pre_nh, nh_mean, nh_sample = out
+    scale_v = max(1.0, np.abs(nv_mean).max())
+    assert np.abs(sc.V2[B:].cpu().numpy() - nv_mean).max() <= 4e-6 * scale_v
+    assert np.abs(-sc.P2[B:].cpu().numpy() - nh_mean).max() <= 4e-6
+    S_o, s_h_o, s_v_o = rbm_np.cd_statistics(v0, ph_mean, nv_mean, nh_mean)
+    assert np.abs(S - S_o).max() <= 1e-5 * max(1.0, np.abs(S_o).max())
+    assert np.abs(s_h - s_h_o).max() <= 1e-5 * max(1.0, np.abs(s_h_o).max())
+    assert np.abs(s_v - s_v_o).max() <= 1e-5 * max(1.0, np.abs(s_v_o).max())
+    if gauss:
+        cost_o = ((rbm_np.sigmoid(pre_nv) - v0) ** 2).sum()
+    else:
+        cost_o = (v0 * rbm_np.softplus(-pre_nv) + (1 - v0) * rbm_np.softplus(pre_nv)).sum()
+    assert abs(cost - cost_o) <= 2e-5 * abs(cost_o)
+
+
+@pytest.mark.parametrize("V,H", [(6, 4), (130, 70), (784, 500), (4096, 1024)])
+@pytest.mark.parametrize("l1,l2,wc,mu,frozen", [(0.0, 0.1, 0.0, 0.0, False), (0.01, 0.01, 0.0, 0.0, False),
+                                                 (0.0, 0.0, 2e-4, 0.9, True), (0.01, 0.1, 2e-4, 0.6, False)])
+def test_apply_update(hip_engine, V, H, l1, l2, wc, mu, frozen):
+    rs = np.random.RandomState(V)
+    ldh, ldv = (H + 3) // 4 * 4, (V + 3) // 4 * 4
+    W = rbm_np.init_W(rs, V, H, np.float32)
+    W[0, 0] = 0.0                                             # exercises the epsilon in the shrink
+    Ws = rs.normal(0, 0.01, (V, H)).astype(np.float32)
+    W0 = rbm_np.init_W(rs, V, H, np.float32)
+    hb, hbs = rs.normal(size=H).astype(np.float32), rs.normal(size=H).astype(np.float32)
+    vb, vbs = rs.normal(size=V).astype(np.float32), rs.normal(size=V).astype(np.float32)
+    S = rs.normal(0, 5, (V, H)).astype(np.float32)
+    s_h, s_v = rs.normal(size=H).astype(np.float32), rs.normal(size=V).astype(np.float32)
+    stats = np.zeros(V * ldh + ldh + ldv + 4, np.float32)
+    stats[:V * ldh].reshape(V, ldh)[:, :H] = S
+    stats[V * ldh:V * ldh + H] = s_h
+    stats[V * ldh + ldh:V * ldh + ldh + V] = s_v
+    stats[V * ldh + ldh + ldv] = 123.0
+    e = hip_engine
+    dW, dWs, dW0 = dev(e, W, Ws, W0)
+    dhb, dhbs, dvb, dvbs = dev(e, hb, hbs, vb, vbs)
+    dstats = torch.from_numpy(stats).to(e.device)
+    cost = e.apply_update(dW, dWs, dW0 if frozen else None, dhb, dhbs, dvb, dvbs, dstats,
+                          0.05, l1, l2, wc, mu, 20.0, 17.0, 0.5)
+    s = rbm_np.RBMState(V, H, W=W, hbias=hb, vbias=vb)
+    s.W_speed, s.hbias_speed, s.vbias_speed = Ws.astype(np.float64), hbs.astype(np.float64), vbs.astype(np.float64)
+    s.W0 = W0.astype(np.float64) if frozen else None
+    g = rbm_np.rbm_grad(s, S.astype(np.float64), s_h.astype(np.float64), s_v.astype(np.float64), 20, 17, wc,
+                        strict_reference=frozen)
+    rbm_np.apply_update(s, g[0], g[1], g[2], 0.05, l1, l2, mu)
+    assert abs(float(cost) - 61.5) < 1e-5
+    for name, t in (("W", dW), ("W_speed", dWs), ("hbias", dhb), ("hbias_speed", dhbs), ("vbias", dvb),
+                    ("vbias_speed", dvbs)):
+        got, want = t.cpu().numpy(), getattr(s, name)
+        assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), name
+    assert not dW.storage_offset() and (ldh == H or not torch.zeros(1).any())
+
+
+def test_classes_same_host_code_both_engines(hip_engine):
+    """The reference-shaped host code (DBN.training) run on the HIP engine and on the CPU
+    checker engine: costs, learned W and outputs agree (fp32 vs f64) after a short run."""
+    import mdbn_amd
+    from _oracle_engine import OracleEngine
+    mdbn_amd.DBN.verbose = False
+    rs = np.random.RandomState(0)
+    train, val = rs.normal(size=(96, 40)).astype(np.float32), rs.normal(size=(16, 40)).astype(np.float32)
+    results = []
+    for eng in (hip_engine, OracleEngine()):
+        dbn = mdbn_amd.DBN(numpy_rng=np.random.RandomState(123), n_ins=40, hidden_layers_sizes=[24], n_outs=8,
+                           engine=eng)
+        dbn.shuffle_rng = np.random.RandomState(5)
+        hist = dbn.training(mdbn_amd.shared(train, engine=eng), batch_size=16, k=1, pretraining_epochs=[30, 30],
+                            pretrain_lr=[0.005, 0.1], lambda_1=0.01, lambda_2=0.1,
+                            validation_set_x=mdbn_amd.shared(val, engine=eng))
+        results.append((hist, [p.get_value() for p in dbn.params], dbn.get_output(train)))
+    (h_a, p_a, o_a), (h_b, p_b, o_b) = results
+    assert [len(x) for x in h_a] == [len(x) for x in h_b]
+    for ra, rb in zip(sum(h_a, []), sum(h_b, [])):
+        assert ra[0] == rb[0] and abs(ra[1] - rb[1]) <= 1e-4 * abs(rb[1]) + 1e-6
+        assert abs(ra[2] - rb[2]) <= 1e-3 * max(1.0, abs(rb[2]))
+    for a, b in zip(p_a, p_b):
+        assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
+    assert np.abs(o_a - o_b).max() <= 1e-4
+
+
+def test_full_size_row_linearity(hip_engine):
+    """Size-independent property at BASELINE's c2 shape (GRBM 4096->1024, B=512): statistics
+    are additive over row shards when the Philox counters are keyed by GLOBAL row -- the
+    identity the data-parallel path relies on.  Two half-batches with row
+    offsets 0 and 256 must sum to the full-batch statistics (fp32 summation-order tolerance),
+    and the positive-phase samples must be bit-identical."""
+    from mdbn_amd import RngAddr
+    V, H, B = 4096, 1024, 512
+    W, hb, vb, x = make(V, H, B, True, seed=11)
+    e = hip_engine
+    dW, dhb, dvb, dx = dev(e, W, hb, vb, x)
+    full, sc = e.cd_step(dx, None, dW, dhb, dvb, True, 1, RngAddr(9, 0, 3, 0, 0))
+    full = full.clone()
+    hs_full = sc.hs.clone()
+    parts = torch.zeros_like(full)
+    for lo in (0, 256):
+        idx = torch.arange(lo, lo + 256, device=e.device)
+        st, sc2 = e.cd_step(dx, idx, dW, dhb, dvb, True, 1, RngAddr(9, 0, 3, 0, lo))
+        assert torch.equal(sc2.hs, hs_full[lo:lo + 256]), "samples depend on the sharding"
+        parts += st
+    scale = float(full.abs().max())
+    assert float((parts - full).abs().max()) <= 2e-6 * scale
+    # and the full-size statistics agree with the float64 oracle
+    s = state64(W, hb, vb, True)
+    ph, _, out = rbm_np.cd_chain(s, x.astype(np.float64), PhiloxDraws(9, 0, 3, 0), 1)
+    S_o, _, _ = rbm_np.cd_statistics(x.astype(np.float64), ph, out[1], out[4])
+    S = full[:V * H].reshape(V, H).cpu().numpy()
+    hs = hs_full.cpu().numpy()
+    if np.array_equal(hs, (PhiloxDraws(9, 0, 3, 0).u(0, B, H) < ph).astype(np.float32)):
+        assert np.abs(S - S_o).max() <= 1e-5 * np.abs(S_o).max()
+
+
+def test_multi_step_weights_track_oracle(hip_engine):
+    """100 CD-1 steps of the c2-shaped update on a smaller GRBM: learned W stays within 1e-4
+    relative of the float64 oracle driven by the same Philox stream."""
+    import mdbn_amd
+    V, H, B, N = 256, 128, 64, 512
+    rs = np.random.RandomState(3)
+    data = rs.normal(size=(N, V)).astype(np.float32)
+    rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123),
+                        theano_rng=mdbn_amd.RandomStreams(17), engine=hip_engine)
+    st = rbm_np.RBMState(V, H, W=rbm.W.get_value(), gauss=True)
+    _, up = rbm.get_cost_updates(lr=0.005, k=1, lambda_1=0.0, lambda_2=0.1, batch_size=B)
+    fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=hip_engine), data_parallel=None)
+    forks = 0
+    for t in range(100):
+        idx = rs.permutation(N)[:B]
+        c = fn(indexes=idx, momentum=0.0)
+        c_o = rbm_np.cd_step(st, data[idx], PhiloxDraws(17, rbm.stream_id, t), lr=0.005, k=1, lambda_2=0.1,
+                             batch_size=B)
+        if abs(float(c) - c_o) > 1e-4 * abs(c_o):
+            forks += 1
+    W, W_o = rbm.W.get_value(), st.W
+    assert forks <= 1
+    assert np.abs(W - W_o).max() <= 1e-4 * np.abs(W_o).max()
