@@ -55,7 +55,7 @@ int fail(int code, const char* fmt, ...)
         if (!(cond)) return fail(MDBN_EINVAL, __VA_ARGS__); \
     } while (0)
 
-constexpr int kTargetBlocks = 256;     // one 128x128 tile job per CU (MI355X: 256 CUs)
+constexpr int kTargetJobs = 256;       // one 8-wave tile job per CU (MI355X: 256 CUs)
 constexpr int kMinSplitK = 128;        // >= 4 slices of BK = 32 per split
 
 inline int64_t ru4(int64_t x) { return (x + 3) & ~int64_t(3); }
@@ -63,17 +63,28 @@ inline int64_t ru64(int64_t x) { return (x + 63) & ~int64_t(63); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 struct Plan {
-    int tiles_m, tiles_n, splitk, kchunk;
+    int tiles_m, tiles_n, splitk, kchunk, bn;
     int64_t slab_floats(int64_t M, int64_t ldc) const { return (int64_t)splitk * M * ldc; }
+    void fill(GemmArgs& g) const
+    {
+        g.kchunk = kchunk; g.splitk = splitk; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.bn = bn;
+        g.inner_m = tiles_m <= tiles_n;
+    }
 };
 
+// Tile shape and split-K: 128x128 tiles whenever they alone give every CU a job; smaller
+// problems keep the 128x128 tile too and split the reduction until about one job per CU
+// exists (never below kMinSplitK of reduction per job); 128x64 tiles are used only when even
+// that leaves CUs idle.
 Plan plan_gemm(int64_t M, int64_t N, int64_t K)
 {
     Plan p;
     p.tiles_m = (int)((M + 127) / 128);
-    p.tiles_n = (int)((N + 127) / 128);
+    const int64_t t128 = (int64_t)p.tiles_m * ((N + 127) / 128);
+    p.bn = (t128 * std::max<int64_t>(1, K / kMinSplitK) >= kTargetJobs) ? 128 : 64;
+    p.tiles_n = (int)((N + p.bn - 1) / p.bn);
     const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
-    int64_t want = std::max<int64_t>(1, kTargetBlocks / std::max<int64_t>(tiles, 1));
+    int64_t want = std::max<int64_t>(1, kTargetJobs / std::max<int64_t>(tiles, 1));
     int64_t maxsplit = std::max<int64_t>(1, K / kMinSplitK);
     int64_t sk = std::min(want, maxsplit);
     int64_t kchunk = ((K + sk - 1) / sk + 31) / 32 * 32;
@@ -84,8 +95,12 @@ Plan plan_gemm(int64_t M, int64_t N, int64_t K)
     return p;
 }
 
-hipError_t timed_gemm(int la, int lb, const GemmArgs& g, hipStream_t s)
+static unsigned long long* g_stamps = nullptr;     // diagnostic builds only
+
+hipError_t timed_gemm(int la, int lb, const GemmArgs& g_in, hipStream_t s)
 {
+    GemmArgs g = g_in;
+    g.stamps = g_stamps;
     if (!g_timing.enabled || g_timing.used >= 8192) return launch_gemm(la, lb, g, s);
     if (g_timing.used == g_timing.pool.size()) {
         hipEvent_t a, b;
@@ -120,8 +135,9 @@ struct Workspace {
     int64_t slab_floats;
     float* cost_partials;
     int64_t cost_floats;
-    float* colP;      // [2 * nch][ldh]
-    float* colV;      // [2 * nch][ldv]
+    float* colPpos;   // [row_groups][ldh]  4-row partial column sums of  ph_mean
+    float* colPneg;   // [row_groups][ldh]                                -nh_mean
+    float* colV;      // [row_groups][ldv]                                 v0 - nv_mean
 };
 
 struct WsSizes {
@@ -138,9 +154,9 @@ WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
     if (st.splitk > 1) s.slab = std::max(s.slab, st.slab_floats(V, ldh));
     s.slab = std::max<int64_t>(s.slab, 4 * std::max(ldv, ldh) * 8);
     s.cost = std::max(epilogue_blocks(B, ldv), epilogue_blocks(B, ldh)) + 64;
-    const int nch = colsum_chunks(B);
-    s.colP = 2 * (int64_t)nch * ldh;
-    s.colV = 2 * (int64_t)nch * ldv;
+    const int ng = row_groups(B);
+    s.colP = 2 * (int64_t)ng * ldh;
+    s.colV = (int64_t)ng * ldv;
     return s;
 }
 
@@ -155,7 +171,7 @@ int carve(void* ws, int64_t bytes, int64_t B, int64_t V, int64_t H, Workspace& o
                         (long long)bytes, (long long)s.total_bytes(), (long long)B, (long long)V, (long long)H);
         out.slabs = p;            out.slab_floats = s.slab;  p += ru64(s.slab);
         out.cost_partials = p;    out.cost_floats = s.cost;  p += ru64(s.cost);
-        out.colP = p;             p += ru64(s.colP);
+        out.colPpos = p;          out.colPneg = p + s.colP / 2;  p += ru64(s.colP);
         out.colV = p;
     } else {
         // propagation only: a fixed cost region at the end, everything else is slabs
@@ -167,7 +183,7 @@ int carve(void* ws, int64_t bytes, int64_t B, int64_t V, int64_t H, Workspace& o
         out.slab_floats = (floats - cost) & ~int64_t(63);
         out.cost_partials = p + out.slab_floats;
         out.cost_floats = cost;
-        out.colP = out.colV = nullptr;
+        out.colPpos = out.colPneg = out.colV = nullptr;
     }
     return MDBN_OK;
 }
@@ -185,6 +201,7 @@ struct Affine {
     const float* target; int64_t ld_target;
     bool want_cost;
     const mdbn_rng* rng; uint32_t draw;
+    float* colsum = nullptr; int colsum_kind = 0;
 };
 
 int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_out)
@@ -207,8 +224,7 @@ int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_
         g.C = ws.slabs;          g.ldc = a.ldo;
         g.slab_stride = R * a.ldo;
         g.M = (int)R; g.N = (int)Ndim; g.K = (int)Kdim; g.Nst = (int)a.ldo;
-        g.kchunk = p.kchunk; g.splitk = p.splitk; g.tiles_m = p.tiles_m; g.tiles_n = p.tiles_n;
-        g.inner_m = p.tiles_m <= p.tiles_n;
+        p.fill(g);
         HIP_OK(timed_gemm(LAY_K, a.dir == 0 ? LAY_MN : LAY_K, g, s));
 
         EpiArgs e;
@@ -222,6 +238,8 @@ int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_
         e.target = a.target ? a.target + r0 * a.ld_target : nullptr;
         e.ld_target = a.ld_target;
         const int nb = epilogue_blocks(R, a.ldo);
+        e.colsum = a.colsum ? a.colsum + (r0 / 4) * a.ldo : nullptr;
+        e.colsum_kind = a.colsum_kind;
         e.cost_partials = nullptr;
         if (a.want_cost) {
             if (n_cost + nb > ws.cost_floats) return fail(MDBN_ENOSPC, "cost scratch exhausted");
@@ -286,6 +304,10 @@ int mdbn_ctx_destroy(mdbn_ctx* ctx)
     delete ctx;
     return MDBN_OK;
 }
+
+#ifdef MDBN_STAMP
+int mdbn_debug_set_stamps(void* p) { g_stamps = (unsigned long long*)p; return MDBN_OK; }
+#endif
 
 int mdbn_kernel_timing(mdbn_ctx* ctx, int enable)
 {
@@ -386,8 +408,8 @@ int mdbn_propdown_sample(mdbn_ctx* ctx, void* stream, const float* h, int64_t B,
             HIP_OK(hipMemcpyAsync(sample, mean ? mean : pre, sizeof(float) * B * ldv, hipMemcpyDeviceToDevice, s));
     }
     if (cost_sum)
-        HIP_OK(launch_finalize_stats(nullptr, nullptr, 0, 0, 0, ws.cost_partials, n_cost, nullptr, nullptr,
-                                     cost_sum, s));
+        HIP_OK(launch_finalize_stats(nullptr, nullptr, nullptr, 0, 0, 0, ws.cost_partials, n_cost, nullptr,
+                                     nullptr, cost_sum, s));
     return MDBN_OK;
 }
 
@@ -407,9 +429,12 @@ int mdbn_cd_stats(mdbn_ctx* ctx, void* stream, const float* V2, const float* P2,
     float* s_v = s_h + ldh;
     float* cost = s_v + ldv;
 
-    HIP_OK(launch_colsum_partial(P2, (int)B, ldh, ws.colP, s));
-    HIP_OK(launch_colsum_partial(V2, (int)B, ldv, ws.colV, s));
-    HIP_OK(launch_finalize_stats(ws.colP, ws.colV, (int)B, ldh, ldv, nullptr, 0, s_h, s_v, cost, s));
+    // bias statistics: P2's second half already holds -nh_mean; s_v = sum(v0 - nv_mean)
+    const int ng = row_groups(B);
+    HIP_OK(launch_colsum_groups(P2, nullptr, (int)B, ldh, ws.colPpos, s));
+    HIP_OK(launch_colsum_groups(P2 + B * ldh, nullptr, (int)B, ldh, ws.colPneg, s));
+    HIP_OK(launch_colsum_groups(V2, V2 + B * ldv, (int)B, ldv, ws.colV, s));
+    HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, ng, ldh, ldv, nullptr, 0, s_h, s_v, cost, s));
 
     // S = [v0 ; nv]^T [ph ; -nh]  : one GEMM over the stacked batch dimension (K = 2B)
     const Plan p = plan_gemm(V, H, 2 * B);
@@ -417,8 +442,7 @@ int mdbn_cd_stats(mdbn_ctx* ctx, void* stream, const float* V2, const float* P2,
     g.A = V2; g.lda = ldv; g.B = P2; g.ldb = ldh;
     g.ldc = ldh; g.slab_stride = V * ldh;
     g.M = (int)V; g.N = (int)H; g.K = (int)(2 * B); g.Nst = (int)ldh;
-    g.kchunk = p.kchunk; g.splitk = p.splitk; g.tiles_m = p.tiles_m; g.tiles_n = p.tiles_n;
-    g.inner_m = p.tiles_m <= p.tiles_n;
+    p.fill(g);
     if (p.splitk == 1) {
         g.C = S;
         HIP_OK(timed_gemm(LAY_MN, LAY_MN, g, s));
@@ -478,6 +502,7 @@ int mdbn_cd_step(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a)
     {
         Affine up{v0, B, ldv, a->W, V, H, ldh, 0, a->hbias, nullptr, ph, a->hs, ldh, 1.0f, 0,
                   nullptr, 0, false, &a->rng, 0u};
+        up.colsum = ws.colPpos;                                         // sum_rows ph_mean
         CHECK(run_affine(up, ws, s, nullptr));
     }
     int n_cost = 0;
@@ -488,12 +513,14 @@ int mdbn_cd_step(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a)
         // its noisy sample never feeds the chain, rbm.py:669, so it is not materialised here)
         Affine down{chain, B, ldh, a->W, V, H, ldh, 1, a->vbias, nullptr, nv, a->gauss ? nullptr : a->vs,
                     ldv, 1.0f, a->gauss, last ? v0 : nullptr, ldv, last, &a->rng, (uint32_t)(2 * t - 1)};
+        if (last) { down.colsum = ws.colV; down.colsum_kind = 1; }      // sum_rows (v0 - nv_mean)
         CHECK(run_affine(down, ws, s, last ? &n_cost : nullptr));
         // h_t | v_t: from the mean for GRBM (rbm.py:669), from the sample for RBM (rbm.py:246)
         const bool need_sample = !last || a->persistent != nullptr;
         float* hdst = (last && a->persistent) ? a->persistent : a->hs;            // rbm.py:369
         Affine up{a->gauss ? nv : a->vs, B, ldv, a->W, V, H, ldh, 0, a->hbias, nullptr, nh,
                   need_sample ? hdst : nullptr, ldh, -1.0f, 0, nullptr, 0, false, &a->rng, (uint32_t)(2 * t)};
+        if (last) up.colsum = ws.colPneg;                               // sum_rows (-nh_mean)
         CHECK(run_affine(up, ws, s, nullptr));
     }
 
@@ -501,17 +528,14 @@ int mdbn_cd_step(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a)
     float* s_h = a->stats + V * ldh;
     float* s_v = s_h + ldh;
     float* cost = s_v + ldv;
-    HIP_OK(launch_colsum_partial(a->P2, (int)B, ldh, ws.colP, s));
-    HIP_OK(launch_colsum_partial(a->V2, (int)B, ldv, ws.colV, s));
-    HIP_OK(launch_finalize_stats(ws.colP, ws.colV, (int)B, ldh, ldv, ws.cost_partials, n_cost, s_h, s_v,
-                                 cost, s));
+    HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials,
+                                 n_cost, s_h, s_v, cost, s));
     const Plan p = plan_gemm(V, H, 2 * B);
     GemmArgs g;
     g.A = a->V2; g.lda = ldv; g.B = a->P2; g.ldb = ldh;
     g.ldc = ldh; g.slab_stride = V * ldh;
     g.M = (int)V; g.N = (int)H; g.K = (int)(2 * B); g.Nst = (int)ldh;
-    g.kchunk = p.kchunk; g.splitk = p.splitk; g.tiles_m = p.tiles_m; g.tiles_n = p.tiles_n;
-    g.inner_m = p.tiles_m <= p.tiles_n;
+    p.fill(g);
     if (p.splitk == 1) {
         g.C = S;
         HIP_OK(timed_gemm(LAY_MN, LAY_MN, g, s));
@@ -548,8 +572,7 @@ int mdbn_free_energy(mdbn_ctx* ctx, void* stream, const float* x, int64_t N, int
         g.A = x + r0 * ldv; g.lda = ldv; g.B = W; g.ldb = ldh; g.C = ws.slabs; g.ldc = ldh;
         g.slab_stride = R * ldh;
         g.M = (int)R; g.N = (int)H; g.K = (int)V; g.Nst = (int)ldh;
-        g.kchunk = p.kchunk; g.splitk = p.splitk; g.tiles_m = p.tiles_m; g.tiles_n = p.tiles_n;
-        g.inner_m = p.tiles_m <= p.tiles_n;
+        p.fill(g);
         HIP_OK(timed_gemm(LAY_K, LAY_MN, g, s));
         HIP_OK(launch_free_energy(ws.slabs, p.splitk, g.slab_stride, ldh, (int)H, hbias, x + r0 * ldv, ldv,
                                   (int)V, vbias, gauss, R, out + r0, s));

@@ -19,7 +19,9 @@ struct GemmArgs {
     int Nst;               // columns stored (>= N; pad columns receive exact zeros)
     int kchunk;            // reduction extent per split, multiple of 32
     int splitk, tiles_m, tiles_n;
+    int bn;                // block tile is 128 x bn (128 or 64)
     int inner_m;           // work-list order inside one split: 1 = tile_m fastest
+    unsigned long long* stamps;   // diagnostic builds only (-DMDBN_STAMP); NULL otherwise
 };
 
 struct EpiArgs {
@@ -37,6 +39,8 @@ struct EpiArgs {
     const float* target;   // nullable: reconstruction-cost target (v0)
     int64_t ld_target;
     float* cost_partials;  // nullable: one float per block
+    float* colsum;         // nullable: [ceil(rows/4)][ld] partial column sums over each 4-row group
+    int colsum_kind;       // 0: sum of stored (scaled) mean ; 1: sum of (target - mean)
     PhiloxKey rng;
 };
 
@@ -45,7 +49,7 @@ inline int epilogue_blocks(int64_t rows, int64_t ld)
     const int64_t n = ((rows + 3) / 4) * (ld / 4);
     return (int)((n + 255) / 256);
 }
-inline int colsum_chunks(int64_t B) { return (int)((B + 63) / 64); }
+inline int row_groups(int64_t B) { return (int)((B + 3) / 4); }
 
 hipError_t launch_gemm(int la, int lb, const GemmArgs& g, hipStream_t s);
 hipError_t launch_act_epilogue(const EpiArgs& e, hipStream_t s);
@@ -54,10 +58,10 @@ hipError_t launch_sum_slabs(const float* slabs, int nsplit, int64_t slab_stride,
 hipError_t launch_gather(const float* src, int64_t n_rows, int64_t cols_ld, int64_t ld_src,
                          const void* idx, int idx64, int64_t n_idx, float* dst, int64_t ld_dst,
                          hipStream_t s);
-hipError_t launch_colsum_partial(const float* X, int B, int64_t ld, float* partial, hipStream_t s);
-hipError_t launch_finalize_stats(const float* partP, const float* partV, int B, int64_t ldh, int64_t ldv,
-                                 const float* cost_partials, int n_cost, float* s_h, float* s_v,
-                                 float* cost, hipStream_t s);
+hipError_t launch_colsum_groups(const float* X, const float* Y, int rows, int64_t ld, float* out, hipStream_t s);
+hipError_t launch_finalize_stats(const float* posP, const float* negP, const float* partV, int ngroups,
+                                 int64_t ldh, int64_t ldv, const float* cost_partials, int n_cost,
+                                 float* s_h, float* s_v, float* cost, hipStream_t s);
 hipError_t launch_update(const mdbn_update_args& a, hipStream_t s);
 hipError_t launch_free_energy(const float* slabs, int nsplit, int64_t slab_stride, int64_t ldh, int H,
                               const float* hbias, const float* x, int64_t ldv, int V, const float* vbias,

@@ -19,100 +19,233 @@ namespace mdbn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128;
-constexpr int BN = 128;
 constexpr int BK = 32;
 constexpr int NTHREADS = 256;
-constexpr int LDK = BK + 1;               // row stride of a K-contiguous LDS tile [128][33]
-constexpr int TILE_FLOATS = 128 * LDK;    // >= 32*128 (MN-contiguous tile [32][128])
-constexpr int GEMM_LDS_BYTES = 4 * TILE_FLOATS * (int)sizeof(float);   // A,B x 2 buffers
+constexpr int LDK = BK + 1;               // row stride of a K-contiguous LDS tile [rows][33]
 
 // ----------------------------------------------------------------------------------
-// operand staging: global -> registers -> LDS
+// operand staging: global -> registers -> LDS, done by the 256 threads of the producer
+// waves.  ROWS = extent of the tile along the operand's output index (128 or 64); the
+// reduction extent is always BK = 32.  GUARD = false is the interior fast path (every
+// float4 inside the operand: straight-line loads).
 // ----------------------------------------------------------------------------------
-template <int LAY>
+template <int LAY, int ROWS, bool GUARD>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t ld, int MN, int K,
-                                          int mn0, int k0, float4 (&r)[4])
+                                          int mn0, int k0, float4 (&r)[ROWS / 32])
 {
-    const int tid = threadIdx.x;
-    if (LAY == LAY_K) {
+    const int tid = threadIdx.x & (NTHREADS - 1);
+    if constexpr (LAY == LAY_K) {
         // P[mn][k], k contiguous: 8 threads cover one 32-float row slice, 32 rows per pass
         const int c = tid & 7, rr = tid >> 3;
         const int kq = k0 + 4 * c;
+        const float* src = P + (int64_t)(mn0 + rr) * ld + kq;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = mn0 + rr + 32 * p;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < MN) {
-                const float* src = P + (int64_t)row * ld + kq;
-                if (kq + 3 < K) {
-                    v = *reinterpret_cast<const float4*>(src);
-                } else {
-                    if (kq + 0 < K) v.x = src[0];
-                    if (kq + 1 < K) v.y = src[1];
-                    if (kq + 2 < K) v.z = src[2];
+        for (int p = 0; p < ROWS / 32; ++p) {
+            const float* sp = src + (int64_t)(32 * p) * ld;
+            if constexpr (!GUARD) {
+                r[p] = *reinterpret_cast<const float4*>(sp);
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mn0 + rr + 32 * p < MN) {
+                    if (kq + 3 < K) {
+                        v = *reinterpret_cast<const float4*>(sp);
+                    } else {
+                        if (kq + 0 < K) v.x = sp[0];
+                        if (kq + 1 < K) v.y = sp[1];
+                        if (kq + 2 < K) v.z = sp[2];
+                    }
                 }
+                r[p] = v;
             }
-            r[p] = v;
         }
     } else {
-        // P[k][mn], mn contiguous: 32 threads cover one 128-float row, 8 k-rows per pass
-        const int c = tid & 31, rr = tid >> 5;
+        // P[k][mn], mn contiguous: ROWS/4 threads cover one row of the tile
+        constexpr int TPR = ROWS / 4, RPP = NTHREADS / TPR;
+        const int c = tid % TPR, rr = tid / TPR;
         const int mq = mn0 + 4 * c;
+        const float* src = P + (int64_t)(k0 + rr) * ld + mq;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int krow = k0 + rr + 8 * p;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (krow < K) {
-                const float* src = P + (int64_t)krow * ld + mq;
-                if (mq + 3 < MN) {
-                    v = *reinterpret_cast<const float4*>(src);
-                } else {
-                    if (mq + 0 < MN) v.x = src[0];
-                    if (mq + 1 < MN) v.y = src[1];
-                    if (mq + 2 < MN) v.z = src[2];
+        for (int p = 0; p < ROWS / 32; ++p) {
+            const float* sp = src + (int64_t)(RPP * p) * ld;
+            if constexpr (!GUARD) {
+                r[p] = *reinterpret_cast<const float4*>(sp);
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + rr + RPP * p < K) {
+                    if (mq + 3 < MN) {
+                        v = *reinterpret_cast<const float4*>(sp);
+                    } else {
+                        if (mq + 0 < MN) v.x = sp[0];
+                        if (mq + 1 < MN) v.y = sp[1];
+                        if (mq + 2 < MN) v.z = sp[2];
+                    }
                 }
+                r[p] = v;
             }
-            r[p] = v;
         }
     }
 }
 
-template <int LAY>
-__device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&r)[4])
+template <int LAY, int ROWS>
+__device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&r)[ROWS / 32])
 {
-    const int tid = threadIdx.x;
-    if (LAY == LAY_K) {
+    const int tid = threadIdx.x & (NTHREADS - 1);
+    if constexpr (LAY == LAY_K) {
         const int c = tid & 7, rr = tid >> 3;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < ROWS / 32; ++p) {
             float* d = T + (rr + 32 * p) * LDK + 4 * c;     // odd stride: reads conflict-free
             d[0] = r[p].x; d[1] = r[p].y; d[2] = r[p].z; d[3] = r[p].w;
         }
     } else {
-        const int c = tid & 31, rr = tid >> 5;
+        constexpr int TPR = ROWS / 4, RPP = NTHREADS / TPR;
+        const int c = tid % TPR, rr = tid / TPR;
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            *reinterpret_cast<float4*>(T + (rr + 8 * p) * 128 + 4 * c) = r[p];
+        for (int p = 0; p < ROWS / 32; ++p)
+        {
+            const float4 v = make_float4(r[p].x, r[p].y, r[p].z, r[p].w);
+            *reinterpret_cast<float4*>(T + (rr + RPP * p) * ROWS + 4 * c) = v;
+        }
     }
 }
 
 // MFMA operand of lane (i = lane & 31, h = lane >> 5): element [mn = base + i][k = kk + h]
-template <int LAY>
+template <int LAY, int ROWS>
 __device__ __forceinline__ float frag(const float* __restrict__ T, int mn, int k)
 {
-    return LAY == LAY_K ? T[mn * LDK + k] : T[k * 128 + mn];
+    return LAY == LAY_K ? T[mn * LDK + k] : T[k * ROWS + mn];
 }
+
+#ifdef MDBN_STAMP
+// diagnostic build: s_memtime stamps of one block's phases (never compiled into the product)
+#define STAMP(slot)                                                                          \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if (g.stamps && blockIdx.x == 8 && (threadIdx.x & 63) == 0 && it < 64)               \
+            g.stamps[(((threadIdx.x >> 6) * 64 + it) * 8) + (slot)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
 
 // ----------------------------------------------------------------------------------
 // C[ks] = A[:, kchunk ks] * B[kchunk ks, :]   (split-K slabs, no epilogue)
 // Replaces tensor.dot at rbm.py:168,198,226,411-412,650,685 and mlp.py:103.
+//
+// Wave-specialised block of 8 waves, one block per CU, block tile (64*MI) x (64*NI):
+//   waves 0-3 (one per SIMD) CONSUME: fragment reads from LDS + v_mfma_f32_32x32x2_f32 only,
+//             2x2 wave grid, MI x NI accumulators of 32x32 each; fragment reads run one
+//             k-group ahead of the MFMAs so the matrix pipe never waits on LDS;
+//   waves 4-7 PRODUCE: global -> registers -> LDS staging of the next BK = 32 slice (its loads
+//             issued a whole slice earlier), sharing each SIMD with one consumer wave whose
+//             MFMA issue they barely disturb.
+// Double-buffered LDS, one barrier per slice.  (Measured with s_memtime stamps: when every
+// wave both staged and multiplied, a wave's ~100 staging instructions took ~3400 cycles per
+// slice next to a partner wave's MFMAs and the matrix pipe idled 26-38% of the time.)
 // ----------------------------------------------------------------------------------
-template <int LA, int LB>
-__global__ __launch_bounds__(NTHREADS) void gemm_splitk_kernel(GemmArgs g)
+constexpr int GEMM_THREADS = 512;
+
+template <int LA, int LB, int MI, int NI, bool GUARD>
+__device__ __forceinline__ void gemm_produce(const GemmArgs& g, float* __restrict__ smem, int m0, int n0,
+                                             int kbeg, int kend, int nt)
 {
+    constexpr int BM = 64 * MI, BN = 64 * NI;
+    constexpr int A_FLOATS = BM * LDK, B_FLOATS = BN * LDK, BUF = A_FLOATS + B_FLOATS;
+    // Two register sets: in slice `it` the set (it & 1) holds slice it+1 (loaded two slices
+    // ago), is written to LDS buffer (it+1) & 1, and is then re-loaded with slice it+3 --
+    // every load has more than a full slice (~2 us) to land before it is needed.
+    float4 ra0[BM / 32], rb0[BN / 32], ra1[BM / 32], rb1[BN / 32];
+#define PRODUCER_LOAD(RA, RB, SLICE)                                                          \
+    do {                                                                                      \
+        load_tile<LA, BM, GUARD>(g.A, g.lda, g.M, kend, m0, kbeg + (SLICE) * BK, RA);         \
+        load_tile<LB, BN, GUARD>(g.B, g.ldb, g.N, kend, n0, kbeg + (SLICE) * BK, RB);         \
+    } while (0)
+#define PRODUCER_STEP(RA, RB)                                                                 \
+    do {                                                                                      \
+        STAMP(0);                                                                             \
+        if (it + 1 < nt) {                                                                    \
+            float* nx = smem + ((it + 1) & 1) * BUF;   /* all reads of it ended at the last barrier */ \
+            store_tile<LA, BM>(nx, RA);                                                       \
+            store_tile<LB, BN>(nx + A_FLOATS, RB);                                            \
+        }                                                                                     \
+        STAMP(1);                                                                             \
+        if (it + 3 < nt) PRODUCER_LOAD(RA, RB, it + 3);                                       \
+        STAMP(2);                                                                             \
+        __syncthreads();                                                                      \
+        STAMP(3);                                                                             \
+    } while (0)
+
+    PRODUCER_LOAD(ra0, rb0, 0);
+    store_tile<LA, BM>(smem, ra0);
+    store_tile<LB, BN>(smem + A_FLOATS, rb0);
+    if (nt > 1) PRODUCER_LOAD(ra0, rb0, 1);         // slices 1 and 2 stay in flight across the barrier
+    if (nt > 2) PRODUCER_LOAD(ra1, rb1, 2);
+    __syncthreads();
+    for (int it = 0; it < nt; ++it) {
+        PRODUCER_STEP(ra0, rb0);
+        if (++it >= nt) break;
+        PRODUCER_STEP(ra1, rb1);
+    }
+#undef PRODUCER_STEP
+#undef PRODUCER_LOAD
+}
+
+template <int LA, int LB, int MI, int NI>
+__device__ __forceinline__ void gemm_consume(const GemmArgs& g, const float* __restrict__ smem,
+                                             f32x16 (&acc)[MI][NI], int nt, int wm, int wn, int i, int h)
+{
+    constexpr int BM = 64 * MI, BN = 64 * NI;
+    constexpr int A_FLOATS = BM * LDK, B_FLOATS = BN * LDK, BUF = A_FLOATS + B_FLOATS;
+    constexpr int KG = 2, NG = BK / (2 * KG);       // 8 groups of 2 k-pairs per slice
+    __syncthreads();                                // slice 0 staged
+    for (int it = 0; it < nt; ++it) {
+        STAMP(0);
+        const float* at = smem + (it & 1) * BUF;
+        const float* bt = at + A_FLOATS;
+        float av[2][KG][MI], bv[2][KG][NI];
+#pragma unroll
+        for (int u = 0; u < KG; ++u) {
+#pragma unroll
+            for (int a = 0; a < MI; ++a) av[0][u][a] = frag<LA, BM>(at, wm + 32 * a + i, 2 * u + h);
+#pragma unroll
+            for (int b = 0; b < NI; ++b) bv[0][u][b] = frag<LB, BN>(bt, wn + 32 * b + i, 2 * u + h);
+        }
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp) {
+            const int cs = grp & 1, ns = cs ^ 1;
+            if (grp + 1 < NG) {
+#pragma unroll
+                for (int u = 0; u < KG; ++u) {
+                    const int kk = 2 * KG * (grp + 1) + 2 * u;
+#pragma unroll
+                    for (int a = 0; a < MI; ++a) av[ns][u][a] = frag<LA, BM>(at, wm + 32 * a + i, kk + h);
+#pragma unroll
+                    for (int b = 0; b < NI; ++b) bv[ns][u][b] = frag<LB, BN>(bt, wn + 32 * b + i, kk + h);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < KG; ++u)
+#pragma unroll
+                for (int a = 0; a < MI; ++a)
+#pragma unroll
+                    for (int b = 0; b < NI; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cs][u][a], bv[cs][u][b], acc[a][b], 0, 0, 0);
+            // keep the next group's reads ahead of this group's MFMAs in the emitted order
+            __builtin_amdgcn_sched_group_barrier(0x100, KG * (MI + NI), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, KG * MI * NI, 0);
+        }
+        STAMP(1);
+        __syncthreads();
+        STAMP(2);
+    }
+}
+
+template <int LA, int LB, int MI, int NI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
+{
+    constexpr int BM = 64 * MI, BN = 64 * NI;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // buffer b: A tile at smem + 2*b*TILE_FLOATS, B tile right behind it
 
     // XCD-aware work mapping: blocks b and b+8 share an XCD (round-robin dispatch), so
     // give each XCD one contiguous chunk of the (ks, tile) list -> its blocks share A/B
@@ -129,62 +262,35 @@ __global__ __launch_bounds__(NTHREADS) void gemm_splitk_kernel(GemmArgs g)
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = ks * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
-    const int nt = (kend - kbeg + BK - 1) / BK;
+    const int nt = (kend - kbeg + BK - 1) / BK;     // >= 1: the host never plans an empty split
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= 4) {
+        const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (kbeg + nt * BK <= g.K);
+        if (interior) gemm_produce<LA, LB, MI, NI, false>(g, smem, m0, n0, kbeg, kend, nt);
+        else gemm_produce<LA, LB, MI, NI, true>(g, smem, m0, n0, kbeg, kend, nt);
+        return;
+    }
+
+    const int lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-
-    f32x16 acc[2][2];
+    const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * (32 * NI);
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MI; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NI; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    float4 ra[4], rb[4];
-    if (nt > 0) {
-        load_tile<LA>(g.A, g.lda, g.M, kend, m0, kbeg, ra);
-        load_tile<LB>(g.B, g.ldb, g.N, kend, n0, kbeg, rb);
-        store_tile<LA>(smem, ra);
-        store_tile<LB>(smem + TILE_FLOATS, rb);
-    }
-    __syncthreads();
-
-    for (int it = 0; it < nt; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < nt) {                      // prefetch next slice into registers
-            load_tile<LA>(g.A, g.lda, g.M, kend, m0, kbeg + (it + 1) * BK, ra);
-            load_tile<LB>(g.B, g.ldb, g.N, kend, n0, kbeg + (it + 1) * BK, rb);
-        }
-        const float* at = smem + cur * (2 * TILE_FLOATS);
-        const float* bt = at + TILE_FLOATS;
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = frag<LA>(at, wm + i, kk + h);
-            const float a1 = frag<LA>(at, wm + 32 + i, kk + h);
-            const float b0 = frag<LB>(bt, wn + i, kk + h);
-            const float b1 = frag<LB>(bt, wn + 32 + i, kk + h);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (it + 1 < nt) {                      // other buffer: last read one barrier ago
-            float* nx = smem + (cur ^ 1) * (2 * TILE_FLOATS);
-            store_tile<LA>(nx, ra);
-            store_tile<LB>(nx + TILE_FLOATS, rb);
-        }
-        __syncthreads();
-    }
+    gemm_consume<LA, LB, MI, NI>(g, smem, acc, nt, wm, wn, i, h);
 
     // accumulator (32x32): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     float* C = g.C + (int64_t)ks * g.slab_stride;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MI; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NI; ++b) {
             const int col = n0 + wn + 32 * b + i;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -194,28 +300,39 @@ __global__ __launch_bounds__(NTHREADS) void gemm_splitk_kernel(GemmArgs g)
         }
 }
 
-template <int LA, int LB>
+template <int LA, int LB, int MI, int NI>
 static hipError_t launch_gemm_t(const GemmArgs& g, hipStream_t s)
 {
+    // The LDS request is padded past half of the CU's 160 KiB so that exactly one 8-wave
+    // block lives on a CU: the jobs then spread evenly over the 256 CUs.
+    constexpr int need_bytes = 2 * (64 * MI + 64 * NI) * LDK * (int)sizeof(float);
+    constexpr int lds_bytes = need_bytes > 84 * 1024 ? need_bytes : 84 * 1024;
     static bool attr_set = false;
-    auto kern = gemm_splitk_kernel<LA, LB>;
+    auto kern = gemm_splitk_kernel<LA, LB, MI, NI>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           GEMM_LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int grid = g.tiles_m * g.tiles_n * g.splitk;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), GEMM_LDS_BYTES, s, g);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), lds_bytes, s, g);
     return hipGetLastError();
+}
+
+template <int LA, int LB>
+static hipError_t launch_gemm_l(const GemmArgs& g, hipStream_t s)
+{
+    if (g.bn == 128) return launch_gemm_t<LA, LB, 2, 2>(g, s);
+    if (g.bn == 64) return launch_gemm_t<LA, LB, 2, 1>(g, s);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_gemm(int la, int lb, const GemmArgs& g, hipStream_t s)
 {
-    if (la == LAY_K && lb == LAY_MN) return launch_gemm_t<LAY_K, LAY_MN>(g, s);
-    if (la == LAY_K && lb == LAY_K) return launch_gemm_t<LAY_K, LAY_K>(g, s);
-    if (la == LAY_MN && lb == LAY_MN) return launch_gemm_t<LAY_MN, LAY_MN>(g, s);
+    if (la == LAY_K && lb == LAY_MN) return launch_gemm_l<LAY_K, LAY_MN>(g, s);
+    if (la == LAY_K && lb == LAY_K) return launch_gemm_l<LAY_K, LAY_K>(g, s);
+    if (la == LAY_MN && lb == LAY_MN) return launch_gemm_l<LAY_MN, LAY_MN>(g, s);
     return hipErrorInvalidValue;
 }
 
@@ -278,8 +395,13 @@ __device__ __forceinline__ void setc(float4& v, int j, float x)
 //   gauss = 1: mean = pre = sum + bias ; sample = mean + N(0,1)      (GRBM rbm.py:650-658)
 //   cost (target != NULL): sum of BCE(sigmoid(pre), target) (rbm.py:479-480) or of
 //              (sigmoid(mean) - target)^2 (rbm.py:697), one partial per block.
+//   colsum != NULL: per-thread partial of the bias statistics (rbm.py:416-417) over the
+//              thread's 4 rows: colsum_kind 0 = sum of the stored (scaled) mean,
+//              1 = sum of (target - mean); written to colsum[row_group][col].
 // One thread = 4 rows x 4 columns: float4 traffic, one Philox block per column.
+// NS > 0: compile-time split count (all slab loads of a row in flight together).
 // ----------------------------------------------------------------------------------
+template <int NS>
 __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
 {
     __shared__ float red[4];
@@ -294,18 +416,40 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
                                          c0 + 2 < e.cols ? e.bias[c0 + 2] : 0.f,
                                          c0 + 3 < e.cols ? e.bias[c0 + 3] : 0.f);
         float4 pre[4];
+        const float* base = e.slabs + (int64_t)r0 * e.ld + c0;
+        if (NS > 0) {
+            float4 v[4][NS > 0 ? NS : 1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int sidx = 0; sidx < NS; ++sidx)
+                    v[r][sidx] = (r0 + r < e.rows)
+                        ? *reinterpret_cast<const float4*>(base + (int64_t)r * e.ld + (int64_t)sidx * e.slab_stride)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float4 a = v[r][0];
+#pragma unroll
+                for (int sidx = 1; sidx < NS; ++sidx) {
+                    a.x += v[r][sidx].x; a.y += v[r][sidx].y; a.z += v[r][sidx].z; a.w += v[r][sidx].w;
+                }
+                pre[r] = a;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r0 + r < e.rows)
+                    for (int sidx = 0; sidx < e.nsplit; ++sidx) {
+                        const float4 t = *reinterpret_cast<const float4*>(base + (int64_t)r * e.ld + (int64_t)sidx * e.slab_stride);
+                        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+                    }
+                pre[r] = a;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r0 + r < e.rows) {
-                const float* p = e.slabs + (int64_t)(r0 + r) * e.ld + c0;
-                for (int s = 0; s < e.nsplit; ++s) {
-                    const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)s * e.slab_stride);
-                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-                }
-                a.x += bias4.x; a.y += bias4.y; a.z += bias4.z; a.w += bias4.w;
-            }
-            pre[r] = a;
+            pre[r].x += bias4.x; pre[r].y += bias4.y; pre[r].z += bias4.z; pre[r].w += bias4.w;
         }
         uint32_t wa[4][4], wb[4][4];       // [col][row]
         const bool need_u = e.sample != nullptr;
@@ -318,6 +462,7 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
                 if (need_z) philox_rows4(e.rng, e.rng.draw | MDBN_NORMAL_BIT, g0, (uint32_t)(c0 + j), wb[j]);
             }
         }
+        float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (r0 + r >= e.rows) continue;
@@ -339,19 +484,22 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
                     m = sigmoidf_(x);
                     if (need_u) sv = philox_u01(wa[j][r]) < m ? 1.0f : 0.0f;
                 }
+                const float tg = comp(tgt4, j);
                 if (e.target && live) {
-                    const float tg = comp(tgt4, j);
                     if (e.gauss) { const float d = sigmoidf_(x) - tg; cost += d * d; }
                     else cost += tg * softplusf_(-x) + (1.0f - tg) * softplusf_(x);
                 }
                 if (!live) { m = 0.f; sv = 0.f; setc(pre[r], j, 0.f); }   // keep pad columns zero
-                setc(mean4, j, m * e.mean_scale);
+                const float ms = m * e.mean_scale;
+                setc(mean4, j, ms);
                 setc(samp4, j, sv);
+                if (live) setc(csum, j, comp(csum, j) + (e.colsum_kind ? tg - m : ms));
             }
             if (e.pre) *reinterpret_cast<float4*>(e.pre + off) = pre[r];
             if (e.mean) *reinterpret_cast<float4*>(e.mean + off) = mean4;
             if (e.sample) *reinterpret_cast<float4*>(e.sample + off) = samp4;
         }
+        if (e.colsum) *reinterpret_cast<float4*>(e.colsum + (int64_t)rg * e.ld + c0) = csum;
     }
     if (e.cost_partials) {
         const float tot = block_sum(cost, red);
@@ -361,7 +509,14 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
 
 hipError_t launch_act_epilogue(const EpiArgs& e, hipStream_t s)
 {
-    hipLaunchKernelGGL(act_epilogue_kernel, dim3(epilogue_blocks(e.rows, e.ld)), dim3(256), 0, s, e);
+    const dim3 grid(epilogue_blocks(e.rows, e.ld)), block(256);
+    switch (e.nsplit) {
+        case 1: hipLaunchKernelGGL(act_epilogue_kernel<1>, grid, block, 0, s, e); break;
+        case 2: hipLaunchKernelGGL(act_epilogue_kernel<2>, grid, block, 0, s, e); break;
+        case 4: hipLaunchKernelGGL(act_epilogue_kernel<4>, grid, block, 0, s, e); break;
+        case 8: hipLaunchKernelGGL(act_epilogue_kernel<8>, grid, block, 0, s, e); break;
+        default: hipLaunchKernelGGL(act_epilogue_kernel<0>, grid, block, 0, s, e); break;
+    }
     return hipGetLastError();
 }
 
@@ -419,77 +574,81 @@ hipError_t launch_gather(const float* src, int64_t n_rows, int64_t cols_ld, int6
 }
 
 // ----------------------------------------------------------------------------------
-// column sums for the bias statistics (rbm.py:416-417), two deterministic passes.
-// Pass 1: partial[c][col] = sum of the rows of chunk c (64 rows, never straddling B).
+// bias statistics (rbm.py:416-417) from the epilogues' 4-row partials, fixed summation
+// order (deterministic):  s_h = sum_g (posP[g] + negP[g]),  s_v = sum_g partV[g];
+// also totals the reconstruction-cost partials.  One block = 64 columns x 4 group slices.
 // ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int B, int64_t ld,
-                                                             int nch, float* __restrict__ partial)
-{
-    __shared__ float4 red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.y, half = c / nch, cc = c - half * nch;
-    const int rbeg = half * B + cc * 64, rend = min(half * B + B, rbeg + 64);
-    const int64_t col = ((int64_t)blockIdx.x * 64 + lane) * 4;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col < ld)
-        for (int r = rbeg + wave; r < rend; r += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(X + (int64_t)r * ld + col);
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-        }
-    red[wave][lane] = a;
-    __syncthreads();
-    if (wave == 0 && col < ld) {
-        float4 t = red[0][lane];
-#pragma unroll
-        for (int k = 1; k < 4; ++k) { t.x += red[k][lane].x; t.y += red[k][lane].y; t.z += red[k][lane].z; t.w += red[k][lane].w; }
-        *reinterpret_cast<float4*>(partial + (int64_t)c * ld + col) = t;
-    }
-}
-
-hipError_t launch_colsum_partial(const float* X, int B, int64_t ld, float* partial, hipStream_t s)
-{
-    const int nch = colsum_chunks(B);
-    dim3 grid((unsigned)((ld / 4 + 63) / 64), (unsigned)(2 * nch));
-    hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, s, X, B, ld, nch, partial);
-    return hipGetLastError();
-}
-
-// Pass 2: s_h = sum_c partP[c]  (P2's second half already holds -nh_mean)
-//         s_v = sum_{c<nch} partV[c] - sum_{c>=nch} partV[c] ; cost_sum = sum cost partials
-__global__ __launch_bounds__(256) void finalize_stats_kernel(const float* __restrict__ partP, const float* __restrict__ partV,
-                                                             int nch, int64_t ldh, int64_t ldv,
+__global__ __launch_bounds__(256) void finalize_stats_kernel(const float* __restrict__ posP, const float* __restrict__ negP,
+                                                             const float* __restrict__ partV, int ngroups,
+                                                             int64_t ldh, int64_t ldv,
                                                              const float* __restrict__ cost_partials, int n_cost,
                                                              float* __restrict__ s_h, float* __restrict__ s_v,
                                                              float* __restrict__ cost)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < ldh) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const int nblk_cols = (int)((ldh + ldv + 63) / 64);
+    if ((int)blockIdx.x < nblk_cols) {
         float a = 0.f;
-        for (int c = 0; c < 2 * nch; ++c) a += partP[(int64_t)c * ldh + i];
-        s_h[i] = a;
-    } else if (i < ldh + ldv) {
-        const int64_t j = i - ldh;
-        float p = 0.f, n = 0.f;
-        for (int c = 0; c < nch; ++c) p += partV[(int64_t)c * ldv + j];
-        for (int c = nch; c < 2 * nch; ++c) n += partV[(int64_t)c * ldv + j];
-        s_v[j] = p - n;
-    }
-    if (blockIdx.x == gridDim.x - 1 && cost_partials) {     // last block also totals the cost
-        __shared__ float red[4];
+        const int per = (ngroups + 3) / 4;
+        const int gbeg = wave * per, gend = min(ngroups, gbeg + per);
+        if (i < ldh) {
+            for (int g = gbeg; g < gend; ++g) a += posP[(int64_t)g * ldh + i] + negP[(int64_t)g * ldh + i];
+        } else if (i < ldh + ldv) {
+            const int64_t j = i - ldh;
+            for (int g = gbeg; g < gend; ++g) a += partV[(int64_t)g * ldv + j];
+        }
+        red[wave][lane] = a;
+        __syncthreads();
+        if (wave == 0) {
+            const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+            if (i < ldh) s_h[i] = t;
+            else if (i < ldh + ldv) s_v[i - ldh] = t;
+        }
+    } else if (cost_partials) {                 // the extra last block totals the cost
+        __shared__ float cred[4];
         float a = 0.f;
         for (int k = threadIdx.x; k < n_cost; k += blockDim.x) a += cost_partials[k];
-        const float t = block_sum(a, red);
+        const float t = block_sum(a, cred);
         if (threadIdx.x == 0) { cost[0] = t; cost[1] = 0.f; cost[2] = 0.f; cost[3] = 0.f; }
     }
 }
 
-hipError_t launch_finalize_stats(const float* partP, const float* partV, int B, int64_t ldh, int64_t ldv,
-                                 const float* cost_partials, int n_cost, float* s_h, float* s_v,
-                                 float* cost, hipStream_t s)
+hipError_t launch_finalize_stats(const float* posP, const float* negP, const float* partV, int ngroups,
+                                 int64_t ldh, int64_t ldv, const float* cost_partials, int n_cost,
+                                 float* s_h, float* s_v, float* cost, hipStream_t s)
 {
-    const int grid = (int)((ldh + ldv + 255) / 256) + 1;
-    hipLaunchKernelGGL(finalize_stats_kernel, dim3(grid), dim3(256), 0, s, partP, partV, colsum_chunks(B),
+    const int grid = (int)((ldh + ldv + 63) / 64) + 1;
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3(grid), dim3(256), 0, s, posP, negP, partV, ngroups,
                        ldh, ldv, cost_partials, n_cost, s_h, s_v, cost);
+    return hipGetLastError();
+}
+
+// column sums over 4-row groups of caller-supplied buffers (mdbn_cd_stats):
+// out[g][col] = sum_{r in group g} (X[r][col] - (Y ? Y[r][col] : 0))
+__global__ __launch_bounds__(256) void colsum_groups_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                            int rows, int64_t ld, float* __restrict__ out)
+{
+    const int ld4 = (int)(ld >> 2);
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int rg = (int)(idx / ld4), cq = (int)(idx - (int64_t)rg * ld4);
+    if (rg * 4 >= rows) return;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = rg * 4; r < min(rows, rg * 4 + 4); ++r) {
+        const float4 v = *reinterpret_cast<const float4*>(X + (int64_t)r * ld + cq * 4);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        if (Y) {
+            const float4 y = *reinterpret_cast<const float4*>(Y + (int64_t)r * ld + cq * 4);
+            a.x -= y.x; a.y -= y.y; a.z -= y.z; a.w -= y.w;
+        }
+    }
+    *reinterpret_cast<float4*>(out + (int64_t)rg * ld + cq * 4) = a;
+}
+
+hipError_t launch_colsum_groups(const float* X, const float* Y, int rows, int64_t ld, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(colsum_groups_kernel, dim3(epilogue_blocks(rows, ld)), dim3(256), 0, s, X, Y, rows, ld, out);
     return hipGetLastError();
 }
 
@@ -499,11 +658,32 @@ hipError_t launch_finalize_stats(const float* partP, const float* partV, int B, 
 //   W'  = W * (1 - 2 lr l2) / (1 + 2 lr l1 / (|W| + eps)) + W_speed(old) * lr
 //   Ws' = g + (W_speed - g) * momentum
 // ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void update_W_kernel(float4* __restrict__ W, float4* __restrict__ Ws,
-                                                       const float4* __restrict__ W0, const float4* __restrict__ S,
-                                                       int64_t n4, float lr, float l1, float l2, float wc,
-                                                       float mu, float inv_bs)
+__global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, float4* __restrict__ Ws,
+                                                     const float4* __restrict__ W0, const float4* __restrict__ S,
+                                                     int64_t n4, float lr, float l1, float l2, float wc,
+                                                     float mu, float inv_bs,
+                                                     float* __restrict__ hb, float* __restrict__ hbs,
+                                                     const float* __restrict__ s_h, int64_t H,
+                                                     float* __restrict__ vb, float* __restrict__ vbs,
+                                                     const float* __restrict__ s_v, int64_t V, float inv_rows,
+                                                     const float* __restrict__ cost_sum, float cost_scale,
+                                                     float* __restrict__ cost_out)
 {
+    if (blockIdx.x == 0) {                      // biases (multipliers are exactly 1, rbm.py:356)
+        for (int64_t i = threadIdx.x; i < H + V; i += blockDim.x) {
+            if (i < H) {
+                const float g = s_h[i] * inv_rows, sp = hbs[i];
+                hbs[i] = g + (sp - g) * mu;
+                hb[i] = hb[i] + sp * lr;
+            } else {
+                const int64_t j = i - H;
+                const float g = s_v[j] * inv_rows, sp = vbs[j];
+                vbs[j] = g + (sp - g) * mu;
+                vb[j] = vb[j] + sp * lr;
+            }
+        }
+        if (threadIdx.x == 0 && cost_out) cost_out[0] = cost_sum[0] * cost_scale;
+    }
     const float two_lr_l1 = 2.0f * lr * l1;
     const float decay = 1.0f - 2.0f * lr * l2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
@@ -529,28 +709,6 @@ __global__ __launch_bounds__(256) void update_W_kernel(float4* __restrict__ W, f
     }
 }
 
-__global__ __launch_bounds__(256) void update_bias_kernel(float* __restrict__ hb, float* __restrict__ hbs,
-                                                          const float* __restrict__ s_h, int64_t H,
-                                                          float* __restrict__ vb, float* __restrict__ vbs,
-                                                          const float* __restrict__ s_v, int64_t V,
-                                                          float lr, float mu, float inv_rows,
-                                                          const float* __restrict__ cost_sum, float cost_scale,
-                                                          float* __restrict__ cost_out)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 && cost_out) cost_out[0] = cost_sum[0] * cost_scale;
-    if (i < H) {
-        const float g = s_h[i] * inv_rows, sp = hbs[i];
-        hbs[i] = g + (sp - g) * mu;
-        hb[i] = hb[i] + sp * lr;
-    } else if (i < H + V) {
-        const int64_t j = i - H;
-        const float g = s_v[j] * inv_rows, sp = vbs[j];
-        vbs[j] = g + (sp - g) * mu;
-        vb[j] = vb[j] + sp * lr;
-    }
-}
-
 hipError_t launch_update(const mdbn_update_args& a, hipStream_t s)
 {
     const int64_t n4 = (a.V * a.ldh) >> 2;
@@ -558,16 +716,11 @@ hipError_t launch_update(const mdbn_update_args& a, hipStream_t s)
     const float* s_h = a.stats + a.V * a.ldh;
     const float* s_v = s_h + a.ldh;
     const int grid = (int)std::min<int64_t>((n4 + 255) / 256, 4096);
-    hipLaunchKernelGGL(update_W_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<float4*>(a.W),
+    hipLaunchKernelGGL(update_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<float4*>(a.W),
                        reinterpret_cast<float4*>(a.W_speed), reinterpret_cast<const float4*>(a.W0),
                        reinterpret_cast<const float4*>(S), n4, a.lr, a.lambda_1, a.lambda_2, a.weightcost,
-                       a.momentum, 1.0f / a.batch_size);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    const int gb = (int)((a.H + a.V + 255) / 256);
-    hipLaunchKernelGGL(update_bias_kernel, dim3(gb), dim3(256), 0, s, a.hbias, a.hbias_speed, s_h, a.H,
-                       a.vbias, a.vbias_speed, s_v, a.V, a.lr, a.momentum, 1.0f / a.n_rows,
-                       s_v + a.ldv, a.cost_scale, a.cost_out);
+                       a.momentum, 1.0f / a.batch_size, a.hbias, a.hbias_speed, s_h, a.H, a.vbias,
+                       a.vbias_speed, s_v, a.V, 1.0f / a.n_rows, s_v + a.ldv, a.cost_scale, a.cost_out);
     return hipGetLastError();
 }
 
