@@ -145,6 +145,18 @@ __device__ __forceinline__ float frag(const float* __restrict__ T, int mn, int k
 // slice next to a partner wave's MFMAs and the matrix pipe idled 26-38% of the time.)
 // ----------------------------------------------------------------------------------
 constexpr int GEMM_THREADS = 512;
+#ifndef ABLATE_STORE
+#define ABLATE_STORE 0    // diagnostic builds only: timing ablations of the producer
+#endif
+#ifndef PRODUCER_SLEEP
+#define PRODUCER_SLEEP 0    // x64 cycles of delay before the store burst (measured: any delay only hurts)
+#endif
+#ifndef PRODUCER_PRIO
+#define PRODUCER_PRIO 3
+#endif
+#ifndef ABLATE_LOAD
+#define ABLATE_LOAD 0
+#endif
 
 template <int LA, int LB, int MI, int NI, bool GUARD>
 __device__ __forceinline__ void gemm_produce(const GemmArgs& g, float* __restrict__ smem, int m0, int n0,
@@ -164,13 +176,14 @@ __device__ __forceinline__ void gemm_produce(const GemmArgs& g, float* __restric
 #define PRODUCER_STEP(RA, RB)                                                                 \
     do {                                                                                      \
         STAMP(0);                                                                             \
-        if (it + 1 < nt) {                                                                    \
+        __builtin_amdgcn_s_sleep(PRODUCER_SLEEP);                                             \
+        if (it + 1 < nt && !ABLATE_STORE) {                                                   \
             float* nx = smem + ((it + 1) & 1) * BUF;   /* all reads of it ended at the last barrier */ \
             store_tile<LA, BM>(nx, RA);                                                       \
             store_tile<LB, BN>(nx + A_FLOATS, RB);                                            \
         }                                                                                     \
         STAMP(1);                                                                             \
-        if (it + 3 < nt) PRODUCER_LOAD(RA, RB, it + 3);                                       \
+        if (it + 3 < nt && !ABLATE_LOAD) PRODUCER_LOAD(RA, RB, it + 3);                       \
         STAMP(2);                                                                             \
         __syncthreads();                                                                      \
         STAMP(3);                                                                             \
@@ -266,6 +279,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= 4) {
+        // the few staging instructions must not queue behind the partner wave's MFMA stream
+        __builtin_amdgcn_s_setprio(PRODUCER_PRIO);
         const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (kbeg + nt * BK <= g.K);
         if (interior) gemm_produce<LA, LB, MI, NI, false>(g, smem, m0, n0, kbeg, kend, nt);
         else gemm_produce<LA, LB, MI, NI, true>(g, smem, m0, n0, kbeg, kend, nt);
@@ -339,10 +354,18 @@ hipError_t launch_gemm(int la, int lb, const GemmArgs& g, hipStream_t s)
 // ----------------------------------------------------------------------------------
 // small device helpers
 // ----------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid / softplus on the hardware transcendentals (v_exp_f32, v_log_f32, v_rcp_f32: ~1 ulp
+// each).  |error| of sigmoid <= ~1e-7 absolute: the exponent's argument rounding |x|*6e-8 is
+// multiplied by sigmoid' = p(1-p) <= 1/4.  The libm-grade expf/division these replace made
+// the epilogue VALU-bound (14 us per call at B*H = 512K elements).
+__device__ __forceinline__ float sigmoidf_(float x)
+{
+    return __frcp_rn(1.0f + __expf(-x));
+}
 __device__ __forceinline__ float softplusf_(float x)
 {
-    return x > 0.f ? x + log1pf(expf(-x)) : log1pf(expf(x));
+    // max(x, 0) + log1p(exp(-|x|)): the log argument is in (1, 2], no cancellation
+    return fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x)));
 }
 
 __device__ __forceinline__ float block_sum(float v, float* red /* >= 4 floats */)
@@ -594,9 +617,11 @@ __global__ __launch_bounds__(256) void finalize_stats_kernel(const float* __rest
         const int per = (ngroups + 3) / 4;
         const int gbeg = wave * per, gend = min(ngroups, gbeg + per);
         if (i < ldh) {
+#pragma unroll 8
             for (int g = gbeg; g < gend; ++g) a += posP[(int64_t)g * ldh + i] + negP[(int64_t)g * ldh + i];
         } else if (i < ldh + ldv) {
             const int64_t j = i - ldh;
+#pragma unroll 8
             for (int g = gbeg; g < gend; ++g) a += partV[(int64_t)g * ldv + j];
         }
         red[wave][lane] = a;
@@ -669,20 +694,19 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
                                                      const float* __restrict__ cost_sum, float cost_scale,
                                                      float* __restrict__ cost_out)
 {
-    if (blockIdx.x == 0) {                      // biases (multipliers are exactly 1, rbm.py:356)
-        for (int64_t i = threadIdx.x; i < H + V; i += blockDim.x) {
-            if (i < H) {
-                const float g = s_h[i] * inv_rows, sp = hbs[i];
-                hbs[i] = g + (sp - g) * mu;
-                hb[i] = hb[i] + sp * lr;
-            } else {
-                const int64_t j = i - H;
-                const float g = s_v[j] * inv_rows, sp = vbs[j];
-                vbs[j] = g + (sp - g) * mu;
-                vb[j] = vb[j] + sp * lr;
-            }
+    {   // biases, one element per thread of the leading blocks (multipliers are exactly 1, rbm.py:356)
+        const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < H) {
+            const float g = s_h[i] * inv_rows, sp = hbs[i];
+            hbs[i] = g + (sp - g) * mu;
+            hb[i] = hb[i] + sp * lr;
+        } else if (i < H + V) {
+            const int64_t j = i - H;
+            const float g = s_v[j] * inv_rows, sp = vbs[j];
+            vbs[j] = g + (sp - g) * mu;
+            vb[j] = vb[j] + sp * lr;
         }
-        if (threadIdx.x == 0 && cost_out) cost_out[0] = cost_sum[0] * cost_scale;
+        if (i == 0 && cost_out) cost_out[0] = cost_sum[0] * cost_scale;
     }
     const float two_lr_l1 = 2.0f * lr * l1;
     const float decay = 1.0f - 2.0f * lr * l2;
@@ -715,7 +739,7 @@ hipError_t launch_update(const mdbn_update_args& a, hipStream_t s)
     const float* S = a.stats;
     const float* s_h = a.stats + a.V * a.ldh;
     const float* s_v = s_h + a.ldh;
-    const int grid = (int)std::min<int64_t>((n4 + 255) / 256, 4096);
+    const int grid = (int)std::max<int64_t>(std::min<int64_t>((n4 + 255) / 256, 4096), (a.H + a.V + 255) / 256);
     hipLaunchKernelGGL(update_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<float4*>(a.W),
                        reinterpret_cast<float4*>(a.W_speed), reinterpret_cast<const float4*>(a.W0),
                        reinterpret_cast<const float4*>(S), n4, a.lr, a.lambda_1, a.lambda_2, a.weightcost,
