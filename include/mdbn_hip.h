@@ -87,6 +87,13 @@ typedef struct mdbn_update_args {
     float n_rows;                   /* divisor of s_h, s_v: rows actually present (rbm.py:416-417) */
     float cost_scale;               /* monitoring cost = stats.cost_sum * cost_scale ...          */
     float *cost_out;                /* ... written here (device scalar) if not NULL               */
+    int32_t phase;                  /* 0 = whole rule; 1 = speeds (+cost) only; 2 = parameters only.
+                                     * Because the parameter step uses the OLD speed (rbm.py:364-365),
+                                     * theta(t+1) never depends on step t's gradient: a data-parallel
+                                     * run applies phase 2 at once and phase 1 when the all-reduced
+                                     * statistics arrive, overlapping the collective with the next step
+                                     * (requires lambda_1 == 0 and weightcost == 0 or a frozen W0). */
+    int32_t reserved;
 } mdbn_update_args;
 
 int  mdbn_version(void);

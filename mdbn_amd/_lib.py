@@ -37,7 +37,8 @@ class UpdateArgs(C.Structure):
                 ("lr", C.c_float), ("lambda_1", C.c_float), ("lambda_2", C.c_float),
                 ("weightcost", C.c_float), ("momentum", C.c_float),
                 ("batch_size", C.c_float), ("n_rows", C.c_float),
-                ("cost_scale", C.c_float), ("cost_out", C.c_void_p)]
+                ("cost_scale", C.c_float), ("cost_out", C.c_void_p),
+                ("phase", C.c_int32), ("reserved", C.c_int32)]
 
 
 _i64, _i32, _f32, _vp = C.c_int64, C.c_int, C.c_float, C.c_void_p

@@ -465,6 +465,9 @@ int mdbn_apply_update(mdbn_ctx* ctx, void* stream, const mdbn_update_args* a)
     REQUIRE(a->stats != nullptr && aligned16(a->stats), "stats not aligned");
     REQUIRE(a->hbias && a->hbias_speed && a->vbias && a->vbias_speed, "bias pointers are NULL");
     REQUIRE(a->batch_size > 0.f && a->n_rows > 0.f, "bad divisors");
+    REQUIRE(a->phase >= 0 && a->phase <= 2, "phase must be 0, 1 or 2");
+    REQUIRE(a->phase == 0 || (a->lambda_1 == 0.f && (a->weightcost == 0.f || a->W0 != nullptr)),
+            "split update phases need lambda_1 == 0 and weightcost == 0 or a frozen W0");
     HIP_OK(launch_update(*a, (hipStream_t)stream));
     return MDBN_OK;
 }

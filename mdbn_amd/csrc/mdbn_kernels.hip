@@ -692,28 +692,31 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
                                                      float* __restrict__ vb, float* __restrict__ vbs,
                                                      const float* __restrict__ s_v, int64_t V, float inv_rows,
                                                      const float* __restrict__ cost_sum, float cost_scale,
-                                                     float* __restrict__ cost_out)
+                                                     float* __restrict__ cost_out, int do_speed, int do_params)
 {
     {   // biases, one element per thread of the leading blocks (multipliers are exactly 1, rbm.py:356)
         const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         if (i < H) {
-            const float g = s_h[i] * inv_rows, sp = hbs[i];
-            hbs[i] = g + (sp - g) * mu;
-            hb[i] = hb[i] + sp * lr;
+            const float sp = hbs[i];
+            if (do_speed) { const float g = s_h[i] * inv_rows; hbs[i] = g + (sp - g) * mu; }
+            if (do_params) hb[i] = hb[i] + sp * lr;
         } else if (i < H + V) {
             const int64_t j = i - H;
-            const float g = s_v[j] * inv_rows, sp = vbs[j];
-            vbs[j] = g + (sp - g) * mu;
-            vb[j] = vb[j] + sp * lr;
+            const float sp = vbs[j];
+            if (do_speed) { const float g = s_v[j] * inv_rows; vbs[j] = g + (sp - g) * mu; }
+            if (do_params) vb[j] = vb[j] + sp * lr;
         }
-        if (i == 0 && cost_out) cost_out[0] = cost_sum[0] * cost_scale;
+        if (i == 0 && cost_out && do_speed) cost_out[0] = cost_sum[0] * cost_scale;
     }
     const float two_lr_l1 = 2.0f * lr * l1;
     const float decay = 1.0f - 2.0f * lr * l2;
+    const bool need_w = do_params || l1 != 0.0f || (wc != 0.0f && W0 == nullptr);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 w = W[i], sp = Ws[i], st = S[i];
-        const float4 wc0 = W0 ? W0[i] : w;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 w = need_w ? W[i] : zero, sp = Ws[i];
+        const float4 st = do_speed ? S[i] : zero;
+        const float4 wc0 = (do_speed && wc != 0.0f) ? (W0 ? W0[i] : w) : zero;
         float4 wn, sn;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -728,8 +731,8 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
             setc(sn, j, g + (spj - g) * mu);
             setc(wn, j, wj * m + spj * lr);
         }
-        W[i] = wn;
-        Ws[i] = sn;
+        if (do_params) W[i] = wn;
+        if (do_speed) Ws[i] = sn;
     }
 }
 
@@ -744,7 +747,8 @@ hipError_t launch_update(const mdbn_update_args& a, hipStream_t s)
                        reinterpret_cast<float4*>(a.W_speed), reinterpret_cast<const float4*>(a.W0),
                        reinterpret_cast<const float4*>(S), n4, a.lr, a.lambda_1, a.lambda_2, a.weightcost,
                        a.momentum, 1.0f / a.batch_size, a.hbias, a.hbias_speed, s_h, a.H, a.vbias,
-                       a.vbias_speed, s_v, a.V, 1.0f / a.n_rows, s_v + a.ldv, a.cost_scale, a.cost_out);
+                       a.vbias_speed, s_v, a.V, 1.0f / a.n_rows, s_v + a.ldv, a.cost_scale, a.cost_out,
+                       a.phase != 2, a.phase != 1);
     return hipGetLastError();
 }
 

@@ -220,6 +220,7 @@ class DBN(object):
                     if patience <= iter:                                # dbn.py:506-508
                         done_looping = True
                         break
+            training_fns[i].flush()
             history.append(records)
 
         end_time = timeit.default_timer()

@@ -22,6 +22,11 @@ class Group(object):
         td.all_reduce(tensor, op=td.ReduceOp.SUM, group=self.pg)
         return tensor
 
+    def all_reduce_sum_async(self, tensor):
+        """Start the sum all-reduce and return the work handle; ``handle.wait()`` makes the
+        current stream (not the host, on RCCL) wait for the result."""
+        return td.all_reduce(tensor, op=td.ReduceOp.SUM, group=self.pg, async_op=True)
+
 
 def shard_bounds(n, rank, world_size):
     base, rem = divmod(int(n), int(world_size))

@@ -154,8 +154,8 @@ class HipEngine(object):
             self._ws_key = (B, V, H)
         return self._workspace
 
-    def stats_buffer(self, V, H):
-        key = (V, H)
+    def stats_buffer(self, V, H, slot=0):
+        key = (V, H, slot)
         if key not in self._stats:
             n = C.c_int64()
             _lib.check(self.lib.mdbn_stats_floats(V, H, C.byref(n)), "mdbn_stats_floats")
@@ -241,7 +241,8 @@ class HipEngine(object):
         return out
 
     # ------------------------------------------------------------------ CD-k
-    def cd_step(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent=None, add_noise=False):
+    def cd_step(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent=None, add_noise=False,
+                stats_slot=0):
         """gather + positive phase + k Gibbs steps + statistics (rbm.py:303-345,374).
         Returns (stats, scratch): the packed [S | s_h | s_v | cost_sum] buffer and the
         CDScratch holding ph_mean / nv_mean / nh_mean for inspection."""
@@ -251,7 +252,7 @@ class HipEngine(object):
         idx = self.index_tensor(indexes) if indexes is not None else None
         B = idx.numel() if idx is not None else data.shape[0]
         sc = self.cd_scratch(B, V, H, need_vs=not gauss)
-        stats = self.stats_buffer(V, H)
+        stats = self.stats_buffer(V, H, stats_slot)
         ws = self.workspace(B, V, H)
         a = _lib.CdArgs()
         a.data, a.n_data = data.data_ptr(), data.shape[0]
@@ -271,8 +272,9 @@ class HipEngine(object):
         return stats, sc
 
     def apply_update(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats,
-                     lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale):
-        """rbm.py:347-365; returns the monitoring cost as a 0-d device tensor."""
+                     lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale, phase=0):
+        """rbm.py:347-365; returns the monitoring cost as a 0-d device tensor.
+        phase: 0 = whole rule, 1 = speeds (+cost) only, 2 = parameters only (mdbn_update_args)."""
         V, H = W.shape
         slot = self._cost_slot
         self._cost_slot = (slot + 1) % self._cost_ring.numel()
@@ -288,6 +290,7 @@ class HipEngine(object):
         u.weightcost, u.momentum = float(weightcost), float(momentum)
         u.batch_size, u.n_rows, u.cost_scale = float(batch_size), float(n_rows), float(cost_scale)
         u.cost_out = cost.data_ptr()
+        u.phase = int(phase)
         _lib.check(self.lib.mdbn_apply_update(self.ctx, self._stream(), C.byref(u)), "mdbn_apply_update")
         return cost
 

@@ -49,6 +49,28 @@ class UpdatePlan(object):
         self.batch_size, self.persistent, self.W0 = batch_size, persistent, W0
 
 
+class LazyCost(object):
+    """Monitoring cost of a data-parallel step whose all-reduce is still in flight: resolving
+    it (``float(c)``) completes the deferred part of that step first."""
+
+    def __init__(self, stepfn, token):
+        self._stepfn, self._token, self._value = stepfn, token, None
+
+    def _resolve(self):
+        if self._value is None:
+            self._stepfn._resolve_cost(self)
+        return self._value
+
+    def reshape(self, *shape):
+        return self._resolve().reshape(*shape)
+
+    def __float__(self):
+        return float(self._resolve())
+
+    def item(self):
+        return float(self)
+
+
 class StepFunction(object):
     """One compiled training step: ``fn(indexes=, momentum=, lr=)`` -> monitoring cost
     (0-d device tensor; ``float(cost)`` synchronises).
@@ -56,9 +78,17 @@ class StepFunction(object):
     Data-parallel: with an initialised ``torch.distributed`` group of N ranks
     each rank computes the statistics of its contiguous slice of the minibatch, the packed
     [S | s_h | s_v | cost] buffer is sum-all-reduced (RCCL over xGMI), and every rank applies
-    the same update; ``batch_size`` is the global minibatch size (rbm.py:413)."""
+    the same update; ``batch_size`` is the global minibatch size (rbm.py:413).
 
-    def __init__(self, updates, train_set_x, input_fn=None, name=None, data_parallel="auto"):
+    Overlap: the parameter step uses the OLD speed (rbm.py:364-365), so theta(t+1) does not
+    depend on step t's gradient.  With ``overlap=True`` (default when eligible: lambda_1 == 0
+    and weightcost == 0 or a frozen W0) the all-reduce of step t is started asynchronously,
+    theta(t+1) is applied at once, and the speed update that needs the reduced statistics runs
+    at the end of step t+1 -- the collective hides behind a whole step of compute while every
+    value stays bit-identical to the synchronous order.  ``flush()`` completes the deferred
+    part (called automatically when speeds or the cost are read)."""
+
+    def __init__(self, updates, train_set_x, input_fn=None, name=None, data_parallel="auto", overlap=True):
         self.plan = updates
         self.rbm = updates.rbm
         self.engine = self.rbm.engine
@@ -66,12 +96,45 @@ class StepFunction(object):
         self.input_fn = input_fn            # maps the DBN's data matrix to this layer's input
         self.name = name
         self.group = _dist.default_group() if data_parallel == "auto" else data_parallel
-        self._pending = None
+        p = updates
+        self.overlap = bool(overlap and self.group is not None and self.group.world_size > 1
+                            and p.persistent is None and p.lambda_1 == 0.0
+                            and (p.weightcost == 0.0 or p.W0 is not None))
+        self._pending = None                # (work, stats, hyper-parameters, LazyCost) of the last step
+        self._n_calls = 0
+        if self.overlap:
+            for arr in self.rbm.params_speed:
+                arr._sync_hook = self.flush
 
     def _data(self):
         if self.input_fn is not None:
             return self.input_fn()
         return self.engine.as_matrix(self.train_set_x)
+
+    # -- deferred half of an overlapped step: speeds (and cost) from the reduced statistics
+    def _complete_pending(self):
+        if self._pending is None:
+            return
+        work, stats, hp, lazy = self._pending
+        self._pending = None
+        work.wait()
+        rbm, p = self.rbm, self.plan
+        cost = self.engine.apply_update(
+            rbm.W.tensor, rbm.W_speed.tensor, p.W0.tensor if p.W0 is not None else None,
+            rbm.hbias.tensor, rbm.hbias_speed.tensor, rbm.vbias.tensor, rbm.vbias_speed.tensor, stats,
+            hp["lr"], p.lambda_1, p.lambda_2, p.weightcost, hp["momentum"], hp["batch_size"],
+            hp["n_rows"], hp["cost_scale"], phase=1)
+        lazy._value = cost
+
+    def _resolve_cost(self, lazy):
+        if self._pending is not None and self._pending[3] is lazy:
+            self._complete_pending()
+        if lazy._value is None:
+            raise RuntimeError("cost of a step that was never completed")
+
+    def flush(self):
+        """Complete the deferred speed update of the last overlapped step (no-op otherwise)."""
+        self._complete_pending()
 
     def __call__(self, indexes=None, momentum=0.0, lr=None):
         p, rbm, eng = self.plan, self.rbm, self.engine
@@ -82,6 +145,7 @@ class StepFunction(object):
         data = self._data()
         n_global = data.shape[0] if indexes is None else len(indexes)
         batch_size = p.batch_size if p.batch_size is not None else n_global
+        distributed = self.group is not None and self.group.world_size > 1
 
         # data-parallel shard of the minibatch: contiguous rows [lo, hi) of `indexes`
         lo, hi = 0, n_global
@@ -95,23 +159,23 @@ class StepFunction(object):
         step = rbm._take_step()
         persistent = None
         if p.persistent is not None:
-            if self.group is not None and self.group.world_size > 1:
+            if distributed:
                 raise NotImplementedError("PCD chains are not sharded across ranks yet")
             persistent = p.persistent.tensor
             if persistent.shape[0] != n_global:
                 raise ValueError("persistent chain has %d rows but the minibatch has %d "
                                  "(the reference fails the same way, rbm.py:416)"
                                  % (persistent.shape[0], n_global))
+        slot = self._n_calls & 1 if self.overlap else 0     # the other buffer may still be reducing
+        self._n_calls += 1
         if hi > lo:
             stats, _ = eng.cd_step(data, idx, rbm.W.tensor, rbm.hbias.tensor, rbm.vbias.tensor,
                                    rbm.gauss, p.k,
                                    RngAddr(rbm.theano_rng.seed, rbm.stream_id, step, 0, lo),
-                                   persistent=persistent)
+                                   persistent=persistent, stats_slot=slot)
         else:                                  # this rank holds no row of a short minibatch
-            stats = eng.stats_buffer(rbm.n_visible, rbm.n_hidden)
+            stats = eng.stats_buffer(rbm.n_visible, rbm.n_hidden, slot)
             stats.zero_()
-        if self.group is not None and self.group.world_size > 1:
-            self.group.all_reduce_sum(stats)
 
         if p.persistent is not None:
             # PCD monitors the pseudo-likelihood (rbm.py:371) with pre-update parameters
@@ -121,21 +185,33 @@ class StepFunction(object):
             cost = None
             # rbm.py:480 (sum over units, mean over rows) / rbm.py:697 (mean over everything)
             cost_scale = 1.0 / (n_global * rbm.n_visible) if rbm.gauss else 1.0 / n_global
-        out = eng.apply_update(rbm.W.tensor, rbm.W_speed.tensor,
-                               p.W0.tensor if p.W0 is not None else None,
-                               rbm.hbias.tensor, rbm.hbias_speed.tensor,
-                               rbm.vbias.tensor, rbm.vbias_speed.tensor, stats,
-                               lr, p.lambda_1, p.lambda_2, p.weightcost, momentum,
+        args = (rbm.W.tensor, rbm.W_speed.tensor, p.W0.tensor if p.W0 is not None else None,
+                rbm.hbias.tensor, rbm.hbias_speed.tensor, rbm.vbias.tensor, rbm.vbias_speed.tensor)
+
+        if self.overlap:
+            work = self.group.all_reduce_sum_async(stats)
+            self._complete_pending()            # speeds(t) from the statistics of step t-1 ...
+            eng.apply_update(*args, stats, lr, p.lambda_1, p.lambda_2, p.weightcost, momentum,
+                             batch_size, n_global, cost_scale, phase=2)   # ... then theta(t+1)
+            lazy = LazyCost(self, self._n_calls)
+            self._pending = (work, stats, dict(lr=lr, momentum=momentum, batch_size=batch_size,
+                                               n_rows=n_global, cost_scale=cost_scale), lazy)
+            rbm._n_updates += 1
+            return lazy
+
+        if distributed:
+            self.group.all_reduce_sum(stats)
+        out = eng.apply_update(*args, stats, lr, p.lambda_1, p.lambda_2, p.weightcost, momentum,
                                batch_size, n_global, cost_scale)
         rbm._n_updates += 1
         return cost if cost is not None else out
 
 
-def function(updates, train_set_x=None, input_fn=None, name=None, data_parallel="auto"):
+def function(updates, train_set_x=None, input_fn=None, name=None, data_parallel="auto", overlap=True):
     """Stand-in for ``theano.function([indexes, momentum, lr], cost, updates=updates,
     givens={x: train_set_x[indexes], rbm.momentum: momentum})`` (dbn.py:302-312)."""
     return StepFunction(updates, train_set_x, input_fn=input_fn, name=name,
-                        data_parallel=data_parallel)
+                        data_parallel=data_parallel, overlap=overlap)
 
 
 class RBM(object):
@@ -352,13 +428,14 @@ class RBM(object):
             costs, start, total = [], 0, 0.0
             for batch_indexes in minibatches:
                 n = len(batch_indexes)
-                costs.append(train_rbm(dev_idx[start:start + n], momentum).reshape(()))
+                costs.append(train_rbm(dev_idx[start:start + n], momentum))
                 start += n
                 if len(costs) >= 256:
-                    total = total + torch.stack(costs).sum()
+                    total = total + torch.stack([c.reshape(()) for c in costs]).sum()
                     costs = []
+            train_rbm.flush()
             if costs:
-                total = total + torch.stack(costs).sum()
+                total = total + torch.stack([c.reshape(()) for c in costs]).sum()
             mean_cost = float(total) / len(minibatches)
             feg = None
             if n_val:

@@ -14,6 +14,7 @@ class SharedArray(object):
     def __init__(self, value, name=None, engine=None, _tensor=None):
         self.engine = engine if engine is not None else get_engine()
         self.name = name
+        self._sync_hook = None      # called before host reads (completes deferred device work)
         if _tensor is not None:
             self.tensor = _tensor
         else:
@@ -23,6 +24,8 @@ class SharedArray(object):
     def get_value(self, borrow=False, return_internal_type=False):
         """Host copy (float32 ndarray).  ``borrow`` is accepted for signature parity; device
         memory cannot be borrowed by numpy, so a copy is always returned."""
+        if self._sync_hook is not None:
+            self._sync_hook()
         if return_internal_type:
             return self.tensor
         return self.engine.to_numpy(self.tensor)

@@ -54,8 +54,8 @@ class OracleEngine(object):
             return indexes.to(torch.int64)
         return torch.from_numpy(np.asarray(indexes).astype(np.int64))
 
-    def stats_buffer(self, V, H):
-        key = (V, H)
+    def stats_buffer(self, V, H, slot=0):
+        key = (V, H, slot)
         if key not in self._stats:
             self._stats[key] = torch.zeros(V * H + H + V + 4, dtype=self.t_dtype)
         return self._stats[key]
@@ -112,7 +112,8 @@ class OracleEngine(object):
         return self.as_matrix(src)[self.index_tensor(indexes)].clone()
 
     # --- CD-k
-    def cd_step(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent=None, add_noise=False):
+    def cd_step(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent=None, add_noise=False,
+                stats_slot=0):
         data = self.as_matrix(data)
         v0 = (data if indexes is None else data[self.index_tensor(indexes)]).numpy()
         s = self._state(W, hbias, vbias, gauss)
@@ -127,7 +128,7 @@ class OracleEngine(object):
             cost = (v0 * rbm_np.softplus(-pre_nv) + (1 - v0) * rbm_np.softplus(pre_nv)).sum()
         if persistent is not None:
             persistent.copy_(self._t(nh_sample))
-        stats = self.stats_buffer(*W.shape)
+        stats = self.stats_buffer(W.shape[0], W.shape[1], stats_slot)
         stats.copy_(self._t(np.concatenate([S.ravel(), s_h, s_v, [cost, 0, 0, 0]])))
         sc = _Scratch()
         sc.ph_mean, sc.nv_mean, sc.nh_mean, sc.ph_sample = ph_mean, nv_mean, nh_mean, ph_sample
@@ -135,7 +136,7 @@ class OracleEngine(object):
         return stats, sc
 
     def apply_update(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats,
-                     lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale):
+                     lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale, phase=0):
         V, H = W.shape
         s = rbm_np.RBMState(V, H, W=W.numpy(), hbias=hbias.numpy(), vbias=vbias.numpy(),
                             dtype=self.np_dtype)
@@ -148,8 +149,9 @@ class OracleEngine(object):
         s_v = st[V * H + H:V * H + H + V]
         g = rbm_np.rbm_grad(s, S, s_h, s_v, batch_size, n_rows, weightcost, strict_reference=W0 is not None)
         rbm_np.apply_update(s, g[0], g[1], g[2], lr, lambda_1, lambda_2, momentum)
-        for dst, src in ((W, s.W), (W_speed, s.W_speed), (hbias, s.hbias), (hbias_speed, s.hbias_speed),
-                         (vbias, s.vbias), (vbias_speed, s.vbias_speed)):
+        params = ((W, s.W), (hbias, s.hbias), (vbias, s.vbias))
+        speeds = ((W_speed, s.W_speed), (hbias_speed, s.hbias_speed), (vbias_speed, s.vbias_speed))
+        for dst, src in (params if phase != 1 else ()) + (speeds if phase != 2 else ()):
             dst.copy_(self._t(src))
         return torch.tensor(float(st[V * H + H + V]) * cost_scale, dtype=self.t_dtype)
 

@@ -1,0 +1,114 @@
+"""Data-parallel path on CPU: world_size 2 over gloo with the checker engine.
+
+  * N ranks on row shards of each minibatch == one process on the whole minibatch with
+    batch_size = global size, for GRBM and Bernoulli RBM, even and ragged shards;
+  * the overlapped mode (all-reduce of step t hidden behind step t+1, speed update deferred)
+    is BIT-identical to the synchronous order, including after flush();
+  * a rank that owns no row of a short minibatch still takes part in the collective.
+"""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def make_problem(gauss):
+    V, H, N = 12, 7, 40
+    rs = np.random.RandomState(0)
+    data = rs.normal(size=(N, V)) if gauss else (rs.uniform(size=(N, V)) < 0.4).astype(np.float64)
+    batches = [rs.permutation(N)[:n].astype(np.int64) for n in (10, 10, 7, 10, 1, 10)]
+    return V, H, data, batches
+
+
+def run_steps(gauss, overlap, group_mode):
+    """Runs in every rank (or alone): returns final parameters, speeds and costs."""
+    import mdbn_amd
+    from _oracle_engine import OracleEngine
+    eng = mdbn_amd.set_engine(OracleEngine())
+    V, H, data, batches = make_problem(gauss)
+    cls = mdbn_amd.GRBM if gauss else mdbn_amd.RBM
+    rbm = cls(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(5),
+              theano_rng=mdbn_amd.RandomStreams(11), engine=eng)
+    hp = dict(lambda_2=0.1) if gauss else dict(weightcost=2e-4)
+    _, up = rbm.get_cost_updates(lr=0.05, k=2, batch_size=10, **hp)
+    fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=eng),
+                           data_parallel="auto" if group_mode else None, overlap=overlap)
+    assert fn.overlap == (overlap and group_mode)
+    costs = [fn(indexes=b, momentum=0.5) for b in batches]
+    mid_speed = rbm.W_speed.get_value().copy()          # reading a speed flushes the pipeline
+    costs = [float(c) for c in costs]
+    fn.flush()
+    return dict(W=rbm.W.tensor.numpy().copy(), Ws=rbm.W_speed.tensor.numpy().copy(),
+                hb=rbm.hbias.tensor.numpy().copy(), vbs=rbm.vbias_speed.tensor.numpy().copy(),
+                mid=mid_speed, costs=np.array(costs))
+
+
+def worker(rank, world, port, outdir, gauss, overlap):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from mdbn_amd import dist
+    dist.init_from_env(backend="gloo")
+    out = run_steps(gauss, overlap, True)
+    np.savez(os.path.join(outdir, "rank%d_%d_%d.npz" % (rank, gauss, overlap)), **out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def dp_results():
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for gauss in (1, 0):
+            for overlap in (0, 1):
+                mp.spawn(worker, args=(2, free_port(), d, gauss, overlap), nprocs=2, join=True)
+                res[(gauss, overlap)] = [dict(np.load(os.path.join(d, "rank%d_%d_%d.npz" % (r, gauss, overlap))))
+                                         for r in range(2)]
+    return res
+
+
+@pytest.mark.parametrize("gauss", [1, 0])
+def test_dp_equals_single_process(dp_results, gauss):
+    sys.path.insert(0, HERE)
+    single = run_steps(gauss, False, False)
+    for overlap in (0, 1):
+        r0, r1 = dp_results[(gauss, overlap)]
+        for k in single:
+            assert np.array_equal(r0[k], r1[k]), "replicas diverged: %s" % k      # identical on every rank
+            np.testing.assert_allclose(r0[k], single[k], rtol=1e-11, atol=1e-13, err_msg=k)
+
+
+@pytest.mark.parametrize("gauss", [1, 0])
+def test_overlap_is_bit_identical_to_sync(dp_results, gauss):
+    sync, ovl = dp_results[(gauss, 0)][0], dp_results[(gauss, 1)][0]
+    for k in sync:
+        assert np.array_equal(sync[k], ovl[k]), k
+
+
+def test_shard_bounds():
+    from mdbn_amd.dist import shard_bounds
+    for n in (0, 1, 7, 8, 512, 513):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

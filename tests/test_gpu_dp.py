@@ -1,0 +1,101 @@
+"""Data-parallel rehearsal on the one-GPU box: two processes share cuda:0 and exchange the
+statistics over gloo (RCCL needs one GPU per rank), running the real HIP kernels through the
+same StepFunction code the 8-GPU bench uses."""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+V, H, N, BG = 320, 192, 1024, 256
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_steps(group_mode, overlap):
+    import mdbn_amd
+    eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
+    rs = np.random.RandomState(0)
+    data = rs.normal(size=(N, V)).astype(np.float32)
+    rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123),
+                        theano_rng=mdbn_amd.RandomStreams(3), engine=eng)
+    _, up = rbm.get_cost_updates(lr=0.002, k=1, lambda_2=0.1, batch_size=BG)
+    fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=eng),
+                           data_parallel="auto" if group_mode else None, overlap=overlap)
+    costs = []
+    for t in range(6):
+        idx = rs.permutation(N)[:BG]
+        costs.append(fn(indexes=idx, momentum=0.3))
+    costs = [float(c) for c in costs]
+    fn.flush()
+    return dict(W=rbm.W.get_value(), Ws=rbm.W_speed.get_value(), vb=rbm.vbias.get_value(),
+                hbs=rbm.hbias_speed.get_value(), costs=np.array(costs))
+
+
+def worker(rank, world, port, outdir, overlap):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from mdbn_amd import dist
+    dist.init_from_env(backend="gloo")
+    out = run_steps(True, overlap)
+    np.savez(os.path.join(outdir, "rank%d_%d.npz" % (rank, overlap)), **out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process_on_device(built_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    single = run_steps(False, False)
+    with tempfile.TemporaryDirectory() as d:
+        res = {}
+        for overlap in (0, 1):
+            mp.spawn(worker, args=(2, free_port(), d, overlap), nprocs=2, join=True)
+            res[overlap] = [dict(np.load(os.path.join(d, "rank%d_%d.npz" % (r, overlap)))) for r in range(2)]
+    for overlap in (0, 1):
+        r0, r1 = res[overlap]
+        for k in single:
+            assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
+            tol = 2e-6 * max(1.0, np.abs(single[k]).max())
+            assert np.abs(r0[k] - single[k]).max() <= tol, (k, np.abs(r0[k] - single[k]).max())
+    for k in single:                     # overlapped == synchronous, bit for bit
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
+
+
+def test_split_update_phases_equal_fused(hip_engine):
+    e = hip_engine
+    rs = np.random.RandomState(1)
+    Vv, Hh = 130, 70
+    ldh, ldv = 72, 132
+    def fresh():
+        r = np.random.RandomState(2)
+        W = e.to_device(r.normal(0, 0.1, (Vv, Hh)).astype(np.float32))
+        Ws = e.to_device(r.normal(0, 0.01, (Vv, Hh)).astype(np.float32))
+        vecs = [e.to_device(r.normal(size=n).astype(np.float32)) for n in (Hh, Hh, Vv, Vv)]
+        return W, Ws, vecs
+    stats = torch.from_numpy(rs.normal(size=Vv * ldh + ldh + ldv + 4).astype(np.float32)).to(e.device)
+    stats.view(-1)[:Vv * ldh].view(Vv, ldh)[:, Hh:] = 0
+    W, Ws, (hb, hbs, vb, vbs) = fresh()
+    c0 = e.apply_update(W, Ws, None, hb, hbs, vb, vbs, stats, 0.05, 0.0, 0.1, 0.0, 0.6, 20.0, 17.0, 0.5, phase=0)
+    W2, Ws2, (hb2, hbs2, vb2, vbs2) = fresh()
+    e.apply_update(W2, Ws2, None, hb2, hbs2, vb2, vbs2, stats, 0.05, 0.0, 0.1, 0.0, 0.6, 20.0, 17.0, 0.5, phase=2)
+    c1 = e.apply_update(W2, Ws2, None, hb2, hbs2, vb2, vbs2, stats, 0.05, 0.0, 0.1, 0.0, 0.6, 20.0, 17.0, 0.5, phase=1)
+    for a, b in ((W, W2), (Ws, Ws2), (hb, hb2), (hbs, hbs2), (vb, vb2), (vbs, vbs2)):
+        assert torch.equal(a, b)
+    assert float(c0) == float(c1)
+    with pytest.raises(Exception):       # lambda_1 != 0 cannot be split
+        e.apply_update(W, Ws, None, hb, hbs, vb, vbs, stats, 0.05, 0.01, 0.1, 0.0, 0.6, 20.0, 17.0, 0.5, phase=1)
