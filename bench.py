@@ -30,6 +30,18 @@ LR, LAMBDA_1, LAMBDA_2 = 0.001, 0.0, 0.1          # lr 0.005 (MDBN.py:49) diverg
 MFMA_F32_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md: f32-input MFMA, dense
 
 
+def gemm_traffic_bytes():
+    """HBM bytes per GEMM launch from the committed PMC profile (FETCH_SIZE / WRITE_SIZE collected
+    in separate rocprofv3 passes and corrected as MI355X_MICROARCH.md prescribes); counters cannot
+    be read from inside this process, so the figure is the profiled one, or null if absent."""
+    path = os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["gemm_avg_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(budget_s=20.0):
     """NumPy float32 restatement of the same step (oracle/rbm_np.py), all host cores via BLAS."""
     from oracle import rbm_np
@@ -168,7 +180,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "gemm_splitk_kernel (v_mfma_f32_32x32x2_f32)",
                      "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": (achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None,
-                     "traffic": None,
+                     "traffic": gemm_traffic_bytes(),
                      "launches_timed": n_launch, "launches_per_step": launches_per_step, "avg_launch_us": 1e6 * avg_gemm_s,
                      "algorithmic_flop_per_launch": flop_per_gemm},
     }
