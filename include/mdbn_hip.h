@@ -11,6 +11,7 @@
  *  - every function returns 0 (MDBN_OK) or a negative MDBN_E* code; text via mdbn_last_error
  *  - device buffers are owned by the caller (torch tensors): raw pointers, float32, row-major,
  *    leading dimensions `ld*` counted in floats, ld % 4 == 0 and 16-byte aligned bases
+ *    (mdbn_padded_ld gives the recommended ld)
  *  - `stream` is a hipStream_t passed as void*; calls enqueue work and never synchronise
  *  - W is [V, ldh] (n_visible rows, n_hidden columns), as src/rbm.py:104
  *  - random matrices are addressed by (seed, stream_id, step, draw, row_offset): see
@@ -110,8 +111,11 @@ int  mdbn_kernel_timing_read(mdbn_ctx *ctx, int64_t *n_launches, double *total_m
 
 /* bytes of split-K / reduction scratch the calls below need for shapes up to (B, V, H) */
 int  mdbn_workspace_bytes(int64_t B, int64_t V, int64_t H, int64_t *bytes);
-/* floats in the packed statistics buffer */
-int  mdbn_stats_floats(int64_t V, int64_t H, int64_t *n);
+/* leading dimension this library recommends for a [., cols] matrix (currently round_up(cols, 4);
+ * see the measurement note in csrc/mdbn_capi.hip).  Any ld % 4 == 0, ld >= cols is accepted. */
+int  mdbn_padded_ld(int64_t cols, int64_t *ld);
+/* floats in the packed statistics buffer [S (V*ldh) | s_h (ldh) | s_v (ldv) | 4] */
+int  mdbn_stats_floats(int64_t V, int64_t ldv, int64_t ldh, int64_t *n);
 
 /* minibatch gather: train_set_x[indexes]  (src/dbn.py:307, src/rbm.py:538) */
 int  mdbn_gather_rows(mdbn_ctx *ctx, void *stream, const float *src, int64_t n_rows,

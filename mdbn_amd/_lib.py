@@ -54,7 +54,8 @@ SIGNATURES = {
     "mdbn_kernel_timing": [_vp, _i32],
     "mdbn_kernel_timing_read": [_vp, C.POINTER(_i64), C.POINTER(C.c_double)],
     "mdbn_workspace_bytes": [_i64, _i64, _i64, C.POINTER(_i64)],
-    "mdbn_stats_floats": [_i64, _i64, C.POINTER(_i64)],
+    "mdbn_padded_ld": [_i64, C.POINTER(_i64)],
+    "mdbn_stats_floats": [_i64, _i64, _i64, C.POINTER(_i64)],
     "mdbn_gather_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _i64, _vp, _i64],
     "mdbn_propup_sample": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp,
                            _vp, _vp, _f32, _vp, _rngp, _vp, _i64],

@@ -59,6 +59,12 @@ constexpr int kTargetJobs = 256;       // one 8-wave tile job per CU (MI355X: 25
 constexpr int kMinSplitK = 128;        // >= 4 slices of BK = 32 per split
 
 inline int64_t ru4(int64_t x) { return (x + 3) & ~int64_t(3); }
+// Leading-dimension policy (mdbn_padded_ld).  Padding 1-KiB-multiple rows by 64 floats (to spread
+// a GEMM slice's rows over the L2 channels) gained ~10% in the isolated GEMM microbenchmark
+// (scripts/gemm_ldpad.py) but LOST 2% on the whole CD step (K1 42.3 vs 40.6 us, update 17.0 vs
+// 13.5 us, profiles r01e vs r01d), so the policy is plain round_up(cols, 4); every entry point
+// accepts any ld % 4 == 0, ld >= cols.
+inline int64_t padded_ld(int64_t cols) { return ru4(cols); }
 inline int64_t ru64(int64_t x) { return (x + 63) & ~int64_t(63); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -147,7 +153,7 @@ struct WsSizes {
 
 WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
 {
-    const int64_t ldv = ru4(V), ldh = ru4(H);
+    const int64_t ldv = padded_ld(V), ldh = padded_ld(H);      // the largest ld the policy hands out
     WsSizes s;
     const Plan up = plan_gemm(B, H, V), down = plan_gemm(B, V, H), st = plan_gemm(V, H, 2 * B);
     s.slab = std::max(up.slab_floats(B, ldh), down.slab_floats(B, ldv));
@@ -339,10 +345,17 @@ int mdbn_workspace_bytes(int64_t B, int64_t V, int64_t H, int64_t* bytes)
     return MDBN_OK;
 }
 
-int mdbn_stats_floats(int64_t V, int64_t H, int64_t* n)
+int mdbn_padded_ld(int64_t cols, int64_t* ld)
 {
-    REQUIRE(n != nullptr && V > 0 && H > 0, "bad arguments");
-    *n = V * ru4(H) + ru4(H) + ru4(V) + 4;
+    REQUIRE(ld != nullptr && cols > 0, "bad arguments");
+    *ld = padded_ld(cols);
+    return MDBN_OK;
+}
+
+int mdbn_stats_floats(int64_t V, int64_t ldv, int64_t ldh, int64_t* n)
+{
+    REQUIRE(n != nullptr && V > 0 && ldv >= V && ldh > 0 && ldv % 4 == 0 && ldh % 4 == 0, "bad arguments");
+    *n = V * ldh + ldh + ldv + 4;
     return MDBN_OK;
 }
 
@@ -458,7 +471,8 @@ int mdbn_cd_stats(mdbn_ctx* ctx, void* stream, const float* V2, const float* P2,
 int mdbn_apply_update(mdbn_ctx* ctx, void* stream, const mdbn_update_args* a)
 {
     REQUIRE(ctx != nullptr && a != nullptr, "NULL argument");
-    REQUIRE(a->V > 0 && a->H > 0 && a->ldh == ru4(a->H) && a->ldv == ru4(a->V), "bad shape / leading dims");
+    REQUIRE(a->V > 0 && a->H > 0 && a->ldh >= a->H && a->ldv >= a->V && a->ldh % 4 == 0 && a->ldv % 4 == 0,
+            "bad shape / leading dims");
     CHECK(check_mat(a->W, a->ldh, a->H, "W"));
     CHECK(check_mat(a->W_speed, a->ldh, a->H, "W_speed"));
     REQUIRE(a->W0 == nullptr || aligned16(a->W0), "W0 not aligned");
@@ -477,7 +491,7 @@ int mdbn_cd_step(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a)
     REQUIRE(ctx != nullptr && a != nullptr, "NULL argument");
     const int64_t B = a->B, V = a->V, H = a->H, ldv = a->ldv, ldh = a->ldh;
     REQUIRE(B > 0 && V > 0 && H > 0 && a->k >= 1, "bad shape / k");
-    REQUIRE(ldv == ru4(V) && ldh == ru4(H), "leading dims must be round_up(V,4), round_up(H,4)");
+    REQUIRE(ldv >= V && ldh >= H && ldv % 4 == 0 && ldh % 4 == 0, "leading dims must be multiples of 4, >= V / H");
     CHECK(check_mat(a->data, ldv, V, "data"));
     CHECK(check_mat(a->W, ldh, H, "W"));
     CHECK(check_mat(a->V2, ldv, V, "V2"));

@@ -7,7 +7,7 @@ H2D/D2H copies, streams).  There is no CPU fallback: constructing the engine wit
 the built library or without a gfx950 GPU raises.
 
 Matrix convention: a device matrix is a torch view [rows, cols] over storage
-[rows, ld] with ld = round_up(cols, 4) and zero padding (``alloc_matrix``).
+[rows, ld] with ld = padded_ld(cols) (a multiple of 4) and zero padding (``alloc_matrix``).
 """
 import ctypes as C
 
@@ -19,6 +19,12 @@ from . import _lib
 
 def round_up4(n):
     return (int(n) + 3) & ~3
+
+
+def padded_ld(cols):
+    """Leading dimension of a device matrix (same policy as mdbn_padded_ld in the library):
+    round_up(cols, 4).  (Padding power-of-two rows was measured and rejected, see mdbn_capi.hip.)"""
+    return round_up4(cols)
 
 
 _default_engine = None
@@ -55,12 +61,12 @@ class RngAddr(object):
 class CDScratch(object):
     """Per-(B, V, H) buffers of one CD step; see mdbn_cd_args in include/mdbn_hip.h."""
 
-    def __init__(self, engine, B, V, H, need_vs):
+    def __init__(self, engine, B, V, H, need_vs, ldv, ldh):
         self.B, self.V, self.H = B, V, H
-        self.V2 = engine.alloc_matrix(2 * B, V)
-        self.P2 = engine.alloc_matrix(2 * B, H)
-        self.hs = engine.alloc_matrix(B, H)
-        self.vs = engine.alloc_matrix(B, V) if need_vs else None
+        self.V2 = engine.alloc_matrix(2 * B, V, ldv)       # same ld as the data matrix
+        self.P2 = engine.alloc_matrix(2 * B, H, ldh)       # same ld as W
+        self.hs = engine.alloc_matrix(B, H, ldh)
+        self.vs = engine.alloc_matrix(B, V, ldv) if need_vs else None
 
 
 class HipEngine(object):
@@ -91,8 +97,8 @@ class HipEngine(object):
             pass
 
     # ------------------------------------------------------------------ arrays
-    def alloc_matrix(self, rows, cols):
-        ld = round_up4(cols)
+    def alloc_matrix(self, rows, cols, ld=None):
+        ld = padded_ld(cols) if ld is None else int(ld)
         return torch.zeros((rows, ld), dtype=torch.float32, device=self.device)[:, :cols]
 
     def alloc_vector(self, n):
@@ -154,20 +160,24 @@ class HipEngine(object):
             self._ws_key = (B, V, H)
         return self._workspace
 
-    def stats_buffer(self, V, H, slot=0):
-        key = (V, H, slot)
+    def stats_buffer(self, V, H, slot=0, ldv=None, ldh=None):
+        ldv = padded_ld(V) if ldv is None else ldv
+        ldh = padded_ld(H) if ldh is None else ldh
+        key = (V, H, slot, ldv, ldh)
         if key not in self._stats:
             n = C.c_int64()
-            _lib.check(self.lib.mdbn_stats_floats(V, H, C.byref(n)), "mdbn_stats_floats")
+            _lib.check(self.lib.mdbn_stats_floats(V, ldv, ldh, C.byref(n)), "mdbn_stats_floats")
             self._stats[key] = torch.zeros(n.value, dtype=torch.float32, device=self.device)
         return self._stats[key]
 
-    def cd_scratch(self, B, V, H, need_vs):
-        key = (B, V, H, bool(need_vs))
+    def cd_scratch(self, B, V, H, need_vs, ldv=None, ldh=None):
+        ldv = padded_ld(V) if ldv is None else ldv
+        ldh = padded_ld(H) if ldh is None else ldh
+        key = (B, V, H, bool(need_vs), ldv, ldh)
         if key not in self._scratch:
             if len(self._scratch) > 8:
                 self._scratch.clear()
-            self._scratch[key] = CDScratch(self, B, V, H, need_vs)
+            self._scratch[key] = CDScratch(self, B, V, H, need_vs, ldv, ldh)
         return self._scratch[key]
 
     @staticmethod
@@ -181,9 +191,10 @@ class HipEngine(object):
         B, V = v.shape
         H = W.shape[1]
         assert W.shape[0] == V, "visible size mismatch: %d vs %d" % (V, W.shape[0])
-        pre = self.alloc_matrix(B, H) if want_pre else None
-        mean = self.alloc_matrix(B, H) if want_mean else None
-        sample = self.alloc_matrix(B, H) if want_sample else None
+        ldh = W.stride(0)                               # the C-ABI writes outputs with W's ld
+        pre = self.alloc_matrix(B, H, ldh) if want_pre else None
+        mean = self.alloc_matrix(B, H, ldh) if want_mean else None
+        sample = self.alloc_matrix(B, H, ldh) if want_sample else None
         ws = self.workspace(min(B, 4096), V, H)
         r = rng.c() if rng is not None else None
         _lib.check(self.lib.mdbn_propup_sample(
@@ -199,6 +210,10 @@ class HipEngine(object):
         B, H = h.shape
         V = W.shape[0]
         assert W.shape[1] == H, "hidden size mismatch"
+        if h.stride(0) != W.stride(0):                  # the C-ABI reads h with W's ld
+            h2 = self.alloc_matrix(B, H, W.stride(0))
+            h2.copy_(h)
+            h = h2
         mean = self.alloc_matrix(B, V)
         sample = self.alloc_matrix(B, V)
         pre = mean if gauss else self.alloc_matrix(B, V)     # GRBM: "pre" is the mean (rbm.py:660)
@@ -207,6 +222,10 @@ class HipEngine(object):
         cost = None
         if v0 is not None:
             v0 = self.as_matrix(v0)
+            if v0.stride(0) != mean.stride(0):          # target is read with the output's ld
+                t = self.alloc_matrix(B, V, mean.stride(0))
+                t.copy_(v0)
+                v0 = t
             cost = torch.zeros(4, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.mdbn_propdown_sample(
             self.ctx, self._stream(), self._p(h), B, h.stride(0), self._p(W), V, H, mean.stride(0),
@@ -251,8 +270,11 @@ class HipEngine(object):
         assert data.shape[1] == V, "data has %d columns, RBM has %d visibles" % (data.shape[1], V)
         idx = self.index_tensor(indexes) if indexes is not None else None
         B = idx.numel() if idx is not None else data.shape[0]
-        sc = self.cd_scratch(B, V, H, need_vs=not gauss)
-        stats = self.stats_buffer(V, H, stats_slot)
+        ldv, ldh = data.stride(0), W.stride(0)
+        sc = self.cd_scratch(B, V, H, not gauss, ldv, ldh)
+        stats = self.stats_buffer(V, H, stats_slot, ldv, ldh)
+        if persistent is not None and persistent.stride(0) != ldh:
+            raise _lib.MdbnError("persistent chain must share W's leading dimension")
         ws = self.workspace(B, V, H)
         a = _lib.CdArgs()
         a.data, a.n_data = data.data_ptr(), data.shape[0]
@@ -272,7 +294,8 @@ class HipEngine(object):
         return stats, sc
 
     def apply_update(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats,
-                     lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale, phase=0):
+                     lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale, phase=0,
+                     ldv=None):
         """rbm.py:347-365; returns the monitoring cost as a 0-d device tensor.
         phase: 0 = whole rule, 1 = speeds (+cost) only, 2 = parameters only (mdbn_update_args)."""
         V, H = W.shape
@@ -284,7 +307,7 @@ class HipEngine(object):
         u.W0 = W0.data_ptr() if W0 is not None else None
         u.hbias, u.hbias_speed = hbias.data_ptr(), hbias_speed.data_ptr()
         u.vbias, u.vbias_speed = vbias.data_ptr(), vbias_speed.data_ptr()
-        u.V, u.H, u.ldv, u.ldh = V, H, round_up4(V), W.stride(0)
+        u.V, u.H, u.ldv, u.ldh = V, H, (padded_ld(V) if ldv is None else ldv), W.stride(0)
         u.stats = stats.data_ptr()
         u.lr, u.lambda_1, u.lambda_2 = float(lr), float(lambda_1), float(lambda_2)
         u.weightcost, u.momentum = float(weightcost), float(momentum)

@@ -123,7 +123,7 @@ class StepFunction(object):
             rbm.W.tensor, rbm.W_speed.tensor, p.W0.tensor if p.W0 is not None else None,
             rbm.hbias.tensor, rbm.hbias_speed.tensor, rbm.vbias.tensor, rbm.vbias_speed.tensor, stats,
             hp["lr"], p.lambda_1, p.lambda_2, p.weightcost, hp["momentum"], hp["batch_size"],
-            hp["n_rows"], hp["cost_scale"], phase=1)
+            hp["n_rows"], hp["cost_scale"], phase=1, ldv=hp["ldv"])
         lazy._value = cost
 
     def _resolve_cost(self, lazy):
@@ -174,7 +174,7 @@ class StepFunction(object):
                                    RngAddr(rbm.theano_rng.seed, rbm.stream_id, step, 0, lo),
                                    persistent=persistent, stats_slot=slot)
         else:                                  # this rank holds no row of a short minibatch
-            stats = eng.stats_buffer(rbm.n_visible, rbm.n_hidden, slot)
+            stats = eng.stats_buffer(rbm.n_visible, rbm.n_hidden, slot, data.stride(0), rbm.W.tensor.stride(0))
             stats.zero_()
 
         if p.persistent is not None:
@@ -192,17 +192,17 @@ class StepFunction(object):
             work = self.group.all_reduce_sum_async(stats)
             self._complete_pending()            # speeds(t) from the statistics of step t-1 ...
             eng.apply_update(*args, stats, lr, p.lambda_1, p.lambda_2, p.weightcost, momentum,
-                             batch_size, n_global, cost_scale, phase=2)   # ... then theta(t+1)
+                             batch_size, n_global, cost_scale, phase=2, ldv=data.stride(0))   # ... then theta(t+1)
             lazy = LazyCost(self, self._n_calls)
             self._pending = (work, stats, dict(lr=lr, momentum=momentum, batch_size=batch_size,
-                                               n_rows=n_global, cost_scale=cost_scale), lazy)
+                                               n_rows=n_global, cost_scale=cost_scale, ldv=data.stride(0)), lazy)
             rbm._n_updates += 1
             return lazy
 
         if distributed:
             self.group.all_reduce_sum(stats)
         out = eng.apply_update(*args, stats, lr, p.lambda_1, p.lambda_2, p.weightcost, momentum,
-                               batch_size, n_global, cost_scale)
+                               batch_size, n_global, cost_scale, ldv=data.stride(0))
         rbm._n_updates += 1
         return cost if cost is not None else out
 
@@ -358,6 +358,10 @@ class RBM(object):
             W0 = SharedArray(None, engine=self.engine, _tensor=self.W.tensor.clone())   # rbm.py:415
         if persistent is not None:
             persistent = shared(persistent, engine=self.engine)
+            if persistent.tensor.stride(0) != self.W.tensor.stride(0):
+                t = self.engine.alloc_matrix(persistent.shape[0], persistent.shape[1], self.W.tensor.stride(0))
+                t.copy_(persistent.tensor)
+                persistent.tensor = t
         updates = UpdatePlan(self, lr, k, lambda_1, lambda_2, weightcost, batch_size, persistent, W0)
         cost = CostHandle('pseudo_likelihood' if persistent is not None else 'reconstruction')
         return cost, updates

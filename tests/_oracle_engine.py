@@ -25,7 +25,7 @@ class OracleEngine(object):
         self.last = None
 
     # --- arrays
-    def alloc_matrix(self, rows, cols):
+    def alloc_matrix(self, rows, cols, ld=None):
         return torch.zeros((rows, cols), dtype=self.t_dtype)
 
     def alloc_vector(self, n):
@@ -54,7 +54,7 @@ class OracleEngine(object):
             return indexes.to(torch.int64)
         return torch.from_numpy(np.asarray(indexes).astype(np.int64))
 
-    def stats_buffer(self, V, H, slot=0):
+    def stats_buffer(self, V, H, slot=0, ldv=None, ldh=None):
         key = (V, H, slot)
         if key not in self._stats:
             self._stats[key] = torch.zeros(V * H + H + V + 4, dtype=self.t_dtype)
@@ -136,7 +136,7 @@ class OracleEngine(object):
         return stats, sc
 
     def apply_update(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats,
-                     lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale, phase=0):
+                     lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale, phase=0, ldv=None):
         V, H = W.shape
         s = rbm_np.RBMState(V, H, W=W.numpy(), hbias=hbias.numpy(), vbias=vbias.numpy(),
                             dtype=self.np_dtype)

@@ -30,9 +30,13 @@ def test_sizes_and_errors_without_gpu(built_lib):
     assert lib.mdbn_version() == 1
     n = C.c_int64()
     assert lib.mdbn_workspace_bytes(512, 4096, 1024, C.byref(n)) == 0 and n.value >= 8 * 512 * 1024 * 4
-    assert lib.mdbn_stats_floats(4096, 1024, C.byref(n)) == 0
+    assert lib.mdbn_stats_floats(4096, 4096, 1024, C.byref(n)) == 0
     assert n.value == 4096 * 1024 + 1024 + 4096 + 4
-    assert lib.mdbn_stats_floats(6, 5, C.byref(n)) == 0 and n.value == 6 * 8 + 8 + 8 + 4
+    assert lib.mdbn_stats_floats(6, 8, 8, C.byref(n)) == 0 and n.value == 6 * 8 + 8 + 8 + 4
+    for cols, want in ((6, 8), (500, 500), (784, 784), (1024, 1024), (4096, 4096), (255, 256)):
+        assert lib.mdbn_padded_ld(cols, C.byref(n)) == 0 and n.value == want, cols
+    from mdbn_amd.engine import padded_ld
+    assert all(padded_ld(c) == w for c, w in ((6, 8), (1024, 1024), (4096, 4096), (500, 500)))
     assert lib.mdbn_workspace_bytes(0, 1, 1, C.byref(n)) == -1
     assert "bad arguments" in _lib.last_error()
 

@@ -38,9 +38,9 @@ def _run_device(engine, case):
     for t in range(mg.N_STEPS):
         out["cost_%d" % t] = float(fn(indexes=idx[t], momentum=momentum))
         if t == 0:
-            sc = engine.cd_scratch(B, V, H, need_vs=not gauss)
-            st = engine.stats_buffer(V, H).cpu().numpy()
-            ldh = (H + 3) // 4 * 4
+            ldv, ldh = fn._data().stride(0), rbm.W.tensor.stride(0)
+            sc = engine.cd_scratch(B, V, H, not gauss, ldv, ldh)
+            st = engine.stats_buffer(V, H, 0, ldv, ldh).cpu().numpy()
             out["ph_mean"] = mg.sub(sc.P2[:B].cpu().numpy())
             out["nh_mean"] = mg.sub(-sc.P2[B:].cpu().numpy())
             out["nv_mean"] = mg.sub(sc.V2[B:].cpu().numpy())

@@ -79,8 +79,9 @@ def test_two_ranks_equal_one_process_on_device(built_lib):
 def test_split_update_phases_equal_fused(hip_engine):
     e = hip_engine
     rs = np.random.RandomState(1)
+    from mdbn_amd.engine import padded_ld
     Vv, Hh = 130, 70
-    ldh, ldv = 72, 132
+    ldh, ldv = padded_ld(Hh), padded_ld(Vv)
     def fresh():
         r = np.random.RandomState(2)
         W = e.to_device(r.normal(0, 0.1, (Vv, Hh)).astype(np.float32))

@@ -169,7 +169,8 @@ def test_cd_step_statistics(hip_engine, V, H, B, k, gauss):
                                                  (0.0, 0.0, 2e-4, 0.9, True), (0.01, 0.1, 2e-4, 0.6, False)])
 def test_apply_update(hip_engine, V, H, l1, l2, wc, mu, frozen):
     rs = np.random.RandomState(V)
-    ldh, ldv = (H + 3) // 4 * 4, (V + 3) // 4 * 4
+    from mdbn_amd.engine import padded_ld
+    ldh, ldv = padded_ld(H), padded_ld(V)
     W = rbm_np.init_W(rs, V, H, np.float32)
     W[0, 0] = 0.0                                             # exercises the epsilon in the shrink
     Ws = rs.normal(0, 0.01, (V, H)).astype(np.float32)
@@ -257,7 +258,7 @@ def test_full_size_row_linearity(hip_engine):
     s = state64(W, hb, vb, True)
     ph, _, out = rbm_np.cd_chain(s, x.astype(np.float64), PhiloxDraws(9, 0, 3, 0), 1)
     S_o, _, _ = rbm_np.cd_statistics(x.astype(np.float64), ph, out[1], out[4])
-    S = full[:V * H].reshape(V, H).cpu().numpy()
+    S = full[:V * dW.stride(0)].reshape(V, dW.stride(0))[:, :H].cpu().numpy()
     hs = hs_full.cpu().numpy()
     if np.array_equal(hs, (PhiloxDraws(9, 0, 3, 0).u(0, B, H) < ph).astype(np.float32)):
         assert np.abs(S - S_o).max() <= 1e-5 * np.abs(S_o).max()
