@@ -103,6 +103,9 @@ int  mdbn_last_error(char *buf, size_t n);
 int  mdbn_ctx_create(mdbn_ctx **out, int device);
 int  mdbn_ctx_destroy(mdbn_ctx *ctx);
 
+/* Tuning knobs (process-wide).  "gemm_bk": GEMM slice depth, 0 = auto, 32 or 64. */
+int  mdbn_set_option(mdbn_ctx *ctx, const char *name, int64_t value);
+
 /* Measurement hook (bench.py): while enabled, every GEMM launch (the dominant kernel) is
  * bracketed by HIP events on its stream; _read synchronises on them and returns the number
  * of launches recorded since enabling and the sum of their durations. */

@@ -51,6 +51,7 @@ SIGNATURES = {
     "mdbn_last_error": [C.c_char_p, C.c_size_t],
     "mdbn_ctx_create": [C.POINTER(_vp), _i32],
     "mdbn_ctx_destroy": [_vp],
+    "mdbn_set_option": [_vp, C.c_char_p, _i64],
     "mdbn_kernel_timing": [_vp, _i32],
     "mdbn_kernel_timing_read": [_vp, C.POINTER(_i64), C.POINTER(C.c_double)],
     "mdbn_workspace_bytes": [_i64, _i64, _i64, C.POINTER(_i64)],

@@ -55,6 +55,7 @@ int fail(int code, const char* fmt, ...)
         if (!(cond)) return fail(MDBN_EINVAL, __VA_ARGS__); \
     } while (0)
 
+static int g_opt_gemm_bk = 0;          // mdbn_set_option("gemm_bk"): 0 = auto, 32, 64
 constexpr int kTargetJobs = 256;       // one 8-wave tile job per CU (MI355X: 256 CUs)
 constexpr int kMinSplitK = 128;        // >= 4 slices of BK = 32 per split
 
@@ -69,11 +70,11 @@ inline int64_t ru64(int64_t x) { return (x + 63) & ~int64_t(63); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 struct Plan {
-    int tiles_m, tiles_n, splitk, kchunk, bn;
+    int tiles_m, tiles_n, splitk, kchunk, bn, bk;
     int64_t slab_floats(int64_t M, int64_t ldc) const { return (int64_t)splitk * M * ldc; }
     void fill(GemmArgs& g) const
     {
-        g.kchunk = kchunk; g.splitk = splitk; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.bn = bn;
+        g.kchunk = kchunk; g.splitk = splitk; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.bn = bn; g.bk = bk;
         g.inner_m = tiles_m <= tiles_n;
     }
 };
@@ -93,8 +94,11 @@ Plan plan_gemm(int64_t M, int64_t N, int64_t K)
     int64_t want = std::max<int64_t>(1, kTargetJobs / std::max<int64_t>(tiles, 1));
     int64_t maxsplit = std::max<int64_t>(1, K / kMinSplitK);
     int64_t sk = std::min(want, maxsplit);
-    int64_t kchunk = ((K + sk - 1) / sk + 31) / 32 * 32;
-    if (kchunk < 32) kchunk = 32;
+    // slice depth: 64 halves the per-slice barrier / pipe-refill overhead; it needs the 128x128
+    // tile (LDS) and at least two slices per job
+    p.bk = (p.bn == 128 && g_opt_gemm_bk != 32 && (K + sk - 1) / sk >= 128) ? 64 : 32;
+    int64_t kchunk = ((K + sk - 1) / sk + p.bk - 1) / p.bk * p.bk;
+    if (kchunk < p.bk) kchunk = p.bk;
     sk = std::max<int64_t>(1, (K + kchunk - 1) / kchunk);
     p.splitk = (int)sk;
     p.kchunk = (int)kchunk;
@@ -314,6 +318,17 @@ int mdbn_ctx_destroy(mdbn_ctx* ctx)
 #ifdef MDBN_STAMP
 int mdbn_debug_set_stamps(void* p) { g_stamps = (unsigned long long*)p; return MDBN_OK; }
 #endif
+
+int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
+{
+    REQUIRE(ctx != nullptr && name != nullptr, "NULL argument");
+    if (strcmp(name, "gemm_bk") == 0) {
+        REQUIRE(value == 0 || value == 32 || value == 64, "gemm_bk must be 0 (auto), 32 or 64");
+        g_opt_gemm_bk = (int)value;
+        return MDBN_OK;
+    }
+    return fail(MDBN_EINVAL, "unknown option %s", name);
+}
 
 int mdbn_kernel_timing(mdbn_ctx* ctx, int enable)
 {

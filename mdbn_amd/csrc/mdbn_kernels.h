@@ -20,6 +20,7 @@ struct GemmArgs {
     int kchunk;            // reduction extent per split, multiple of 32
     int splitk, tiles_m, tiles_n;
     int bn;                // block tile is 128 x bn (128 or 64)
+    int bk;                // slice depth along the reduction index (32 or 64; 64 only with bn = 128)
     int inner_m;           // work-list order inside one split: 1 = tile_m fastest
     unsigned long long* stamps;   // diagnostic builds only (-DMDBN_STAMP); NULL otherwise
 };

@@ -19,34 +19,35 @@ namespace mdbn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
-constexpr int NTHREADS = 256;
-constexpr int LDK = BK + 1;               // row stride of a K-contiguous LDS tile [rows][33]
+constexpr int NTHREADS = 256;            // threads of one role (4 producer waves / 4 consumer waves)
+// KB = slice depth along the reduction index (32 or 64); a K-contiguous LDS tile is [rows][KB + 1]
+// (odd row stride: transposing 4-byte stores, conflict-free ds_read_b32 fragment reads)
 
 // ----------------------------------------------------------------------------------
 // operand staging: global -> registers -> LDS, done by the 256 threads of the producer
 // waves.  ROWS = extent of the tile along the operand's output index (128 or 64); the
-// reduction extent is always BK = 32.  GUARD = false is the interior fast path (every
+// reduction extent is the slice depth KB.  GUARD = false is the interior fast path (every
 // float4 inside the operand: straight-line loads).
 // ----------------------------------------------------------------------------------
-template <int LAY, int ROWS, bool GUARD>
+template <int LAY, int ROWS, int KB, bool GUARD>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t ld, int MN, int K,
-                                          int mn0, int k0, float4 (&r)[ROWS / 32])
+                                          int mn0, int k0, float4 (&r)[ROWS * KB / 1024])
 {
     const int tid = threadIdx.x & (NTHREADS - 1);
     if constexpr (LAY == LAY_K) {
-        // P[mn][k], k contiguous: 8 threads cover one 32-float row slice, 32 rows per pass
-        const int c = tid & 7, rr = tid >> 3;
+        // P[mn][k], k contiguous: KB/4 threads cover one KB-float row slice
+        constexpr int TPRK = KB / 4, RPPK = NTHREADS / TPRK;
+        const int c = tid % TPRK, rr = tid / TPRK;
         const int kq = k0 + 4 * c;
         const float* src = P + (int64_t)(mn0 + rr) * ld + kq;
 #pragma unroll
-        for (int p = 0; p < ROWS / 32; ++p) {
-            const float* sp = src + (int64_t)(32 * p) * ld;
+        for (int p = 0; p < ROWS * KB / 1024; ++p) {
+            const float* sp = src + (int64_t)(RPPK * p) * ld;
             if constexpr (!GUARD) {
                 r[p] = *reinterpret_cast<const float4*>(sp);
             } else {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (mn0 + rr + 32 * p < MN) {
+                if (mn0 + rr + RPPK * p < MN) {
                     if (kq + 3 < K) {
                         v = *reinterpret_cast<const float4*>(sp);
                     } else {
@@ -65,7 +66,7 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t l
         const int mq = mn0 + 4 * c;
         const float* src = P + (int64_t)(k0 + rr) * ld + mq;
 #pragma unroll
-        for (int p = 0; p < ROWS / 32; ++p) {
+        for (int p = 0; p < ROWS * KB / 1024; ++p) {
             const float* sp = src + (int64_t)(RPP * p) * ld;
             if constexpr (!GUARD) {
                 r[p] = *reinterpret_cast<const float4*>(sp);
@@ -86,22 +87,23 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t l
     }
 }
 
-template <int LAY, int ROWS>
-__device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&r)[ROWS / 32])
+template <int LAY, int ROWS, int KB>
+__device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&r)[ROWS * KB / 1024])
 {
     const int tid = threadIdx.x & (NTHREADS - 1);
     if constexpr (LAY == LAY_K) {
-        const int c = tid & 7, rr = tid >> 3;
+        constexpr int TPRK = KB / 4, RPPK = NTHREADS / TPRK;
+        const int c = tid % TPRK, rr = tid / TPRK;
 #pragma unroll
-        for (int p = 0; p < ROWS / 32; ++p) {
-            float* d = T + (rr + 32 * p) * LDK + 4 * c;     // odd stride: reads conflict-free
+        for (int p = 0; p < ROWS * KB / 1024; ++p) {
+            float* d = T + (rr + RPPK * p) * (KB + 1) + 4 * c;     // odd stride: reads conflict-free
             d[0] = r[p].x; d[1] = r[p].y; d[2] = r[p].z; d[3] = r[p].w;
         }
     } else {
         constexpr int TPR = ROWS / 4, RPP = NTHREADS / TPR;
         const int c = tid % TPR, rr = tid / TPR;
 #pragma unroll
-        for (int p = 0; p < ROWS / 32; ++p)
+        for (int p = 0; p < ROWS * KB / 1024; ++p)
         {
             const float4 v = make_float4(r[p].x, r[p].y, r[p].z, r[p].w);
             *reinterpret_cast<float4*>(T + (rr + RPP * p) * ROWS + 4 * c) = v;
@@ -110,10 +112,10 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (
 }
 
 // MFMA operand of lane (i = lane & 31, h = lane >> 5): element [mn = base + i][k = kk + h]
-template <int LAY, int ROWS>
+template <int LAY, int ROWS, int KB>
 __device__ __forceinline__ float frag(const float* __restrict__ T, int mn, int k)
 {
-    return LAY == LAY_K ? T[mn * LDK + k] : T[k * ROWS + mn];
+    return LAY == LAY_K ? T[mn * (KB + 1) + k] : T[k * ROWS + mn];
 }
 
 #ifdef MDBN_STAMP
@@ -137,7 +139,7 @@ __device__ __forceinline__ float frag(const float* __restrict__ T, int mn, int k
 //   waves 0-3 (one per SIMD) CONSUME: fragment reads from LDS + v_mfma_f32_32x32x2_f32 only,
 //             2x2 wave grid, MI x NI accumulators of 32x32 each; fragment reads run one
 //             k-group ahead of the MFMAs so the matrix pipe never waits on LDS;
-//   waves 4-7 PRODUCE: global -> registers -> LDS staging of the next BK = 32 slice (its loads
+//   waves 4-7 PRODUCE: global -> registers -> LDS staging of the next KB-deep slice (its loads
 //             issued a whole slice earlier), sharing each SIMD with one consumer wave whose
 //             MFMA issue they barely disturb.
 // Double-buffered LDS, one barrier per slice.  (Measured with s_memtime stamps: when every
@@ -158,20 +160,20 @@ constexpr int GEMM_THREADS = 512;
 #define ABLATE_LOAD 0
 #endif
 
-template <int LA, int LB, int MI, int NI, bool GUARD>
+template <int LA, int LB, int MI, int NI, int KB, bool GUARD>
 __device__ __forceinline__ void gemm_produce(const GemmArgs& g, float* __restrict__ smem, int m0, int n0,
                                              int kbeg, int kend, int nt)
 {
     constexpr int BM = 64 * MI, BN = 64 * NI;
-    constexpr int A_FLOATS = BM * LDK, B_FLOATS = BN * LDK, BUF = A_FLOATS + B_FLOATS;
+    constexpr int A_FLOATS = BM * (KB + 1), B_FLOATS = BN * (KB + 1), BUF = A_FLOATS + B_FLOATS;
     // Two register sets: in slice `it` the set (it & 1) holds slice it+1 (loaded two slices
     // ago), is written to LDS buffer (it+1) & 1, and is then re-loaded with slice it+3 --
     // every load has more than a full slice (~2 us) to land before it is needed.
-    float4 ra0[BM / 32], rb0[BN / 32], ra1[BM / 32], rb1[BN / 32];
+    float4 ra0[BM * KB / 1024], rb0[BN * KB / 1024], ra1[BM * KB / 1024], rb1[BN * KB / 1024];
 #define PRODUCER_LOAD(RA, RB, SLICE)                                                          \
     do {                                                                                      \
-        load_tile<LA, BM, GUARD>(g.A, g.lda, g.M, kend, m0, kbeg + (SLICE) * BK, RA);         \
-        load_tile<LB, BN, GUARD>(g.B, g.ldb, g.N, kend, n0, kbeg + (SLICE) * BK, RB);         \
+        load_tile<LA, BM, KB, GUARD>(g.A, g.lda, g.M, kend, m0, kbeg + (SLICE) * KB, RA);         \
+        load_tile<LB, BN, KB, GUARD>(g.B, g.ldb, g.N, kend, n0, kbeg + (SLICE) * KB, RB);         \
     } while (0)
 #define PRODUCER_STEP(RA, RB)                                                                 \
     do {                                                                                      \
@@ -179,8 +181,8 @@ __device__ __forceinline__ void gemm_produce(const GemmArgs& g, float* __restric
         __builtin_amdgcn_s_sleep(PRODUCER_SLEEP);                                             \
         if (it + 1 < nt && !ABLATE_STORE) {                                                   \
             float* nx = smem + ((it + 1) & 1) * BUF;   /* all reads of it ended at the last barrier */ \
-            store_tile<LA, BM>(nx, RA);                                                       \
-            store_tile<LB, BN>(nx + A_FLOATS, RB);                                            \
+            store_tile<LA, BM, KB>(nx, RA);                                                       \
+            store_tile<LB, BN, KB>(nx + A_FLOATS, RB);                                            \
         }                                                                                     \
         STAMP(1);                                                                             \
         if (it + 3 < nt && !ABLATE_LOAD) PRODUCER_LOAD(RA, RB, it + 3);                       \
@@ -190,8 +192,8 @@ __device__ __forceinline__ void gemm_produce(const GemmArgs& g, float* __restric
     } while (0)
 
     PRODUCER_LOAD(ra0, rb0, 0);
-    store_tile<LA, BM>(smem, ra0);
-    store_tile<LB, BN>(smem + A_FLOATS, rb0);
+    store_tile<LA, BM, KB>(smem, ra0);
+    store_tile<LB, BN, KB>(smem + A_FLOATS, rb0);
     if (nt > 1) PRODUCER_LOAD(ra0, rb0, 1);         // slices 1 and 2 stay in flight across the barrier
     if (nt > 2) PRODUCER_LOAD(ra1, rb1, 2);
     __syncthreads();
@@ -204,13 +206,13 @@ __device__ __forceinline__ void gemm_produce(const GemmArgs& g, float* __restric
 #undef PRODUCER_LOAD
 }
 
-template <int LA, int LB, int MI, int NI>
+template <int LA, int LB, int MI, int NI, int KB>
 __device__ __forceinline__ void gemm_consume(const GemmArgs& g, const float* __restrict__ smem,
                                              f32x16 (&acc)[MI][NI], int nt, int wm, int wn, int i, int h)
 {
     constexpr int BM = 64 * MI, BN = 64 * NI;
-    constexpr int A_FLOATS = BM * LDK, B_FLOATS = BN * LDK, BUF = A_FLOATS + B_FLOATS;
-    constexpr int KG = 2, NG = BK / (2 * KG);       // 8 groups of 2 k-pairs per slice
+    constexpr int A_FLOATS = BM * (KB + 1), B_FLOATS = BN * (KB + 1), BUF = A_FLOATS + B_FLOATS;
+    constexpr int KG = 2, NG = KB / (2 * KG);       // groups of 2 k-pairs per slice
     __syncthreads();                                // slice 0 staged
     for (int it = 0; it < nt; ++it) {
         STAMP(0);
@@ -220,9 +222,9 @@ __device__ __forceinline__ void gemm_consume(const GemmArgs& g, const float* __r
 #pragma unroll
         for (int u = 0; u < KG; ++u) {
 #pragma unroll
-            for (int a = 0; a < MI; ++a) av[0][u][a] = frag<LA, BM>(at, wm + 32 * a + i, 2 * u + h);
+            for (int a = 0; a < MI; ++a) av[0][u][a] = frag<LA, BM, KB>(at, wm + 32 * a + i, 2 * u + h);
 #pragma unroll
-            for (int b = 0; b < NI; ++b) bv[0][u][b] = frag<LB, BN>(bt, wn + 32 * b + i, 2 * u + h);
+            for (int b = 0; b < NI; ++b) bv[0][u][b] = frag<LB, BN, KB>(bt, wn + 32 * b + i, 2 * u + h);
         }
 #pragma unroll
         for (int grp = 0; grp < NG; ++grp) {
@@ -232,9 +234,9 @@ __device__ __forceinline__ void gemm_consume(const GemmArgs& g, const float* __r
                 for (int u = 0; u < KG; ++u) {
                     const int kk = 2 * KG * (grp + 1) + 2 * u;
 #pragma unroll
-                    for (int a = 0; a < MI; ++a) av[ns][u][a] = frag<LA, BM>(at, wm + 32 * a + i, kk + h);
+                    for (int a = 0; a < MI; ++a) av[ns][u][a] = frag<LA, BM, KB>(at, wm + 32 * a + i, kk + h);
 #pragma unroll
-                    for (int b = 0; b < NI; ++b) bv[ns][u][b] = frag<LB, BN>(bt, wn + 32 * b + i, kk + h);
+                    for (int b = 0; b < NI; ++b) bv[ns][u][b] = frag<LB, BN, KB>(bt, wn + 32 * b + i, kk + h);
                 }
             }
 #pragma unroll
@@ -254,7 +256,7 @@ __device__ __forceinline__ void gemm_consume(const GemmArgs& g, const float* __r
     }
 }
 
-template <int LA, int LB, int MI, int NI>
+template <int LA, int LB, int MI, int NI, int KB>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
 {
     constexpr int BM = 64 * MI, BN = 64 * NI;
@@ -275,15 +277,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = ks * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
-    const int nt = (kend - kbeg + BK - 1) / BK;     // >= 1: the host never plans an empty split
+    const int nt = (kend - kbeg + KB - 1) / KB;     // >= 1: the host never plans an empty split
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= 4) {
         // the few staging instructions must not queue behind the partner wave's MFMA stream
         __builtin_amdgcn_s_setprio(PRODUCER_PRIO);
-        const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (kbeg + nt * BK <= g.K);
-        if (interior) gemm_produce<LA, LB, MI, NI, false>(g, smem, m0, n0, kbeg, kend, nt);
-        else gemm_produce<LA, LB, MI, NI, true>(g, smem, m0, n0, kbeg, kend, nt);
+        const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (kbeg + nt * KB <= g.K);
+        if (interior) gemm_produce<LA, LB, MI, NI, KB, false>(g, smem, m0, n0, kbeg, kend, nt);
+        else gemm_produce<LA, LB, MI, NI, KB, true>(g, smem, m0, n0, kbeg, kend, nt);
         return;
     }
 
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    gemm_consume<LA, LB, MI, NI>(g, smem, acc, nt, wm, wn, i, h);
+    gemm_consume<LA, LB, MI, NI, KB>(g, smem, acc, nt, wm, wn, i, h);
 
     // accumulator (32x32): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     float* C = g.C + (int64_t)ks * g.slab_stride;
@@ -315,15 +317,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
         }
 }
 
-template <int LA, int LB, int MI, int NI>
+template <int LA, int LB, int MI, int NI, int KB>
 static hipError_t launch_gemm_t(const GemmArgs& g, hipStream_t s)
 {
     // The LDS request is padded past half of the CU's 160 KiB so that exactly one 8-wave
     // block lives on a CU: the jobs then spread evenly over the 256 CUs.
-    constexpr int need_bytes = 2 * (64 * MI + 64 * NI) * LDK * (int)sizeof(float);
+    constexpr int need_bytes = 2 * (64 * MI + 64 * NI) * (KB + 1) * (int)sizeof(float);
     constexpr int lds_bytes = need_bytes > 84 * 1024 ? need_bytes : 84 * 1024;
     static bool attr_set = false;
-    auto kern = gemm_splitk_kernel<LA, LB, MI, NI>;
+    auto kern = gemm_splitk_kernel<LA, LB, MI, NI, KB>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -338,8 +340,9 @@ static hipError_t launch_gemm_t(const GemmArgs& g, hipStream_t s)
 template <int LA, int LB>
 static hipError_t launch_gemm_l(const GemmArgs& g, hipStream_t s)
 {
-    if (g.bn == 128) return launch_gemm_t<LA, LB, 2, 2>(g, s);
-    if (g.bn == 64) return launch_gemm_t<LA, LB, 2, 1>(g, s);
+    if (g.bn == 128 && g.bk == 64) return launch_gemm_t<LA, LB, 2, 2, 64>(g, s);
+    if (g.bn == 128 && g.bk == 32) return launch_gemm_t<LA, LB, 2, 2, 32>(g, s);
+    if (g.bn == 64 && g.bk == 32) return launch_gemm_t<LA, LB, 2, 1, 32>(g, s);
     return hipErrorInvalidValue;
 }
 
@@ -683,6 +686,7 @@ hipError_t launch_colsum_groups(const float* X, const float* Y, int rows, int64_
 //   W'  = W * (1 - 2 lr l2) / (1 + 2 lr l1 / (|W| + eps)) + W_speed(old) * lr
 //   Ws' = g + (W_speed - g) * momentum
 // ----------------------------------------------------------------------------------
+template <bool DO_SPEED, bool DO_PARAMS>
 __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, float4* __restrict__ Ws,
                                                      const float4* __restrict__ W0, const float4* __restrict__ S,
                                                      int64_t n4, float lr, float l1, float l2, float wc,
@@ -692,8 +696,9 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
                                                      float* __restrict__ vb, float* __restrict__ vbs,
                                                      const float* __restrict__ s_v, int64_t V, float inv_rows,
                                                      const float* __restrict__ cost_sum, float cost_scale,
-                                                     float* __restrict__ cost_out, int do_speed, int do_params)
+                                                     float* __restrict__ cost_out)
 {
+    constexpr bool do_speed = DO_SPEED, do_params = DO_PARAMS;
     {   // biases, one element per thread of the leading blocks (multipliers are exactly 1, rbm.py:356)
         const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         if (i < H) {
@@ -743,12 +748,16 @@ hipError_t launch_update(const mdbn_update_args& a, hipStream_t s)
     const float* s_h = a.stats + a.V * a.ldh;
     const float* s_v = s_h + a.ldh;
     const int grid = (int)std::max<int64_t>(std::min<int64_t>((n4 + 255) / 256, 4096), (a.H + a.V + 255) / 256);
-    hipLaunchKernelGGL(update_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<float4*>(a.W),
-                       reinterpret_cast<float4*>(a.W_speed), reinterpret_cast<const float4*>(a.W0),
-                       reinterpret_cast<const float4*>(S), n4, a.lr, a.lambda_1, a.lambda_2, a.weightcost,
-                       a.momentum, 1.0f / a.batch_size, a.hbias, a.hbias_speed, s_h, a.H, a.vbias,
-                       a.vbias_speed, s_v, a.V, 1.0f / a.n_rows, s_v + a.ldv, a.cost_scale, a.cost_out,
-                       a.phase != 2, a.phase != 1);
+#define LAUNCH_UPDATE(SP, PA)                                                                          \
+    hipLaunchKernelGGL((update_kernel<SP, PA>), dim3(grid), dim3(256), 0, s, reinterpret_cast<float4*>(a.W), \
+                       reinterpret_cast<float4*>(a.W_speed), reinterpret_cast<const float4*>(a.W0),    \
+                       reinterpret_cast<const float4*>(S), n4, a.lr, a.lambda_1, a.lambda_2, a.weightcost, \
+                       a.momentum, 1.0f / a.batch_size, a.hbias, a.hbias_speed, s_h, a.H, a.vbias,    \
+                       a.vbias_speed, s_v, a.V, 1.0f / a.n_rows, s_v + a.ldv, a.cost_scale, a.cost_out)
+    if (a.phase == 1) LAUNCH_UPDATE(true, false);
+    else if (a.phase == 2) LAUNCH_UPDATE(false, true);
+    else LAUNCH_UPDATE(true, true);
+#undef LAUNCH_UPDATE
     return hipGetLastError();
 }
 

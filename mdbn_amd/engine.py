@@ -326,6 +326,10 @@ class HipEngine(object):
                    "mdbn_rng_*")
         return out
 
+    def set_option(self, name, value):
+        """Library tuning knob (mdbn_set_option), e.g. ``set_option('gemm_bk', 32)``."""
+        _lib.check(self.lib.mdbn_set_option(self.ctx, name.encode(), int(value)), "mdbn_set_option")
+
     def kernel_timing(self, enable):
         """Bracket every GEMM launch with HIP events (measurement only; bench.py)."""
         _lib.check(self.lib.mdbn_kernel_timing(self.ctx, int(bool(enable))), "mdbn_kernel_timing")
