@@ -13,8 +13,8 @@ from .utils import get_minibatches_idx
 from .mlp import HiddenLayer
 from .rbm import RBM, GRBM, Scalar, function
 from .dbn import DBN
-from . import MDBN, dist
+from . import MDBN, checkpoint, dist, utils
 
 __all__ = ["MdbnError", "HipEngine", "RngAddr", "get_engine", "set_engine", "RandomStreams",
            "SharedArray", "shared", "get_minibatches_idx", "HiddenLayer", "RBM", "GRBM",
-           "Scalar", "function", "DBN", "MDBN", "dist"]
+           "Scalar", "function", "DBN", "MDBN", "dist", "checkpoint", "utils"]

@@ -5,9 +5,8 @@ Kept from the reference: constructor arguments and numpy draw order (dbn.py:110-
 155-159), shared W/b between HiddenLayer and RBM (dbn.py:168-202), ``params`` order
 [W0, b0, W1, b1, ...] with names 'W'/'b', the greedy layer-wise loop with its momentum
 schedule and patience rule (dbn.py:426-508), ``get_output`` / ``number_of_nodes``.
-Not kept: matplotlib output (``graph_output`` is accepted and ignored), Theano MonitorMode
-(``monitor`` is accepted and ignored) and the TSV loader behind
-``MLP_output_from_datafile`` (data plumbing is out of the hot path).
+Not kept: matplotlib output (``graph_output`` is accepted and ignored) and Theano MonitorMode
+(``monitor`` is accepted and ignored).
 """
 from __future__ import print_function
 
@@ -230,6 +229,10 @@ class DBN(object):
 
     def MLP_output_from_datafile(self, datafile, holdout=0.0, repeats=1, clip=None,
                                  transform_fn=None, exponent=1.0, datadir='data'):
-        raise NotImplementedError(
-            "the TSV loader of reference utils.py:34-119 is data plumbing outside the CD-k hot "
-            "path; load the table yourself and call get_output(train_set), get_output(validation_set)")
+        """Reload a table (unshuffled) and return the network's outputs for its train and
+        validation parts (dbn.py:519-536)."""
+        from .utils import load_n_preprocess_data
+        train_set, validation_set = load_n_preprocess_data(datafile, holdout=holdout, clip=clip,
+                                                           transform_fn=transform_fn, exponent=exponent,
+                                                           repeats=repeats, shuffle=False, datadir=datadir)
+        return (self.get_output(train_set), self.get_output(validation_set))

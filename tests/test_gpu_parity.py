@@ -287,3 +287,27 @@ def test_multi_step_weights_track_oracle(hip_engine):
     W, W_o = rbm.W.get_value(), st.W
     assert forks <= 1
     assert np.abs(W - W_o).max() <= 1e-4 * np.abs(W_o).max()
+
+
+def test_checkpoint_resume_is_exact_on_device(hip_engine, tmp_path):
+    """Save with the resume extension mid-training, reload, continue: identical to not stopping."""
+    import mdbn_amd
+    from mdbn_amd import checkpoint
+    mdbn_amd.DBN.verbose = False
+    rs = np.random.RandomState(0)
+    x = rs.normal(size=(64, 40)).astype(np.float32)
+    a = mdbn_amd.DBN(numpy_rng=np.random.RandomState(1), n_ins=40, hidden_layers_sizes=[24], n_outs=8, engine=hip_engine)
+    def steps(d, n, first):
+        r = d.rbm_layers[0]
+        _, up = r.get_cost_updates(0.005, k=1, lambda_2=0.1, batch_size=16)
+        fn = mdbn_amd.function(up, mdbn_amd.shared(x, engine=hip_engine), data_parallel=None)
+        return [float(fn(indexes=np.arange(16) + 16 * ((first + t) % 4), momentum=0.0)) for t in range(n)]
+    steps(a, 3, 0)
+    path = str(tmp_path / "ck.npz")
+    checkpoint.save_network(path, {'ge': a}, resume=True)
+    b = checkpoint.load_network(path, engine=hip_engine)['ge']
+    ca, cb = steps(a, 3, 3), steps(b, 3, 3)
+    assert ca == cb
+    for pa, pb in zip(a.params, b.params):
+        assert np.array_equal(pa.get_value(), pb.get_value())
+    assert np.array_equal(a.rbm_layers[0].W_speed.get_value(), b.rbm_layers[0].W_speed.get_value())

@@ -1,0 +1,115 @@
+"""Rows f2-f4 of SURVEY 8f on the CPU checker engine: TSV loading / preprocessing, the npz
+checkpoint schema (+ resume extension), class post-processing."""
+import os
+
+import numpy as np
+import pytest
+
+import mdbn_amd
+from mdbn_amd import DBN, checkpoint, utils
+
+
+def write_table(path, data):
+    n_feat, n_person = data.shape
+    with open(path, "w") as f:
+        f.write("gene\t" + "\t".join("p%d" % i for i in range(n_person)) + "\n")
+        for i, row in enumerate(data):
+            f.write("g%d\t" % i + "\t".join("%.6f" % v for v in row) + "\n")
+
+
+def test_tsv_loader_and_preprocessing(tmp_path, oracle_engine):
+    rs = np.random.RandomState(0)
+    raw = rs.normal(5, 2, size=(7, 12))
+    raw[3] = 1.0                                   # zero variance -> NaN z-scores -> dropped (utils.py:97)
+    write_table(str(tmp_path / "t.tsv"), raw)
+    n_data, n_cols, data = utils.import_TCGA_data("t.tsv", str(tmp_path), "float64")
+    assert (n_data, n_cols) == (12, 12) and data.shape == (7, 12)
+    np.testing.assert_allclose(data, raw, atol=1e-6)
+    train, val = utils.preprocess_table(data, holdout=0.25, repeats=1, shuffle=False)
+    assert train.shape == (9, 6) and val.shape == (3, 6)      # one row per person, NaN feature gone
+    keep = [0, 1, 2, 4, 5, 6]
+    z = (raw[keep] - raw[keep].mean(1, keepdims=True)) / raw[keep].std(1, keepdims=True)
+    np.testing.assert_allclose(np.concatenate([train, val]), z.T, atol=1e-5)
+    # clip + the reference's repeats quirk: only the first n_persons replicated rows are used
+    train, val = utils.preprocess_table(data, holdout=0.0, repeats=3, clip=(-1, 1), shuffle=False)
+    assert val is None and train.shape == (12, 6) and np.abs(train).max() <= 1.0
+    np.testing.assert_allclose(train[:3], np.repeat(np.clip(z.T[:1], -1, 1), 3, axis=0), atol=1e-5)
+    # gz + device upload
+    import gzip, shutil
+    with open(str(tmp_path / "t.tsv"), "rb") as fi, gzip.open(str(tmp_path / "t.tsv.gz"), "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    tr, va = utils.load_n_preprocess_data("t.tsv.gz", holdout=0.25, repeats=1, shuffle=True, datadir=str(tmp_path),
+                                          rng=np.random.RandomState(1))
+    assert tr.shape == (9, 6) and va.shape == (3, 6)
+    both = np.concatenate([tr.get_value(), va.get_value()])
+    order = lambda a: a[np.lexsort(np.round(a, 3).T[::-1])]
+    np.testing.assert_allclose(order(both.astype(np.float64)), order(z.T), atol=1e-4)
+
+
+def test_mlp_output_from_datafile(tmp_path, oracle_engine):
+    DBN.verbose = False
+    raw = np.random.RandomState(1).normal(size=(8, 10))
+    write_table(str(tmp_path / "ge.tsv"), raw)
+    dbn = DBN(numpy_rng=np.random.RandomState(123), n_ins=8, hidden_layers_sizes=[5], n_outs=3)
+    out_t, out_v = dbn.MLP_output_from_datafile("ge.tsv", holdout=0.2, datadir=str(tmp_path))
+    assert out_t.shape == (8, 3) and out_v.shape == (2, 3)
+    train, val = utils.preprocess_table(raw, holdout=0.2, repeats=1, shuffle=False)
+    np.testing.assert_allclose(out_t, dbn.get_output(train), rtol=1e-5)
+
+
+def test_checkpoint_schema_and_resume(tmp_path, oracle_engine):
+    DBN.verbose = False
+    rs = np.random.RandomState(0)
+    ge = DBN(numpy_rng=np.random.RandomState(1), n_ins=10, hidden_layers_sizes=[6], n_outs=4)
+    top = DBN(numpy_rng=np.random.RandomState(2), n_ins=4, gauss=False, hidden_layers_sizes=[5], n_outs=3)
+    ge.shuffle_rng = np.random.RandomState(3)
+    ge.training(rs.normal(size=(40, 10)), batch_size=10, k=1, pretraining_epochs=[6, 6], pretrain_lr=[0.005, 0.1])
+    path = str(tmp_path / "parameters_and_classes.npz")
+    classes = np.arange(5.0)
+    checkpoint.save_network(path, {'ge': ge, 'top': top, 'dm': None}, classes=classes, holdout=0.1, repeats=10,
+                            configs={'ge': {'epochs': [8000, 800], 'learning_rate': [0.005, 0.1],
+                                            'batch_size': 20, 'k': 1}}, resume=True)
+    # the reference's reader (AMLsm2.py:165-205) works on the file as is
+    npz = np.load(path, allow_pickle=True)
+    cfg = npz['ge_config'].tolist()
+    params = npz['ge_params']
+    assert cfg['number_of_nodes'] == [10, 6, 4] and cfg['k'] == 1
+    assert params[0]['W'].shape == (10, 6) and params[1]['b'].shape == (6,) and params[2]['W'].shape == (6, 4)
+    assert float(npz['holdout']) == 0.1 and int(npz['repeats']) == 10
+    # round trip, including what the reference loses (vbias, speeds, RNG position)
+    nets = checkpoint.load_network(path)
+    assert set(nets) >= {'ge', 'top', 'classes'} and np.array_equal(nets['classes'], classes)
+    g2 = nets['ge']
+    assert not isinstance(nets['top'].rbm_layers[0], mdbn_amd.GRBM) and isinstance(g2.rbm_layers[0], mdbn_amd.GRBM)
+    for a, b in zip(ge.params, g2.params):
+        assert np.array_equal(a.get_value(), b.get_value()) and a.name == b.name
+    for ra, rb in zip(ge.rbm_layers, g2.rbm_layers):
+        assert np.array_equal(ra.vbias.get_value(), rb.vbias.get_value())
+        assert np.array_equal(ra.W_speed.get_value(), rb.W_speed.get_value())
+        assert (ra._rng_step, ra.stream_id, ra.theano_rng.seed) == (rb._rng_step, rb.stream_id, rb.theano_rng.seed)
+    # resumed training continues exactly where the original would have
+    x = rs.normal(size=(20, 10))
+    for d in (ge, g2):
+        _, up = d.rbm_layers[0].get_cost_updates(0.005, k=1, lambda_2=0.1, batch_size=10)
+        fn = mdbn_amd.function(up, mdbn_amd.shared(x))
+        d._c = [float(fn(indexes=np.arange(10) + 10 * t, momentum=0.0)) for t in range(2)]
+    # (the CPU checker engine computes in float64 while checkpoints hold float32: compare to 1e-6;
+    #  on the HIP engine, whose state IS float32, the continuation is exact -- tests/test_gpu_parity.py)
+    np.testing.assert_allclose(ge._c, g2._c, rtol=1e-6)
+    np.testing.assert_allclose(ge.params[0].get_value(), g2.params[0].get_value(), rtol=1e-5, atol=1e-7)
+
+
+def test_class_postprocessing():
+    out = np.array([[1, 0, 1], [0, 0, 0], [1, 0, 1], [1, 1, 1], [1, 0, 1], [0, 0, 0], [0, 1, 0]], dtype=np.float64)
+    classes, D = utils.find_unique_classes(out)
+    assert D.shape == (4, 4) and np.allclose(np.diag(D), 0) and np.allclose(D, D.T)
+    assert len(set(classes)) == 4 and classes[0] == classes[2] == classes[4] and classes[1] == classes[5]
+    pats = {int(c): tuple(out[i]) for i, c in enumerate(classes)}
+    for a in pats:
+        for b in pats:
+            assert abs(D[a, b] - np.mean(np.array(pats[a]) != np.array(pats[b]))) < 1e-12
+    merged = utils.remap_class(classes.astype(int), D, 2)
+    assert set(merged) == {0, 1}
+    assert merged[0] == merged[2] == merged[4] == 0          # most frequent class -> 0
+    assert merged[1] == merged[5] == 1
+    assert merged[3] in (0, 1) and merged[6] in (0, 1)
