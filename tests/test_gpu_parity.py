@@ -311,3 +311,98 @@ def test_checkpoint_resume_is_exact_on_device(hip_engine, tmp_path):
     for pa, pb in zip(a.params, b.params):
         assert np.array_equal(pa.get_value(), pb.get_value())
     assert np.array_equal(a.rbm_layers[0].W_speed.get_value(), b.rbm_layers[0].W_speed.get_value())
+
+
+def test_large_n_forward_is_chunked_consistently(hip_engine):
+    """get_output / sampling over more rows than the workspace holds at once: the C-ABI chunks
+    the rows; means, samples (Philox keyed by absolute row) and free energies must not notice."""
+    from mdbn_amd import RngAddr
+    V, H, N = 1024, 1024, 9000
+    W, hb, vb, x = make(V, H, N, True, seed=3)
+    e = hip_engine
+    dW, dhb, dvb, dx = dev(e, W, hb, vb, x)
+    addr = RngAddr(5, 0, 1, 0, 4)
+    _, mean, sample = e.propup(dx, dW, dhb, rng=addr, want_pre=False)
+    s = state64(W, hb, vb, True)
+    mean_o = rbm_np.propup(s, x.astype(np.float64))[1]
+    # 9.2 M probabilities from unsplit 1024-long fp32 chains: the maximum sits further out in the tail
+    assert np.abs(mean.cpu().numpy() - mean_o).max() <= 2 * ptol(V)
+    u = philox_np.uniform(N, H, 5, 0, 1, 0, 4).astype(np.float64)
+    bad = sample.cpu().numpy() != (u < mean_o)
+    assert np.all(np.abs(u - mean_o)[bad] < 1e-6) and bad.sum() <= 4
+    F = e.free_energy(dx, dW, dhb, dvb, True).cpu().numpy()
+    F_o = rbm_np.free_energy(s, x.astype(np.float64))
+    assert (np.abs(F - F_o) / np.maximum(np.abs(F_o), 1.0)).max() <= 1e-4
+
+
+def test_config4_two_layer_dbn_full_width(hip_engine):
+    """BASELINE configs[3]: DBN 4096 -> 1024 -> 256, CD-1, layer-wise, B = 512: both layers'
+    step functions (layer 1 consuming the cached sigmoid activations of layer 0) against the
+    oracle driven with the same Philox streams."""
+    import mdbn_amd
+    mdbn_amd.DBN.verbose = False
+    N, B = 1024, 512
+    x = np.random.RandomState(0).normal(size=(N, 4096)).astype(np.float32)
+    dbn = mdbn_amd.DBN(numpy_rng=np.random.RandomState(123), n_ins=4096, hidden_layers_sizes=[1024], n_outs=256,
+                       engine=hip_engine)
+    W0, W1 = dbn.params[0].get_value(), dbn.params[2].get_value()
+    fns, fe_fns = dbn.training_functions(mdbn_amd.shared(x, engine=hip_engine), batch_size=B, k=1,
+                                         lambda_1=0.0, lambda_2=0.1)
+    r0, r1 = dbn.rbm_layers
+    s0 = rbm_np.RBMState(4096, 1024, W=W0, gauss=True)
+    s1 = rbm_np.RBMState(1024, 256, W=W1); s1.freeze_W0()
+    idx = [np.arange(B), np.arange(B) + B]
+    for t in range(2):                                   # layer 0: GRBM, lr 0.001 (stable), momentum 0
+        c = float(fns[0](indexes=idx[t], momentum=0.0, lr=0.001))
+        c_o = rbm_np.cd_step(s0, x[idx[t]], PhiloxDraws(r0.theano_rng.seed, r0.stream_id, t), lr=0.001, k=1,
+                             lambda_2=0.1, batch_size=B)
+        assert abs(c - c_o) <= 1e-4 * abs(c_o)
+    assert np.abs(r0.W.get_value() - s0.W).max() <= 2e-6
+    lower = rbm_np.mlp_forward([s0.W], [s0.hbias], x.astype(np.float64), 0)
+    for t in range(2):                                   # layer 1: Bernoulli RBM on sigmoid(x W0 + b0)
+        c = float(fns[1](indexes=idx[t], momentum=0.6, lr=0.1))
+        c_o = rbm_np.cd_step(s1, lower[idx[t]], PhiloxDraws(r1.theano_rng.seed, r1.stream_id, t), lr=0.1, k=1,
+                             weightcost=0.0002, batch_size=B, momentum=0.6)
+        assert abs(c - c_o) <= 2e-4 * abs(c_o), (t, c, c_o)
+    assert np.abs(r1.W_speed.get_value() - s1.W_speed).max() <= 1e-4 * np.abs(s1.W_speed).max() + 1e-6
+    out = dbn.get_output(x[:64])
+    out_o = rbm_np.mlp_forward([s0.W, s1.W], [s0.hbias, s1.hbias], x[:64].astype(np.float64))
+    assert np.abs(out - out_o).max() <= 1e-4
+    ft, fv = fe_fns[0](x[:64], x[64:128])
+    np.testing.assert_allclose(ft, rbm_np.free_energy(s0, x[:64].astype(np.float64)), rtol=1e-4, atol=1e-2)
+
+
+def test_config5_three_modality_mdbn(hip_engine):
+    """BASELINE configs[4] at reduced row count: GE 2048 -> 400 -> 40, miRNA 512 -> 40 (CD-5),
+    SM 256 -> 200 -> 20, concatenated 100 -> joint Bernoulli layer 128; one numpy RandomState
+    threaded ME -> GE -> SM -> top as AMLsm2.py:38-62.  Same host code on both engines."""
+    import mdbn_amd
+    from _oracle_engine import OracleEngine
+    mdbn_amd.DBN.verbose = False
+    rs = np.random.RandomState(0)
+    N = 128
+    ge = rs.normal(size=(N, 2048)).astype(np.float32)
+    me = rs.normal(size=(N, 512)).astype(np.float32)
+    sm = (rs.uniform(size=(N, 256)) < 0.02).astype(np.float32)
+    sm = ((sm - sm.mean(0)) / (sm.std(0) + 1e-3)).astype(np.float32)
+    outs = []
+    for eng in (hip_engine, OracleEngine()):
+        rng = np.random.RandomState(123)
+        res = []
+        for data, sizes, k, lr in ((me, [40], 5, [0.002]), (ge, [400, 40], 1, [0.001, 0.1]), (sm, [200, 20], 1, [0.002, 0.1])):
+            d = mdbn_amd.DBN(numpy_rng=rng, n_ins=data.shape[1], hidden_layers_sizes=sizes[:-1], n_outs=sizes[-1], engine=eng)
+            d.shuffle_rng = np.random.RandomState(9)
+            d.training(mdbn_amd.shared(data, engine=eng), batch_size=32, k=k, pretraining_epochs=[8] * len(sizes),
+                       pretrain_lr=lr, lambda_1=0.0, lambda_2=0.1)
+            res.append(d.get_output(data))
+        joint = np.concatenate(res, axis=1)
+        top = mdbn_amd.DBN(numpy_rng=rng, n_ins=100, gauss=False, hidden_layers_sizes=[128], n_outs=3, engine=eng)
+        top.shuffle_rng = np.random.RandomState(10)
+        top.training(mdbn_amd.shared(joint, engine=eng), batch_size=32, k=1, pretraining_epochs=[8, 8], pretrain_lr=[0.1, 0.1])
+        outs.append((joint, top.get_output(joint), top.params[0].get_value()))
+    (ja, ta, wa), (jb, tb, wb) = outs
+    assert ja.shape == (N, 100) and ta.shape == (N, 3)
+    assert np.abs(ja - jb).max() <= 2e-4
+    assert np.abs(wa - wb).max() <= 2e-4 * max(1.0, np.abs(wb).max())
+    # fp32 vs float64 after four trained, stacked layers (sampling included): drift, not error
+    assert np.abs(ta - tb).max() <= 3e-3
