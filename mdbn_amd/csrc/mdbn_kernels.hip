@@ -112,10 +112,29 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (
 }
 
 // MFMA operand of lane (i = lane & 31, h = lane >> 5): element [mn = base + i][k = kk + h]
+#ifndef MFMA_AGPR
+#define MFMA_AGPR 0        // 1: inline-asm MFMA with the accumulators pinned to AGPRs
+#endif
+#ifndef CONSUMER_KG
+#define CONSUMER_KG 2      // k-pairs per fragment group = prefetch distance of the LDS reads
+#endif
+#ifndef ABLATE_FRAG
+#define ABLATE_FRAG 0    // diagnostic builds only: MFMA operands without LDS reads
+#endif
 template <int LAY, int ROWS, int KB>
 __device__ __forceinline__ float frag(const float* __restrict__ T, int mn, int k)
 {
+#if ABLATE_FRAG == 1
+    return (float)(mn + k) * 1e-3f;
+#elif ABLATE_FRAG == 3
+    return (float)(mn + k) * 1e-3f;
+#elif ABLATE_FRAG == 2
+    const float v = LAY == LAY_K ? T[mn * (KB + 1) + k] : T[k * ROWS + mn];
+    asm volatile("" :: "v"(v));
+    return (float)(mn + k) * 1e-3f;
+#else
     return LAY == LAY_K ? T[mn * (KB + 1) + k] : T[k * ROWS + mn];
+#endif
 }
 
 #ifdef MDBN_STAMP
@@ -212,7 +231,7 @@ __device__ __forceinline__ void gemm_consume(const GemmArgs& g, const float* __r
 {
     constexpr int BM = 64 * MI, BN = 64 * NI;
     constexpr int A_FLOATS = BM * (KB + 1), B_FLOATS = BN * (KB + 1), BUF = A_FLOATS + B_FLOATS;
-    constexpr int KG = 2, NG = KB / (2 * KG);       // groups of 2 k-pairs per slice
+    constexpr int KG = CONSUMER_KG, NG = KB / (2 * KG);   // groups of KG k-pairs per slice
     __syncthreads();                                // slice 0 staged
     for (int it = 0; it < nt; ++it) {
         STAMP(0);
@@ -245,10 +264,30 @@ __device__ __forceinline__ void gemm_consume(const GemmArgs& g, const float* __r
                 for (int a = 0; a < MI; ++a)
 #pragma unroll
                     for (int b = 0; b < NI; ++b)
+#if MFMA_AGPR
+                        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0"
+                                     : "+a"(acc[a][b]) : "v"(av[cs][u][a]), "v"(bv[cs][u][b]));
+#else
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cs][u][a], bv[cs][u][b], acc[a][b], 0, 0, 0);
-            // keep the next group's reads ahead of this group's MFMAs in the emitted order
-            __builtin_amdgcn_sched_group_barrier(0x100, KG * (MI + NI), 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, KG * MI * NI, 0);
+#endif
+#if ABLATE_FRAG == 3
+            {   // same bytes as the real fragment reads, fetched as 16-byte reads (dummy data)
+                const int ln = threadIdx.x & 63;
+#pragma unroll
+                for (int q = 0; q < KG * (MI + NI) / 4; ++q) {
+                    const float4 d = *reinterpret_cast<const float4*>(at + 4 * ln + 256 * (grp * 2 + q));
+                    asm volatile("" :: "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));
+                }
+            }
+#endif
+            // emitted order: one fragment read of the NEXT group behind every MFMA of this group,
+            // so each read issues in the 64-cycle shadow of a running MFMA (issued as a block
+            // after the MFMAs, the reads cost the matrix pipe ~18% -- diagnostic ablation)
+#pragma unroll
+            for (int m = 0; m < KG * MI * NI; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
         }
         STAMP(1);
         __syncthreads();
@@ -301,6 +340,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
     gemm_consume<LA, LB, MI, NI, KB>(g, smem, acc, nt, wm, wn, i, h);
+#if MFMA_AGPR
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA result -> v_accvgpr_read hazard (asm is opaque to hipcc)
+#endif
 
     // accumulator (32x32): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     float* C = g.C + (int64_t)ks * g.slab_stride;
@@ -397,10 +439,17 @@ __device__ __forceinline__ void philox_rows4(const PhiloxKey& k, uint32_t draw, 
     } else {
         uint32_t hi[4];
         philox4x32_10(col, (uint32_t)(g0 >> 2) + 1u, draw, k.step, k.k0, k.k1, hi);
+        // rows g0..g0+3 straddle two blocks: element r is word (ph + r) of the 8 words lo|hi.
+        // Selected with compile-time indices only (a runtime index would put lo/hi in scratch).
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint32_t s = ph + r;
-            w[r] = s < 4 ? lo[s & 3] : hi[s & 3];
+            uint32_t v = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t cand = j < 4 ? lo[j & 3] : hi[j & 3];
+                v = (ph + (uint32_t)r == (uint32_t)j) ? cand : v;
+            }
+            w[r] = v;
         }
     }
 }
