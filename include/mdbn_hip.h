@@ -103,7 +103,9 @@ int  mdbn_last_error(char *buf, size_t n);
 int  mdbn_ctx_create(mdbn_ctx **out, int device);
 int  mdbn_ctx_destroy(mdbn_ctx *ctx);
 
-/* Tuning knobs (process-wide).  "gemm_bk": GEMM slice depth, 0 = auto, 32 or 64. */
+/* Tuning knobs (process-wide).  "gemm_bk": GEMM slice depth, 0 = auto, 32 or 64.
+ * "update_overlap": 1 = mdbn_cd_train_step overlaps part of the update with the statistics GEMM
+ * on a side stream (default 0: measured slower, see csrc/mdbn_capi.hip). */
 int  mdbn_set_option(mdbn_ctx *ctx, const char *name, int64_t value);
 
 /* Measurement hook (bench.py): while enabled, every GEMM launch (the dominant kernel) is
@@ -156,6 +158,14 @@ int  mdbn_apply_update(mdbn_ctx *ctx, void *stream, const mdbn_update_args *a);
  * leaves the packed statistics in a->stats; follow with mdbn_apply_update (after the
  * all-reduce in data-parallel runs). */
 int  mdbn_cd_step(mdbn_ctx *ctx, void *stream, const mdbn_cd_args *a);
+
+/* The whole compiled step function for a single device (src/rbm.py:258-376): mdbn_cd_step
+ * followed by the update, in one call; results are identical to mdbn_cd_step +
+ * mdbn_apply_update.  upd->phase is ignored.  (Option "update_overlap" moves the bias / cost
+ * finalisation and the parameter half of the update onto an internal side stream under the
+ * statistics GEMM, which never reads W.) */
+int  mdbn_cd_train_step(mdbn_ctx *ctx, void *stream, const mdbn_cd_args *a,
+                        const mdbn_update_args *upd);
 
 /* free energy: RBM src/rbm.py:166-171, GRBM src/rbm.py:684-688;  out[N] */
 int  mdbn_free_energy(mdbn_ctx *ctx, void *stream, const float *x, int64_t N, int64_t ldv,

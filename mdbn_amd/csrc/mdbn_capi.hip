@@ -16,6 +16,10 @@ using namespace mdbn;
 struct mdbn_ctx {
     int device;
     int num_cu;
+    // side stream + events for mdbn_cd_train_step (memory-bound update work overlapped with the
+    // compute-bound statistics GEMM); created on first use
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 // Optional HIP-event timing of the GEMM launches (the dominant kernel), used by bench.py to
@@ -56,6 +60,10 @@ int fail(int code, const char* fmt, ...)
     } while (0)
 
 static int g_opt_gemm_bk = 0;          // mdbn_set_option("gemm_bk"): 0 = auto, 32, 64
+// mdbn_set_option("update_overlap"): run finalize + the parameter half of the update on a side
+// stream under the statistics GEMM.  Measured (profile r01j): the fork/join events cost more than
+// the ~12 us they hide (278.7 vs 259.6 us per step), so it is off by default.
+static int g_opt_update_overlap = 0;
 constexpr int kTargetJobs = 256;       // one 8-wave tile job per CU (MI355X: 256 CUs)
 constexpr int kMinSplitK = 128;        // >= 4 slices of BK = 32 per split
 
@@ -311,6 +319,11 @@ int mdbn_ctx_create(mdbn_ctx** out, int device)
 
 int mdbn_ctx_destroy(mdbn_ctx* ctx)
 {
+    if (ctx) {
+        if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+        if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+        if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    }
     delete ctx;
     return MDBN_OK;
 }
@@ -325,6 +338,10 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "gemm_bk") == 0) {
         REQUIRE(value == 0 || value == 32 || value == 64, "gemm_bk must be 0 (auto), 32 or 64");
         g_opt_gemm_bk = (int)value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "update_overlap") == 0) {
+        g_opt_update_overlap = value != 0;
         return MDBN_OK;
     }
     return fail(MDBN_EINVAL, "unknown option %s", name);
@@ -483,9 +500,18 @@ int mdbn_cd_stats(mdbn_ctx* ctx, void* stream, const float* V2, const float* P2,
     return MDBN_OK;
 }
 
+static int check_update_args(const mdbn_update_args* a);
+
 int mdbn_apply_update(mdbn_ctx* ctx, void* stream, const mdbn_update_args* a)
 {
     REQUIRE(ctx != nullptr && a != nullptr, "NULL argument");
+    CHECK(check_update_args(a));
+    HIP_OK(launch_update(*a, (hipStream_t)stream));
+    return MDBN_OK;
+}
+
+static int check_update_args(const mdbn_update_args* a)
+{
     REQUIRE(a->V > 0 && a->H > 0 && a->ldh >= a->H && a->ldv >= a->V && a->ldh % 4 == 0 && a->ldv % 4 == 0,
             "bad shape / leading dims");
     CHECK(check_mat(a->W, a->ldh, a->H, "W"));
@@ -497,11 +523,10 @@ int mdbn_apply_update(mdbn_ctx* ctx, void* stream, const mdbn_update_args* a)
     REQUIRE(a->phase >= 0 && a->phase <= 2, "phase must be 0, 1 or 2");
     REQUIRE(a->phase == 0 || (a->lambda_1 == 0.f && (a->weightcost == 0.f || a->W0 != nullptr)),
             "split update phases need lambda_1 == 0 and weightcost == 0 or a frozen W0");
-    HIP_OK(launch_update(*a, (hipStream_t)stream));
     return MDBN_OK;
 }
 
-int mdbn_cd_step(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a)
+static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, const mdbn_update_args* upd)
 {
     REQUIRE(ctx != nullptr && a != nullptr, "NULL argument");
     const int64_t B = a->B, V = a->V, H = a->H, ldv = a->ldv, ldh = a->ldh;
@@ -560,8 +585,36 @@ int mdbn_cd_step(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a)
     float* s_h = a->stats + V * ldh;
     float* s_v = s_h + ldh;
     float* cost = s_v + ldv;
-    HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials,
-                                 n_cost, s_h, s_v, cost, s));
+
+    // The statistics GEMM reads only V2 / P2 -- never W -- and the parameter half of the update
+    // (theta * m + OLD speed * lr, rbm.py:364-365) does not need its result.  With an update
+    // attached (single device) the bias/cost finalize and that parameter half run on a side
+    // stream UNDER the compute-bound GEMM; only the speed half waits for S.
+    bool overlap = false;
+    mdbn_update_args u;
+    if (upd) {
+        u = *upd;
+        REQUIRE(u.stats == a->stats && u.W == a->W && u.ldh == ldh && u.ldv == ldv && u.V == V && u.H == H,
+                "update arguments do not match the step's buffers");
+        overlap = g_opt_update_overlap != 0 && u.lambda_1 == 0.f && (u.weightcost == 0.f || u.W0 != nullptr);
+        if (overlap && ctx->side == nullptr) {
+            HIP_OK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+    }
+    if (overlap) {
+        HIP_OK(hipEventRecord(ctx->ev_fork, s));
+        HIP_OK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials,
+                                     n_cost, s_h, s_v, cost, ctx->side));
+        u.phase = 2;
+        HIP_OK(launch_update(u, ctx->side));
+        HIP_OK(hipEventRecord(ctx->ev_join, ctx->side));
+    } else {
+        HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials,
+                                     n_cost, s_h, s_v, cost, s));
+    }
     const Plan p = plan_gemm(V, H, 2 * B);
     GemmArgs g;
     g.A = a->V2; g.lda = ldv; g.B = a->P2; g.ldb = ldh;
@@ -576,7 +629,28 @@ int mdbn_cd_step(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a)
         HIP_OK(timed_gemm(LAY_MN, LAY_MN, g, s));
         HIP_OK(launch_sum_slabs(ws.slabs, p.splitk, g.slab_stride, V * ldh, S, s));
     }
+    if (upd) {
+        if (overlap) {
+            HIP_OK(hipStreamWaitEvent(s, ctx->ev_join, 0));
+            u.phase = 1;
+        } else {
+            u.phase = 0;
+        }
+        HIP_OK(launch_update(u, s));
+    }
     return MDBN_OK;
+}
+
+int mdbn_cd_step(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a)
+{
+    return cd_step_impl(ctx, stream, a, nullptr);
+}
+
+int mdbn_cd_train_step(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, const mdbn_update_args* upd)
+{
+    REQUIRE(upd != nullptr, "update arguments are NULL");
+    CHECK(check_update_args(upd));
+    return cd_step_impl(ctx, stream, a, upd);
 }
 
 int mdbn_free_energy(mdbn_ctx* ctx, void* stream, const float* x, int64_t N, int64_t ldv, const float* W,

@@ -764,29 +764,42 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
     }
     const float two_lr_l1 = 2.0f * lr * l1;
     const float decay = 1.0f - 2.0f * lr * l2;
-    const bool need_w = do_params || l1 != 0.0f || (wc != 0.0f && W0 == nullptr);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 w = need_w ? W[i] : zero, sp = Ws[i];
-        const float4 st = do_speed ? S[i] : zero;
-        const float4 wc0 = (do_speed && wc != 0.0f) ? (W0 ? W0[i] : w) : zero;
-        float4 wn, sn;
+        const float4 sp = Ws[i];
+        if constexpr (DO_SPEED && DO_PARAMS) {
+            const float4 w = W[i], st = S[i];
+            const float4 wc0 = W0 ? W0[i] : w;
+            float4 wn, sn;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float wj = comp(w, j), spj = comp(sp, j);
-            float g = comp(st, j) * inv_bs - wc * comp(wc0, j);
-            float m = decay;
-            if (l1 != 0.0f) {
-                const float shrink = 1.0f + two_lr_l1 / (fabsf(wj) + 0.001f);
-                g = g / shrink;
-                m = decay / shrink;
+            for (int j = 0; j < 4; ++j) {
+                const float wj = comp(w, j), spj = comp(sp, j);
+                float g = comp(st, j) * inv_bs - wc * comp(wc0, j);
+                float m = decay;
+                if (l1 != 0.0f) {
+                    const float shrink = 1.0f + two_lr_l1 / (fabsf(wj) + 0.001f);
+                    g = g / shrink;
+                    m = decay / shrink;
+                }
+                setc(sn, j, g + (spj - g) * mu);
+                setc(wn, j, wj * m + spj * lr);
             }
-            setc(sn, j, g + (spj - g) * mu);
-            setc(wn, j, wj * m + spj * lr);
+            W[i] = wn;
+            Ws[i] = sn;
+        } else if constexpr (DO_PARAMS) {           // lambda_1 == 0 (checked by the host): m = decay
+            const float4 w = W[i];
+            W[i] = make_float4(w.x * decay + sp.x * lr, w.y * decay + sp.y * lr,
+                               w.z * decay + sp.z * lr, w.w * decay + sp.w * lr);
+        } else {                                    // speeds only; weight cost, if any, uses W0
+            const float4 st = S[i];
+            float4 g = make_float4(st.x * inv_bs, st.y * inv_bs, st.z * inv_bs, st.w * inv_bs);
+            if (wc != 0.0f) {
+                const float4 w0 = W0[i];
+                g.x -= wc * w0.x; g.y -= wc * w0.y; g.z -= wc * w0.z; g.w -= wc * w0.w;
+            }
+            Ws[i] = make_float4(g.x + (sp.x - g.x) * mu, g.y + (sp.y - g.y) * mu,
+                                g.z + (sp.z - g.z) * mu, g.w + (sp.w - g.w) * mu);
         }
-        if (do_params) W[i] = wn;
-        if (do_speed) Ws[i] = sn;
     }
 }
 

@@ -260,11 +260,7 @@ class HipEngine(object):
         return out
 
     # ------------------------------------------------------------------ CD-k
-    def cd_step(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent=None, add_noise=False,
-                stats_slot=0):
-        """gather + positive phase + k Gibbs steps + statistics (rbm.py:303-345,374).
-        Returns (stats, scratch): the packed [S | s_h | s_v | cost_sum] buffer and the
-        CDScratch holding ph_mean / nv_mean / nh_mean for inspection."""
+    def _cd_args(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent, add_noise, stats_slot):
         data = self.as_matrix(data)
         V, H = W.shape
         assert data.shape[1] == V, "data has %d columns, RBM has %d visibles" % (data.shape[1], V)
@@ -282,7 +278,7 @@ class HipEngine(object):
         a.index_is_64 = int(idx is not None and idx.dtype == torch.int64)
         a.gauss, a.add_noise, a.k = int(bool(gauss)), int(bool(add_noise)), int(k)
         a.B, a.V, a.H = B, V, H
-        a.ldv, a.ldh = data.stride(0), W.stride(0)
+        a.ldv, a.ldh = ldv, ldh
         a.W, a.hbias, a.vbias = W.data_ptr(), hbias.data_ptr(), vbias.data_ptr()
         a.persistent = persistent.data_ptr() if persistent is not None else None
         a.V2, a.P2, a.hs = sc.V2.data_ptr(), sc.P2.data_ptr(), sc.hs.data_ptr()
@@ -290,14 +286,20 @@ class HipEngine(object):
         a.stats = stats.data_ptr()
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         a.rng = rng.c()
+        return a, stats, sc, (data, idx, ws)        # keep the tensors alive until enqueued
+
+    def cd_step(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent=None, add_noise=False,
+                stats_slot=0):
+        """gather + positive phase + k Gibbs steps + statistics (rbm.py:303-345,374).
+        Returns (stats, scratch): the packed [S | s_h | s_v | cost_sum] buffer and the
+        CDScratch holding ph_mean / nv_mean / nh_mean for inspection."""
+        a, stats, sc, _keep = self._cd_args(data, indexes, W, hbias, vbias, gauss, k, rng, persistent,
+                                            add_noise, stats_slot)
         _lib.check(self.lib.mdbn_cd_step(self.ctx, self._stream(), C.byref(a)), "mdbn_cd_step")
         return stats, sc
 
-    def apply_update(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats,
-                     lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale, phase=0,
-                     ldv=None):
-        """rbm.py:347-365; returns the monitoring cost as a 0-d device tensor.
-        phase: 0 = whole rule, 1 = speeds (+cost) only, 2 = parameters only (mdbn_update_args)."""
+    def _update_args(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats, lr, lambda_1,
+                     lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale, phase, ldv):
         V, H = W.shape
         slot = self._cost_slot
         self._cost_slot = (slot + 1) % self._cost_ring.numel()
@@ -314,6 +316,29 @@ class HipEngine(object):
         u.batch_size, u.n_rows, u.cost_scale = float(batch_size), float(n_rows), float(cost_scale)
         u.cost_out = cost.data_ptr()
         u.phase = int(phase)
+        return u, cost
+
+    def cd_train_step(self, data, indexes, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, gauss, k,
+                      rng, lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale):
+        """The whole single-device step function (mdbn_cd_train_step): cd_step + update, with the
+        finalize / parameter half of the update overlapped under the statistics GEMM.  Returns the
+        monitoring cost (0-d device tensor)."""
+        a, stats, sc, _keep = self._cd_args(data, indexes, W, hbias, vbias, gauss, k, rng, None, False, 0)
+        u, cost = self._update_args(W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats, lr,
+                                    lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale,
+                                    0, a.ldv)
+        _lib.check(self.lib.mdbn_cd_train_step(self.ctx, self._stream(), C.byref(a), C.byref(u)),
+                   "mdbn_cd_train_step")
+        return cost
+
+    def apply_update(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats,
+                     lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale, phase=0,
+                     ldv=None):
+        """rbm.py:347-365; returns the monitoring cost as a 0-d device tensor.
+        phase: 0 = whole rule, 1 = speeds (+cost) only, 2 = parameters only (mdbn_update_args)."""
+        u, cost = self._update_args(W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats, lr,
+                                    lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale,
+                                    phase, ldv)
         _lib.check(self.lib.mdbn_apply_update(self.ctx, self._stream(), C.byref(u)), "mdbn_apply_update")
         return cost
 

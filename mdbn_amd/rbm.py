@@ -166,6 +166,18 @@ class StepFunction(object):
                 raise ValueError("persistent chain has %d rows but the minibatch has %d "
                                  "(the reference fails the same way, rbm.py:416)"
                                  % (persistent.shape[0], n_global))
+        if not distributed and p.persistent is None and hi > lo:
+            # single device: the whole step function in one library call (mdbn_cd_train_step)
+            cost_scale = 1.0 / (n_global * rbm.n_visible) if rbm.gauss else 1.0 / n_global
+            out = eng.cd_train_step(data, idx, rbm.W.tensor, rbm.W_speed.tensor,
+                                    p.W0.tensor if p.W0 is not None else None,
+                                    rbm.hbias.tensor, rbm.hbias_speed.tensor, rbm.vbias.tensor,
+                                    rbm.vbias_speed.tensor, rbm.gauss, p.k,
+                                    RngAddr(rbm.theano_rng.seed, rbm.stream_id, step, 0, lo),
+                                    lr, p.lambda_1, p.lambda_2, p.weightcost, momentum, batch_size,
+                                    n_global, cost_scale)
+            rbm._n_updates += 1
+            return out
         slot = self._n_calls & 1 if self.overlap else 0     # the other buffer may still be reducing
         self._n_calls += 1
         if hi > lo:

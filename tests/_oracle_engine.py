@@ -155,6 +155,12 @@ class OracleEngine(object):
             dst.copy_(self._t(src))
         return torch.tensor(float(st[V * H + H + V]) * cost_scale, dtype=self.t_dtype)
 
+    def cd_train_step(self, data, indexes, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, gauss, k,
+                      rng, lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale):
+        stats, _ = self.cd_step(data, indexes, W, hbias, vbias, gauss, k, rng)
+        return self.apply_update(W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats, lr, lambda_1,
+                                 lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale)
+
     def rng_uniform(self, rows, cols, rng, normal_=False):
         f = normal if normal_ else uniform
         return torch.from_numpy(f(rows, cols, rng.seed, rng.stream_id, rng.step, rng.draw, rng.row_offset))
