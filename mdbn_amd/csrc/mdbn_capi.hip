@@ -171,7 +171,7 @@ WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
     s.slab = std::max(up.slab_floats(B, ldh), down.slab_floats(B, ldv));
     if (st.splitk > 1) s.slab = std::max(s.slab, st.slab_floats(V, ldh));
     s.slab = std::max<int64_t>(s.slab, 4 * std::max(ldv, ldh) * 8);
-    s.cost = std::max(epilogue_blocks(B, ldv), epilogue_blocks(B, ldh)) + 64;
+    s.cost = (((B + 3) / 4) * std::max(ldv, ldh) + 255) / 256 + 64;     // worst case: one column per thread
     const int ng = row_groups(B);
     s.colP = 2 * (int64_t)ng * ldh;
     s.colV = (int64_t)ng * ldv;
@@ -338,6 +338,11 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "gemm_bk") == 0) {
         REQUIRE(value == 0 || value == 32 || value == 64, "gemm_bk must be 0 (auto), 32 or 64");
         g_opt_gemm_bk = (int)value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "epilogue_cw") == 0) {
+        REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "epilogue_cw must be 0 (auto), 1, 2 or 4");
+        set_epilogue_cw((int)value);
         return MDBN_OK;
     }
     if (strcmp(name, "update_overlap") == 0) {

@@ -45,11 +45,10 @@ struct EpiArgs {
     PhiloxKey rng;
 };
 
-inline int epilogue_blocks(int64_t rows, int64_t ld)
-{
-    const int64_t n = ((rows + 3) / 4) * (ld / 4);
-    return (int)((n + 255) / 256);
-}
+// blocks (= cost partials) the activation epilogue launches for a [rows, ld] output
+int epilogue_blocks(int64_t rows, int64_t ld);
+int epilogue_cw(int64_t rows, int64_t ld);
+void set_epilogue_cw(int cw);
 inline int row_groups(int64_t B) { return (int)((B + 3) / 4); }
 
 hipError_t launch_gemm(int la, int lb, const GemmArgs& g, hipStream_t s);

@@ -473,81 +473,92 @@ __device__ __forceinline__ void setc(float4& v, int j, float x)
 //   colsum != NULL: per-thread partial of the bias statistics (rbm.py:416-417) over the
 //              thread's 4 rows: colsum_kind 0 = sum of the stored (scaled) mean,
 //              1 = sum of (target - mean); written to colsum[row_group][col].
-// One thread = 4 rows x 4 columns: float4 traffic, one Philox block per column.
+// One thread = 4 rows x CW columns (CW = 4, 2 or 1: float4 / float2 / float traffic), one
+// Philox block per column.  The kernel is latency-bound (one wave of blocks, slabs resident in
+// L2 / Infinity Cache), so narrower threads = more of them = shorter serial chain per thread.
 // NS > 0: compile-time split count (all slab loads of a row in flight together).
 // ----------------------------------------------------------------------------------
-template <int NS>
+template <int CW> struct VecIO;
+template <> struct VecIO<4> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct VecIO<2> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[2]) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[2]) { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+};
+template <> struct VecIO<1> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[1]) { v[0] = *p; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[1]) { *p = v[0]; }
+};
+
+template <int NS, int CW>
 __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
 {
     __shared__ float red[4];
-    const int ld4 = (int)(e.ld >> 2);
+    const int ldc = (int)(e.ld / CW);                    // column groups per row
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int rg = (int)(idx / ld4), cq = (int)(idx - (int64_t)rg * ld4);
-    const int r0 = rg * 4, c0 = cq * 4;
+    const int rg = (int)(idx / ldc), cq = (int)(idx - (int64_t)rg * ldc);
+    const int r0 = rg * 4, c0 = cq * CW;
     float cost = 0.f;
     if (r0 < e.rows) {
-        const float4 bias4 = make_float4(c0 + 0 < e.cols ? e.bias[c0 + 0] : 0.f,
-                                         c0 + 1 < e.cols ? e.bias[c0 + 1] : 0.f,
-                                         c0 + 2 < e.cols ? e.bias[c0 + 2] : 0.f,
-                                         c0 + 3 < e.cols ? e.bias[c0 + 3] : 0.f);
-        float4 pre[4];
+        float bias[CW];
+#pragma unroll
+        for (int j = 0; j < CW; ++j) bias[j] = c0 + j < e.cols ? e.bias[c0 + j] : 0.f;
+        float pre[4][CW];
         const float* base = e.slabs + (int64_t)r0 * e.ld + c0;
-        if (NS > 0) {
-            float4 v[4][NS > 0 ? NS : 1];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int sidx = 0; sidx < NS; ++sidx)
-                    v[r][sidx] = (r0 + r < e.rows)
-                        ? *reinterpret_cast<const float4*>(base + (int64_t)r * e.ld + (int64_t)sidx * e.slab_stride)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float4 a = v[r][0];
-#pragma unroll
-                for (int sidx = 1; sidx < NS; ++sidx) {
-                    a.x += v[r][sidx].x; a.y += v[r][sidx].y; a.z += v[r][sidx].z; a.w += v[r][sidx].w;
-                }
-                pre[r] = a;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r0 + r < e.rows)
-                    for (int sidx = 0; sidx < e.nsplit; ++sidx) {
-                        const float4 t = *reinterpret_cast<const float4*>(base + (int64_t)r * e.ld + (int64_t)sidx * e.slab_stride);
-                        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-                    }
-                pre[r] = a;
-            }
-        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            pre[r].x += bias4.x; pre[r].y += bias4.y; pre[r].z += bias4.z; pre[r].w += bias4.w;
+#pragma unroll
+            for (int j = 0; j < CW; ++j) pre[r][j] = 0.f;
+            if (r0 + r < e.rows) {
+                if (NS > 0) {
+                    float v[NS > 0 ? NS : 1][CW];
+#pragma unroll
+                    for (int sidx = 0; sidx < NS; ++sidx)
+                        VecIO<CW>::load(base + (int64_t)r * e.ld + (int64_t)sidx * e.slab_stride, v[sidx]);
+#pragma unroll
+                    for (int sidx = 0; sidx < NS; ++sidx)
+#pragma unroll
+                        for (int j = 0; j < CW; ++j) pre[r][j] += v[sidx][j];
+                } else {
+                    for (int sidx = 0; sidx < e.nsplit; ++sidx) {
+                        float v[CW];
+                        VecIO<CW>::load(base + (int64_t)r * e.ld + (int64_t)sidx * e.slab_stride, v);
+#pragma unroll
+                        for (int j = 0; j < CW; ++j) pre[r][j] += v[j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CW; ++j) pre[r][j] += bias[j];
         }
-        uint32_t wa[4][4], wb[4][4];       // [col][row]
+        uint32_t wa[CW][4], wb[CW][4];       // [col][row]
         const bool need_u = e.sample != nullptr;
         const bool need_z = need_u && e.gauss;
         if (need_u) {
             const uint64_t g0 = e.rng.row_offset + (uint64_t)r0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < CW; ++j) {
                 philox_rows4(e.rng, e.rng.draw, g0, (uint32_t)(c0 + j), wa[j]);
                 if (need_z) philox_rows4(e.rng, e.rng.draw | MDBN_NORMAL_BIT, g0, (uint32_t)(c0 + j), wb[j]);
             }
         }
-        float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+        float csum[CW];
+#pragma unroll
+        for (int j = 0; j < CW; ++j) csum[j] = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (r0 + r >= e.rows) continue;
             const int64_t off = (int64_t)(r0 + r) * e.ld + c0;
-            float4 mean4, samp4, tgt4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e.target) tgt4 = *reinterpret_cast<const float4*>(e.target + (int64_t)(r0 + r) * e.ld_target + c0);
+            float mean[CW], samp[CW], tgt[CW];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < CW; ++j) tgt[j] = 0.f;
+            if (e.target) VecIO<CW>::load(e.target + (int64_t)(r0 + r) * e.ld_target + c0, tgt);
+#pragma unroll
+            for (int j = 0; j < CW; ++j) {
                 const bool live = c0 + j < e.cols;
-                const float x = comp(pre[r], j);
+                const float x = pre[r][j];
                 float m, sv = 0.f;
                 if (e.gauss) {
                     m = x;
@@ -559,22 +570,21 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
                     m = sigmoidf_(x);
                     if (need_u) sv = philox_u01(wa[j][r]) < m ? 1.0f : 0.0f;
                 }
-                const float tg = comp(tgt4, j);
                 if (e.target && live) {
-                    if (e.gauss) { const float d = sigmoidf_(x) - tg; cost += d * d; }
-                    else cost += tg * softplusf_(-x) + (1.0f - tg) * softplusf_(x);
+                    if (e.gauss) { const float d = sigmoidf_(x) - tgt[j]; cost += d * d; }
+                    else cost += tgt[j] * softplusf_(-x) + (1.0f - tgt[j]) * softplusf_(x);
                 }
-                if (!live) { m = 0.f; sv = 0.f; setc(pre[r], j, 0.f); }   // keep pad columns zero
+                if (!live) { m = 0.f; sv = 0.f; pre[r][j] = 0.f; }   // keep pad columns zero
                 const float ms = m * e.mean_scale;
-                setc(mean4, j, ms);
-                setc(samp4, j, sv);
-                if (live) setc(csum, j, comp(csum, j) + (e.colsum_kind ? tg - m : ms));
+                mean[j] = ms;
+                samp[j] = sv;
+                if (live) csum[j] += e.colsum_kind ? tgt[j] - m : ms;
             }
-            if (e.pre) *reinterpret_cast<float4*>(e.pre + off) = pre[r];
-            if (e.mean) *reinterpret_cast<float4*>(e.mean + off) = mean4;
-            if (e.sample) *reinterpret_cast<float4*>(e.sample + off) = samp4;
+            if (e.pre) VecIO<CW>::store(e.pre + off, pre[r]);
+            if (e.mean) VecIO<CW>::store(e.mean + off, mean);
+            if (e.sample) VecIO<CW>::store(e.sample + off, samp);
         }
-        if (e.colsum) *reinterpret_cast<float4*>(e.colsum + (int64_t)rg * e.ld + c0) = csum;
+        if (e.colsum) VecIO<CW>::store(e.colsum + (int64_t)rg * e.ld + c0, csum);
     }
     if (e.cost_partials) {
         const float tot = block_sum(cost, red);
@@ -582,15 +592,44 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
     }
 }
 
+static int g_epilogue_cw = 0;     // 0 = auto; 4, 2 or 1 (mdbn_set_option "epilogue_cw")
+void set_epilogue_cw(int cw) { g_epilogue_cw = cw; }
+
+int epilogue_cw(int64_t rows, int64_t ld)
+{
+    if (g_epilogue_cw) return g_epilogue_cw;
+    // enough 4-wide threads to fill the chip several times over? then keep float4 traffic
+    const int64_t threads4 = ((rows + 3) / 4) * (ld / 4);
+    return threads4 >= 8 * 256 * 256 ? 4 : 2;
+}
+
+int epilogue_blocks(int64_t rows, int64_t ld)
+{
+    const int cw = epilogue_cw(rows, ld);
+    const int64_t n = ((rows + 3) / 4) * (ld / cw);
+    return (int)((n + 255) / 256);
+}
+
+template <int CW>
+static void launch_act_epilogue_cw(const EpiArgs& e, hipStream_t s)
+{
+    const int64_t n = ((int64_t)(e.rows + 3) / 4) * (e.ld / CW);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    switch (e.nsplit) {
+        case 1: hipLaunchKernelGGL((act_epilogue_kernel<1, CW>), grid, block, 0, s, e); break;
+        case 2: hipLaunchKernelGGL((act_epilogue_kernel<2, CW>), grid, block, 0, s, e); break;
+        case 4: hipLaunchKernelGGL((act_epilogue_kernel<4, CW>), grid, block, 0, s, e); break;
+        case 8: hipLaunchKernelGGL((act_epilogue_kernel<8, CW>), grid, block, 0, s, e); break;
+        default: hipLaunchKernelGGL((act_epilogue_kernel<0, CW>), grid, block, 0, s, e); break;
+    }
+}
+
 hipError_t launch_act_epilogue(const EpiArgs& e, hipStream_t s)
 {
-    const dim3 grid(epilogue_blocks(e.rows, e.ld)), block(256);
-    switch (e.nsplit) {
-        case 1: hipLaunchKernelGGL(act_epilogue_kernel<1>, grid, block, 0, s, e); break;
-        case 2: hipLaunchKernelGGL(act_epilogue_kernel<2>, grid, block, 0, s, e); break;
-        case 4: hipLaunchKernelGGL(act_epilogue_kernel<4>, grid, block, 0, s, e); break;
-        case 8: hipLaunchKernelGGL(act_epilogue_kernel<8>, grid, block, 0, s, e); break;
-        default: hipLaunchKernelGGL(act_epilogue_kernel<0>, grid, block, 0, s, e); break;
+    switch (epilogue_cw(e.rows, e.ld)) {
+        case 4: launch_act_epilogue_cw<4>(e, s); break;
+        case 2: launch_act_epilogue_cw<2>(e, s); break;
+        default: launch_act_epilogue_cw<1>(e, s); break;
     }
     return hipGetLastError();
 }
@@ -628,14 +667,15 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
                                                           int idx64, int64_t ld4, float* __restrict__ dst,
                                                           int64_t ld_dst)
 {
-    const int64_t r = blockIdx.x;
+    // one float4 per thread: grid = (column chunks of 256 float4, rows)
+    const int64_t r = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ld4) return;
     int64_t s = r;
     if (idx) s = idx64 ? reinterpret_cast<const int64_t*>(idx)[r] : (int64_t)reinterpret_cast<const int32_t*>(idx)[r];
     if (s < 0) s += n_rows;                       // numpy-style negative index
     s = s < 0 ? 0 : (s >= n_rows ? n_rows - 1 : s);   // never fault on a bad index
-    const float4* in = reinterpret_cast<const float4*>(src + s * ld_src);
-    float4* out = reinterpret_cast<float4*>(dst + r * ld_dst);
-    for (int64_t c = threadIdx.x; c < ld4; c += blockDim.x) out[c] = in[c];
+    reinterpret_cast<float4*>(dst + r * ld_dst)[c] = reinterpret_cast<const float4*>(src + s * ld_src)[c];
 }
 
 hipError_t launch_gather(const float* src, int64_t n_rows, int64_t cols_ld, int64_t ld_src,
@@ -643,8 +683,18 @@ hipError_t launch_gather(const float* src, int64_t n_rows, int64_t cols_ld, int6
                          hipStream_t s)
 {
     if (n_idx <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n_idx), dim3(256), 0, s, src, n_rows, ld_src,
-                       idx, idx64, cols_ld >> 2, dst, ld_dst);
+    const int64_t ld4 = cols_ld >> 2;
+    const int64_t rows_per_launch = 65535;        // gridDim.y limit
+    for (int64_t r0 = 0; r0 < n_idx; r0 += rows_per_launch) {
+        const int64_t nr = std::min(rows_per_launch, n_idx - r0);
+        const void* ip = idx ? (idx64 ? (const void*)(reinterpret_cast<const int64_t*>(idx) + r0)
+                                      : (const void*)(reinterpret_cast<const int32_t*>(idx) + r0))
+                             : nullptr;
+        // identity gather of a later chunk: offset the source instead of the (absent) index list
+        const float* sp = idx ? src : src + r0 * ld_src;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ld4 + 255) / 256), (unsigned)nr), dim3(256), 0, s,
+                           sp, idx ? n_rows : n_rows - r0, ld_src, ip, idx64, ld4, dst + r0 * ld_dst, ld_dst);
+    }
     return hipGetLastError();
 }
 

@@ -1,0 +1,27 @@
+"""Interleaved A/B of a library option on the full CD-1 step (bench workload)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, mdbn_amd
+opt, values = sys.argv[1], [int(v) for v in sys.argv[2:]]
+eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
+V, H, B, N = 4096, 1024, 512, 32768
+g = torch.Generator(device="cpu").manual_seed(0)
+data = mdbn_amd.shared(torch.randn((N, V), generator=g).to(eng.device))
+rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123))
+_, up = rbm.get_cost_updates(lr=0.001, k=1, lambda_2=0.1, batch_size=B)
+fn = mdbn_amd.function(up, data)
+perm = torch.from_numpy(np.random.RandomState(1).permutation(N)).to(eng.device)
+def run(n):
+    for it in range(n):
+        mb = it % (N // B)
+        fn(indexes=perm[mb * B:(mb + 1) * B], momentum=0.0)
+res = {v: [] for v in values}
+run(20); eng.synchronize()
+for rnd in range(5):
+    for v in values:
+        eng.set_option(opt, v)
+        run(5); eng.synchronize()
+        t0 = time.perf_counter(); run(100); eng.synchronize()
+        res[v].append((time.perf_counter() - t0) * 1e4)
+for v in values:
+    print("%s=%d: median %.1f us/step (min %.1f)" % (opt, v, np.median(res[v]), min(res[v])))
