@@ -54,7 +54,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MDBN_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals (RCCL needs
+            # one GPU per rank); the default on GPUs is nccl = RCCL over xGMI
+            backend = os.environ.get("MDBN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
