@@ -195,6 +195,8 @@ class HipEngine(object):
         pre = self.alloc_matrix(B, H, ldh) if want_pre else None
         mean = self.alloc_matrix(B, H, ldh) if want_mean else None
         sample = self.alloc_matrix(B, H, ldh) if want_sample else None
+        if B == 0:
+            return pre, mean, sample
         ws = self.workspace(min(B, 4096), V, H)
         r = rng.c() if rng is not None else None
         _lib.check(self.lib.mdbn_propup_sample(
@@ -217,6 +219,8 @@ class HipEngine(object):
         mean = self.alloc_matrix(B, V)
         sample = self.alloc_matrix(B, V)
         pre = mean if gauss else self.alloc_matrix(B, V)     # GRBM: "pre" is the mean (rbm.py:660)
+        if B == 0:
+            return (pre, mean, sample) if v0 is None else (pre, mean, sample, torch.zeros((), device=self.device))
         ws = self.workspace(min(B, 4096), V, H)
         r = rng.c() if rng is not None else None
         cost = None
@@ -242,6 +246,8 @@ class HipEngine(object):
         N, V = x.shape
         H = W.shape[1]
         out = self.alloc_vector(N)
+        if N == 0:
+            return out
         ws = self.workspace(min(N, 4096), V, H)
         _lib.check(self.lib.mdbn_free_energy(
             self.ctx, self._stream(), self._p(x), N, x.stride(0), self._p(W), V, H, W.stride(0),
@@ -253,6 +259,8 @@ class HipEngine(object):
         src = self.as_matrix(src)
         idx = self.index_tensor(indexes)
         out = self.alloc_matrix(idx.numel(), src.shape[1])
+        if idx.numel() == 0:
+            return out
         _lib.check(self.lib.mdbn_gather_rows(
             self.ctx, self._stream(), self._p(src), src.shape[0], src.shape[1], src.stride(0),
             self._p(idx), int(idx.dtype == torch.int64), idx.numel(), self._p(out), out.stride(0)),

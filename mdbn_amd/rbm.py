@@ -367,7 +367,10 @@ class RBM(object):
                 "and has no device kernel; the RBM-specific gradient (rbm.py:392-419) is used")
         W0 = None
         if weightcost != 0.0 and self.strict_reference:
-            W0 = SharedArray(None, engine=self.engine, _tensor=self.W.tensor.clone())   # rbm.py:415
+            # rbm.py:415; same padded layout as W (a plain clone() would drop the leading dimension)
+            snap = self.engine.alloc_matrix(self.n_visible, self.n_hidden, self.W.tensor.stride(0))
+            snap.copy_(self.W.tensor)
+            W0 = SharedArray(None, engine=self.engine, _tensor=snap)
         if persistent is not None:
             persistent = shared(persistent, engine=self.engine)
             if persistent.tensor.stride(0) != self.W.tensor.stride(0):

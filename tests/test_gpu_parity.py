@@ -406,3 +406,87 @@ def test_config5_three_modality_mdbn(hip_engine):
     assert np.abs(wa - wb).max() <= 2e-4 * max(1.0, np.abs(wb).max())
     # fp32 vs float64 after four trained, stacked layers (sampling included): drift, not error
     assert np.abs(ta - tb).max() <= 3e-3
+
+
+def _sweep_shapes():
+    rs = np.random.RandomState(2024)
+    shapes = [(1, 1, 1), (2, 3, 1), (5, 7, 2), (31, 33, 3), (32, 32, 4), (33, 31, 5), (63, 65, 7), (64, 64, 1),
+              (127, 129, 9), (129, 127, 130), (257, 61, 33), (61, 257, 65), (500, 784, 20), (1021, 509, 131),
+              (96, 2053, 17), (2053, 96, 260)]
+    for _ in range(8):
+        shapes.append((int(rs.randint(1, 700)), int(rs.randint(1, 700)), int(rs.randint(1, 300))))
+    return shapes
+
+
+@pytest.mark.parametrize("V,H,B", _sweep_shapes())
+def test_shape_sweep_chain_and_update(hip_engine, V, H, B):
+    """Tile edges everywhere: sizes below one tile / one slice, primes, ragged tails, single rows.
+    One CD-2 step of a Bernoulli RBM and one CD-1 step of a GRBM through the classes vs the oracle."""
+    import mdbn_amd
+    rs = np.random.RandomState(V * 7 + H * 3 + B)
+    N = B + 3
+    for cls, gauss, hp, k in ((mdbn_amd.RBM, False, dict(lr=0.1, weightcost=2e-4), 2),
+                              (mdbn_amd.GRBM, True, dict(lr=0.002, lambda_1=0.01, lambda_2=0.1), 1)):
+        data = rs.normal(size=(N, V)).astype(np.float32) if gauss else (rs.uniform(size=(N, V)) < 0.4).astype(np.float32)
+        rbm = cls(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(V + H), theano_rng=mdbn_amd.RandomStreams(77),
+                  engine=hip_engine)
+        st = rbm_np.RBMState(V, H, W=rbm.W.get_value(), gauss=gauss)
+        if hp.get("weightcost"):
+            st.freeze_W0()
+        _, up = rbm.get_cost_updates(k=k, batch_size=B, **hp)
+        fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=hip_engine), data_parallel=None)
+        idx = rs.permutation(N)[:B]
+        for t in range(2):
+            c = float(fn(indexes=idx, momentum=0.5))
+            c_o = rbm_np.cd_step(st, data[idx], PhiloxDraws(77, rbm.stream_id, t), k=k, batch_size=B, momentum=0.5, **hp)
+            assert abs(c - c_o) <= 2e-4 * abs(c_o) + 1e-6, (cls.__name__, t, c, c_o)
+        for name in ("W", "hbias", "vbias", "W_speed", "hbias_speed", "vbias_speed"):
+            got, want = getattr(rbm, name).get_value(), getattr(st, name)
+            # two steps of fp32 chains (k up to 2053 long) against float64
+            assert np.abs(got - want).max() <= 5e-5 * max(1.0, np.abs(want).max()), (cls.__name__, name)
+        F = rbm.free_energy(data).get_value()
+        F_o = rbm_np.free_energy(st, data.astype(np.float64))
+        assert np.abs(F - F_o).max() <= 1e-4 * max(1.0, np.abs(F_o).max())
+
+
+def test_pcd_on_device(hip_engine):
+    """PCD-k (rbm.py:308-311,367-371): persistent chain as chain start, replaced by nh_sample,
+    pseudo-likelihood cost with the rotating bit index -- against the oracle, 4 steps."""
+    import mdbn_amd
+    V, H, B, N = 96, 40, 16, 64
+    rs = np.random.RandomState(5)
+    data = (rs.uniform(size=(N, V)) < 0.3).astype(np.float32)
+    rbm = mdbn_amd.RBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(1), theano_rng=mdbn_amd.RandomStreams(9),
+                       engine=hip_engine)
+    st = rbm_np.RBMState(V, H, W=rbm.W.get_value())
+    st.persistent = np.zeros((B, H))
+    chain = mdbn_amd.shared(np.zeros((B, H), dtype=np.float32), engine=hip_engine)
+    _, up = rbm.get_cost_updates(lr=0.1, k=2, batch_size=B, persistent=chain)
+    fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=hip_engine), data_parallel=None)
+    for t in range(4):
+        idx = rs.permutation(N)[:B]
+        c = float(fn(indexes=idx, momentum=0.0))
+        c_o = rbm_np.cd_step(st, data[idx], PhiloxDraws(9, rbm.stream_id, t), lr=0.1, k=2, batch_size=B,
+                             persistent=True)
+        assert abs(c - c_o) <= 1e-4 * abs(c_o), (t, c, c_o)
+        assert np.array_equal(up.persistent.get_value(), st.persistent.astype(np.float32)), "chain diverged"
+    assert rbm.bit_i_idx == st.bit_i_idx == 4
+    assert np.abs(rbm.W.get_value() - st.W).max() <= 1e-5
+    with pytest.raises(ValueError):                       # ragged minibatch vs fixed chain (rbm.py:416)
+        fn(indexes=np.arange(B - 1), momentum=0.0)
+
+
+def test_empty_and_degenerate_inputs(hip_engine):
+    import mdbn_amd
+    mdbn_amd.DBN.verbose = False
+    rbm = mdbn_amd.RBM(n_visible=12, n_hidden=5, engine=hip_engine)
+    empty = np.zeros((0, 12), dtype=np.float32)
+    pre, mean, sample = rbm.sample_h_given_v(empty)
+    assert pre.shape == mean.shape == sample.shape == (0, 5)
+    assert rbm.free_energy(empty).shape == (0,)
+    dbn = mdbn_amd.DBN(n_ins=12, hidden_layers_sizes=[5], n_outs=3, engine=hip_engine)
+    assert dbn.get_output(empty).shape == (0, 3)
+    with pytest.raises(AssertionError):
+        rbm.sample_h_given_v(np.zeros((3, 11), dtype=np.float32))      # wrong width
+    one = rbm.sample_h_given_v(np.ones((1, 12), dtype=np.float32))     # a single row
+    assert one[1].shape == (1, 5)
