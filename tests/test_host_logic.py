@@ -196,3 +196,49 @@ def test_minibatches_mirror():
     a = get_minibatches_idx(47, 10, shuffle=True, rng=np.random.RandomState(3))
     b = rbm_np.get_minibatches_idx(47, 10, shuffle=True, rng=np.random.RandomState(3))
     assert list(a[0]) == list(b[0]) and all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
+
+
+def test_dbn_training_control_flow_scripted(oracle_engine, monkeypatch):
+    """dbn.py:426-508 with scripted step costs: momentum 0.0 for the Gaussian layer, 0.6 -> 0.9 at
+    epoch 6 for Bernoulli layers; lr per layer; validation every min(20 * n_batches, patience // 2)
+    iterations; patience (an ITERATION budget, dbn.py:440,506) doubled to 2 * iter on a > 0.5 %
+    improvement; stop when patience <= iter."""
+    DBN.verbose = False
+    dbn = DBN(numpy_rng=np.random.RandomState(1), n_ins=6, hidden_layers_sizes=[5], n_outs=3)
+    dbn.shuffle_rng = np.random.RandomState(0)
+    calls = {0: [], 1: []}
+
+    class FakeFn(object):
+        def __init__(self, layer, costs):
+            self.layer, self.costs, self.n = layer, costs, 0
+        def __call__(self, indexes=None, momentum=None, lr=None):
+            calls[self.layer].append((len(indexes), momentum, lr))
+            c = self.costs(self.n)
+            self.n += 1
+            return c
+        def flush(self):
+            pass
+
+    # layer 0: cost improves by 10 % at every validation point -> patience keeps doubling until the
+    # epoch budget ends; layer 1: cost flat -> stops when the initial patience runs out
+    fns = [FakeFn(0, lambda n: 100.0 * 0.9 ** (n // 4)), FakeFn(1, lambda n: 5.0)]
+    monkeypatch.setattr(dbn, "training_functions", lambda **kw: (fns, [dbn.rbm_layers[0].free_energies] * 2))
+    train = np.random.RandomState(0).normal(size=(40, 6))
+    hist = dbn.training(train, batch_size=10, k=1, pretraining_epochs=[8, 8], pretrain_lr=[0.005, 0.1])
+    n_batches = 4
+    # layer 0 (GRBM): validation_frequency = min(80, 8 // 2) = 4; improvements keep it alive for all 8 epochs
+    assert len(calls[0]) == 8 * n_batches
+    assert all(m == 0.0 and lr == 0.005 and n == 10 for n, m, lr in calls[0])
+    assert [r[0] for r in hist[0]] == list(range(3, 32, 4))           # iterations of the validation points
+    # layer 1 (RBM): flat cost -> first validation sets best, no significant improvement afterwards:
+    # patience = max(8, 2 * 3) = 8 after iter 3 ... loop ends when patience <= iter, i.e. at iter 8
+    assert len(calls[1]) == 9
+    assert all(lr == 0.1 for _, _, lr in calls[1])
+    assert [m for _, m, _ in calls[1]] == [0.6] * 9                   # epoch 6 never reached
+    # momentum switch at epoch 6 (dbn.py:452-453) with a budget long enough to get there
+    fns2 = [FakeFn(0, lambda n: 1.0), FakeFn(1, lambda n: 100.0 * 0.9 ** (n // 2))]
+    calls[0].clear(); calls[1].clear()
+    monkeypatch.setattr(dbn, "training_functions", lambda **kw: (fns2, [dbn.rbm_layers[0].free_energies] * 2))
+    dbn.training(train, batch_size=10, k=1, pretraining_epochs=[1, 7], pretrain_lr=[0.005, 0.1])
+    moms = [m for _, m, _ in calls[1]]
+    assert moms[:5 * n_batches] == [0.6] * 20 and set(moms[5 * n_batches:]) == {0.9} and len(moms) == 7 * n_batches
