@@ -56,6 +56,9 @@ typedef struct mdbn_cd_args {
     int32_t      index_is_64; /* 1 = int64 (dbn.py:271), 0 = int32 (rbm.py:528)                  */
     int32_t      gauss;       /* 1 = GRBM (rbm.py:631-699), 0 = Bernoulli RBM                    */
     int32_t      add_noise;   /* GRBM only: 1 = error_free False (rbm.py:652-658)                */
+    int32_t      sample_stats;/* 1 = negative visible statistics from nv_SAMPLE, not nv_mean: the
+                               * chain_end of compute_symbolic_grad (rbm.py:339-342,378-390)      */
+    int32_t      reserved0;
     int32_t      k;           /* Gibbs steps                                                     */
     int64_t      B, V, H;     /* local minibatch rows, n_visible, n_hidden                       */
     int64_t      ldv, ldh;    /* leading dims of [.,V] and [.,H] matrices (W uses ldh)           */

@@ -545,6 +545,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
     REQUIRE(a->hbias && a->vbias, "bias pointers are NULL");
     REQUIRE(a->stats != nullptr && aligned16(a->stats), "stats not aligned");
     REQUIRE(a->gauss || a->vs != nullptr, "Bernoulli RBM needs the vs buffer");
+    REQUIRE(!(a->sample_stats && a->gauss && a->add_noise), "sample statistics of a noisy GRBM are not supported");
     REQUIRE(a->vs == nullptr || aligned16(a->vs), "vs not aligned");
     REQUIRE(a->persistent == nullptr || aligned16(a->persistent), "persistent not aligned");
     REQUIRE(a->indexes != nullptr || B <= a->n_data, "identity minibatch longer than data");
@@ -573,14 +574,18 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         const float* chain = (t == 1 && a->persistent) ? a->persistent : a->hs;   // rbm.py:308-311
         // v_t | h_{t-1}: RBM sigmoid + Bernoulli (rbm.py:229-240); GRBM linear mean (rbm.py:647-660;
         // its noisy sample never feeds the chain, rbm.py:669, so it is not materialised here)
-        Affine down{chain, B, ldh, a->W, V, H, ldh, 1, a->vbias, nullptr, nv, a->gauss ? nullptr : a->vs,
+        // sample_stats (compute_symbolic_grad, rbm.py:339-342,378-390): the negative visible data is
+        // the SAMPLE nv_samples[-1]; it then also is the input of the last propup, as in rbm.py:246
+        const bool samp_stats = last && a->sample_stats && !a->gauss;
+        Affine down{chain, B, ldh, a->W, V, H, ldh, 1, a->vbias, nullptr, samp_stats ? nullptr : nv,
+                    a->gauss ? nullptr : (samp_stats ? nv : a->vs),
                     ldv, 1.0f, a->gauss, last ? v0 : nullptr, ldv, last, &a->rng, (uint32_t)(2 * t - 1)};
-        if (last) { down.colsum = ws.colV; down.colsum_kind = 1; }      // sum_rows (v0 - nv_mean)
+        if (last) { down.colsum = ws.colV; down.colsum_kind = samp_stats ? 2 : 1; }   // sum_rows (v0 - nv)
         CHECK(run_affine(down, ws, s, last ? &n_cost : nullptr));
         // h_t | v_t: from the mean for GRBM (rbm.py:669), from the sample for RBM (rbm.py:246)
         const bool need_sample = !last || a->persistent != nullptr;
         float* hdst = (last && a->persistent) ? a->persistent : a->hs;            // rbm.py:369
-        Affine up{a->gauss ? nv : a->vs, B, ldv, a->W, V, H, ldh, 0, a->hbias, nullptr, nh,
+        Affine up{(a->gauss || samp_stats) ? nv : a->vs, B, ldv, a->W, V, H, ldh, 0, a->hbias, nullptr, nh,
                   need_sample ? hdst : nullptr, ldh, -1.0f, 0, nullptr, 0, false, &a->rng, (uint32_t)(2 * t)};
         if (last) up.colsum = ws.colPneg;                               // sum_rows (-nh_mean)
         CHECK(run_affine(up, ws, s, nullptr));

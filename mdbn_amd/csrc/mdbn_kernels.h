@@ -41,7 +41,7 @@ struct EpiArgs {
     int64_t ld_target;
     float* cost_partials;  // nullable: one float per block
     float* colsum;         // nullable: [ceil(rows/4)][ld] partial column sums over each 4-row group
-    int colsum_kind;       // 0: sum of stored (scaled) mean ; 1: sum of (target - mean)
+    int colsum_kind;       // 0: sum of stored (scaled) mean ; 1: sum of (target - mean) ; 2: sum of (target - sample)
     PhiloxKey rng;
 };
 

@@ -472,7 +472,8 @@ __device__ __forceinline__ void setc(float4& v, int j, float x)
 //              (sigmoid(mean) - target)^2 (rbm.py:697), one partial per block.
 //   colsum != NULL: per-thread partial of the bias statistics (rbm.py:416-417) over the
 //              thread's 4 rows: colsum_kind 0 = sum of the stored (scaled) mean,
-//              1 = sum of (target - mean); written to colsum[row_group][col].
+//              1 = sum of (target - mean), 2 = sum of (target - sample); written to
+//              colsum[row_group][col].
 // One thread = 4 rows x CW columns (CW = 4, 2 or 1: float4 / float2 / float traffic), one
 // Philox block per column.  The kernel is latency-bound (one wave of blocks, slabs resident in
 // L2 / Infinity Cache), so narrower threads = more of them = shorter serial chain per thread.
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
                 const float ms = m * e.mean_scale;
                 mean[j] = ms;
                 samp[j] = sv;
-                if (live) csum[j] += e.colsum_kind ? tgt[j] - m : ms;
+                if (live) csum[j] += e.colsum_kind == 0 ? ms : (e.colsum_kind == 1 ? tgt[j] - m : tgt[j] - sv);
             }
             if (e.pre) VecIO<CW>::store(e.pre + off, pre[r]);
             if (e.mean) VecIO<CW>::store(e.mean + off, mean);

@@ -268,7 +268,8 @@ class HipEngine(object):
         return out
 
     # ------------------------------------------------------------------ CD-k
-    def _cd_args(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent, add_noise, stats_slot):
+    def _cd_args(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent, add_noise, stats_slot,
+                 sample_stats=False):
         data = self.as_matrix(data)
         V, H = W.shape
         assert data.shape[1] == V, "data has %d columns, RBM has %d visibles" % (data.shape[1], V)
@@ -285,6 +286,7 @@ class HipEngine(object):
         a.indexes = idx.data_ptr() if idx is not None else None
         a.index_is_64 = int(idx is not None and idx.dtype == torch.int64)
         a.gauss, a.add_noise, a.k = int(bool(gauss)), int(bool(add_noise)), int(k)
+        a.sample_stats = int(bool(sample_stats))
         a.B, a.V, a.H = B, V, H
         a.ldv, a.ldh = ldv, ldh
         a.W, a.hbias, a.vbias = W.data_ptr(), hbias.data_ptr(), vbias.data_ptr()
@@ -297,12 +299,12 @@ class HipEngine(object):
         return a, stats, sc, (data, idx, ws)        # keep the tensors alive until enqueued
 
     def cd_step(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent=None, add_noise=False,
-                stats_slot=0):
+                stats_slot=0, sample_stats=False):
         """gather + positive phase + k Gibbs steps + statistics (rbm.py:303-345,374).
         Returns (stats, scratch): the packed [S | s_h | s_v | cost_sum] buffer and the
         CDScratch holding ph_mean / nv_mean / nh_mean for inspection."""
         a, stats, sc, _keep = self._cd_args(data, indexes, W, hbias, vbias, gauss, k, rng, persistent,
-                                            add_noise, stats_slot)
+                                            add_noise, stats_slot, sample_stats)
         _lib.check(self.lib.mdbn_cd_step(self.ctx, self._stream(), C.byref(a)), "mdbn_cd_step")
         return stats, sc
 
@@ -327,11 +329,13 @@ class HipEngine(object):
         return u, cost
 
     def cd_train_step(self, data, indexes, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, gauss, k,
-                      rng, lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale):
+                      rng, lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale,
+                      sample_stats=False):
         """The whole single-device step function (mdbn_cd_train_step): cd_step + update, with the
         finalize / parameter half of the update overlapped under the statistics GEMM.  Returns the
         monitoring cost (0-d device tensor)."""
-        a, stats, sc, _keep = self._cd_args(data, indexes, W, hbias, vbias, gauss, k, rng, None, False, 0)
+        a, stats, sc, _keep = self._cd_args(data, indexes, W, hbias, vbias, gauss, k, rng, None, False, 0,
+                                            sample_stats)
         u, cost = self._update_args(W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats, lr,
                                     lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale,
                                     0, a.ldv)

@@ -43,10 +43,14 @@ class UpdatePlan(object):
     """The ``updates`` dictionary of rbm.py:353-371 in closed form: everything one
     CD-k / PCD-k step needs, bound when ``get_cost_updates`` is called."""
 
-    def __init__(self, rbm, lr, k, lambda_1, lambda_2, weightcost, batch_size, persistent, W0):
+    def __init__(self, rbm, lr, k, lambda_1, lambda_2, weightcost, batch_size, persistent, W0,
+                 symbolic_grad=False):
         self.rbm, self.lr, self.k = rbm, lr, int(k)
         self.lambda_1, self.lambda_2, self.weightcost = lambda_1, lambda_2, weightcost
         self.batch_size, self.persistent, self.W0 = batch_size, persistent, W0
+        # compute_symbolic_grad (rbm.py:378-390): negative data = nv_samples[-1], no weight-cost
+        # term, true means (the batch_size argument is not used)
+        self.symbolic_grad = bool(symbolic_grad)
 
 
 class LazyCost(object):
@@ -144,7 +148,7 @@ class StepFunction(object):
             raise TypeError("step function needs lr= (learning rate is a symbolic input)")
         data = self._data()
         n_global = data.shape[0] if indexes is None else len(indexes)
-        batch_size = p.batch_size if p.batch_size is not None else n_global
+        batch_size = p.batch_size if (p.batch_size is not None and not p.symbolic_grad) else n_global
         distributed = self.group is not None and self.group.world_size > 1
 
         # data-parallel shard of the minibatch: contiguous rows [lo, hi) of `indexes`
@@ -175,7 +179,7 @@ class StepFunction(object):
                                     rbm.vbias_speed.tensor, rbm.gauss, p.k,
                                     RngAddr(rbm.theano_rng.seed, rbm.stream_id, step, 0, lo),
                                     lr, p.lambda_1, p.lambda_2, p.weightcost, momentum, batch_size,
-                                    n_global, cost_scale)
+                                    n_global, cost_scale, sample_stats=p.symbolic_grad)
             rbm._n_updates += 1
             return out
         slot = self._n_calls & 1 if self.overlap else 0     # the other buffer may still be reducing
@@ -184,7 +188,7 @@ class StepFunction(object):
             stats, _ = eng.cd_step(data, idx, rbm.W.tensor, rbm.hbias.tensor, rbm.vbias.tensor,
                                    rbm.gauss, p.k,
                                    RngAddr(rbm.theano_rng.seed, rbm.stream_id, step, 0, lo),
-                                   persistent=persistent, stats_slot=slot)
+                                   persistent=persistent, stats_slot=slot, sample_stats=p.symbolic_grad)
         else:                                  # this rank holds no row of a short minibatch
             stats = eng.stats_buffer(rbm.n_visible, rbm.n_hidden, slot, data.stride(0), rbm.W.tensor.stride(0))
             stats.zero_()
@@ -361,10 +365,10 @@ class RBM(object):
 
         ``lr`` may be a float or a ``Scalar`` (then the step function takes ``lr=``).
         ``persistent``: None for CD, a SharedArray [batch_size, n_hidden] for PCD."""
+        if symbolic_grad and self.gauss and not getattr(self, "error_free", True):
+            raise NotImplementedError("symbolic_grad with a noisy GRBM (error_free=False) is not supported")
         if symbolic_grad:
-            raise NotImplementedError(
-                "symbolic_grad=True (rbm.py:378-390) is never selected by the reference's callers "
-                "and has no device kernel; the RBM-specific gradient (rbm.py:392-419) is used")
+            weightcost = 0.0           # tensor.grad of the free-energy difference has no such term
         W0 = None
         if weightcost != 0.0 and self.strict_reference:
             # rbm.py:415; same padded layout as W (a plain clone() would drop the leading dimension)
@@ -377,7 +381,8 @@ class RBM(object):
                 t = self.engine.alloc_matrix(persistent.shape[0], persistent.shape[1], self.W.tensor.stride(0))
                 t.copy_(persistent.tensor)
                 persistent.tensor = t
-        updates = UpdatePlan(self, lr, k, lambda_1, lambda_2, weightcost, batch_size, persistent, W0)
+        updates = UpdatePlan(self, lr, k, lambda_1, lambda_2, weightcost, batch_size, persistent, W0,
+                             symbolic_grad=symbolic_grad)
         cost = CostHandle('pseudo_likelihood' if persistent is not None else 'reconstruction')
         return cost, updates
 

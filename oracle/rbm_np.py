@@ -223,7 +223,7 @@ def apply_update(s, g_W, g_hb, g_vb, lr, lambda_1, lambda_2, momentum):
 
 def cd_step(s, v0, draws, lr=0.1, k=1, lambda_1=0.0, lambda_2=0.0, weightcost=0.0,
             batch_size=None, momentum=0.0, persistent=False, strict_reference=True,
-            return_extras=False):
+            return_extras=False, symbolic_grad=False):
     """One call of the compiled step function of rbm.py:258-376 (get_cost_updates +
     theano.function with updates): mutates ``s`` and returns the monitoring cost.
 
@@ -235,9 +235,15 @@ def cd_step(s, v0, draws, lr=0.1, k=1, lambda_1=0.0, lambda_2=0.0, weightcost=0.
     chain0 = s.persistent if persistent else None
     ph_mean, ph_sample, out = cd_chain(s, v0, draws, k, chain0)
     pre_nv, nv_mean, nv_sample, pre_nh, nh_mean, nh_sample = out
-    S, s_h, s_v = cd_statistics(v0, ph_mean, nv_mean, nh_mean)
-    g_W, g_hb, g_vb = rbm_grad(s, S, s_h, s_v, batch_size, v0.shape[0], weightcost,
-                               strict_reference)
+    if symbolic_grad:
+        # rbm.py:341-342,378-390: gradient of mean F(chain_end) - mean F(input) with
+        # chain_end = nv_samples[-1] held constant; no weight-cost term, true means.
+        g_W, g_hb, g_vb = symbolic_grad_fn(s, v0, nv_sample)
+        S, s_h, s_v = cd_statistics(v0, ph_mean, nv_sample, propup(s, nv_sample)[1])
+    else:
+        S, s_h, s_v = cd_statistics(v0, ph_mean, nv_mean, nh_mean)
+        g_W, g_hb, g_vb = rbm_grad(s, S, s_h, s_v, batch_size, v0.shape[0], weightcost,
+                                   strict_reference)
     if persistent:
         cost = pseudo_likelihood_cost(s, v0)                             # :371 (pre-update params)
     else:
@@ -254,7 +260,7 @@ def cd_step(s, v0, draws, lr=0.1, k=1, lambda_1=0.0, lambda_2=0.0, weightcost=0.
     return cost
 
 
-def symbolic_grad(s, v0, chain_end):
+def symbolic_grad_fn(s, v0, chain_end):
     """rbm.py:378-390: d/dtheta [mean F(chain_end) - mean F(input)], chain_end constant.
     Closed form, used only as a cross-check of rbm_grad."""
     def dF(v):
@@ -293,3 +299,6 @@ def mlp_forward(W_list, b_list, x, layer=-1):
     for l in range(last + 1):
         out = sigmoid(out @ W_list[l] + b_list[l])
     return out
+
+
+symbolic_grad = symbolic_grad_fn      # name used by the cross-check tests

@@ -113,7 +113,7 @@ class OracleEngine(object):
 
     # --- CD-k
     def cd_step(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent=None, add_noise=False,
-                stats_slot=0):
+                stats_slot=0, sample_stats=False):
         data = self.as_matrix(data)
         v0 = (data if indexes is None else data[self.index_tensor(indexes)]).numpy()
         s = self._state(W, hbias, vbias, gauss)
@@ -121,6 +121,8 @@ class OracleEngine(object):
         chain0 = persistent.numpy().copy() if persistent is not None else None
         ph_mean, ph_sample, out = rbm_np.cd_chain(s, v0, draws, k, chain0)
         pre_nv, nv_mean, nv_sample, pre_nh, nh_mean, nh_sample = out
+        if sample_stats:      # compute_symbolic_grad: chain_end = nv_samples[-1] (rbm.py:339-342)
+            nv_mean, nh_mean = nv_sample, rbm_np.propup(s, nv_sample)[1]
         S, s_h, s_v = rbm_np.cd_statistics(v0, ph_mean, nv_mean, nh_mean)
         if gauss:
             cost = ((rbm_np.sigmoid(pre_nv) - v0) ** 2).sum()
@@ -156,8 +158,9 @@ class OracleEngine(object):
         return torch.tensor(float(st[V * H + H + V]) * cost_scale, dtype=self.t_dtype)
 
     def cd_train_step(self, data, indexes, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, gauss, k,
-                      rng, lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale):
-        stats, _ = self.cd_step(data, indexes, W, hbias, vbias, gauss, k, rng)
+                      rng, lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale,
+                      sample_stats=False):
+        stats, _ = self.cd_step(data, indexes, W, hbias, vbias, gauss, k, rng, sample_stats=sample_stats)
         return self.apply_update(W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats, lr, lambda_1,
                                  lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale)
 

@@ -494,3 +494,27 @@ def test_empty_and_degenerate_inputs(hip_engine):
         rbm.sample_h_given_v(np.zeros((3, 11), dtype=np.float32))      # wrong width
     one = rbm.sample_h_given_v(np.ones((1, 12), dtype=np.float32))     # a single row
     assert one[1].shape == (1, 5)
+
+
+@pytest.mark.parametrize("gauss", [False, True])
+def test_symbolic_grad_on_device(hip_engine, gauss):
+    """compute_symbolic_grad path (rbm.py:378-390) through the C-ABI: sample statistics."""
+    import mdbn_amd
+    V, H, B, N = 130, 70, 24, 96
+    rs = np.random.RandomState(3)
+    data = rs.normal(size=(N, V)).astype(np.float32) if gauss else (rs.uniform(size=(N, V)) < 0.4).astype(np.float32)
+    cls = mdbn_amd.GRBM if gauss else mdbn_amd.RBM
+    rbm = cls(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(1), theano_rng=mdbn_amd.RandomStreams(21),
+              engine=hip_engine)
+    st = rbm_np.RBMState(V, H, W=rbm.W.get_value(), gauss=gauss)
+    _, up = rbm.get_cost_updates(lr=0.01, k=2, batch_size=B, symbolic_grad=True)
+    fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=hip_engine), data_parallel=None)
+    for t in range(3):
+        idx = rs.permutation(N)[:B]
+        c = float(fn(indexes=idx, momentum=0.5))
+        c_o = rbm_np.cd_step(st, data[idx], PhiloxDraws(21, rbm.stream_id, t), lr=0.01, k=2, momentum=0.5,
+                             symbolic_grad=True)
+        assert abs(c - c_o) <= 1e-4 * abs(c_o)
+    for name in ("W", "W_speed", "hbias_speed", "vbias_speed"):
+        got, want = getattr(rbm, name).get_value(), getattr(st, name)
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), name

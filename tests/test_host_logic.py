@@ -87,8 +87,9 @@ def test_step_function_needs_lr_when_symbolic(oracle_engine):
     with pytest.raises(TypeError):
         fn(indexes=np.arange(3))
     fn(indexes=np.arange(3), momentum=0.0, lr=0.01)
+    noisy = GRBM(n_visible=6, n_hidden=4, error_free=False)
     with pytest.raises(NotImplementedError):
-        rbm.get_cost_updates(0.1, symbolic_grad=True)
+        noisy.get_cost_updates(0.1, symbolic_grad=True)
 
 
 def test_eager_sampling_api(oracle_engine):
@@ -242,3 +243,25 @@ def test_dbn_training_control_flow_scripted(oracle_engine, monkeypatch):
     dbn.training(train, batch_size=10, k=1, pretraining_epochs=[1, 7], pretrain_lr=[0.005, 0.1])
     moms = [m for _, m, _ in calls[1]]
     assert moms[:5 * n_batches] == [0.6] * 20 and set(moms[5 * n_batches:]) == {0.9} and len(moms) == 7 * n_batches
+
+
+@pytest.mark.parametrize("cls", [RBM, GRBM])
+def test_symbolic_grad_step(oracle_engine, cls):
+    """symbolic_grad=True (rbm.py:341-342,378-390): negative data = the chain's last visible SAMPLE,
+    no weight cost, true means -- step function vs the oracle's closed-form free-energy gradient."""
+    V, H, N, B = 10, 6, 24, 8
+    rs = np.random.RandomState(0)
+    data = rs.normal(size=(N, V)) if cls is GRBM else (rs.uniform(size=(N, V)) < 0.4).astype(np.float64)
+    rbm = cls(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(5), theano_rng=RandomStreams(99))
+    st = rbm_np.RBMState(V, H, W=rbm.W.tensor.numpy(), gauss=rbm.gauss)
+    _, updates = rbm.get_cost_updates(lr=0.05, k=2, weightcost=0.3, batch_size=1000, symbolic_grad=True)
+    fn = function(updates, shared(data))
+    idx = np.array([3, 1, 17, 9, 23, 0, 4, 12])
+    for step in range(3):
+        got = float(fn(indexes=idx, momentum=0.6))
+        want = rbm_np.cd_step(st, data[idx], PhiloxDraws(99, rbm.stream_id, step), lr=0.05, k=2,
+                              momentum=0.6, symbolic_grad=True)
+        assert abs(got - want) < 1e-9
+    np.testing.assert_allclose(rbm.W.tensor.numpy(), st.W, rtol=1e-12)
+    np.testing.assert_allclose(rbm.W_speed.tensor.numpy(), st.W_speed, rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(rbm.vbias_speed.tensor.numpy(), st.vbias_speed, rtol=1e-11, atol=1e-14)
