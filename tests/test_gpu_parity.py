@@ -518,3 +518,30 @@ def test_symbolic_grad_on_device(hip_engine, gauss):
     for name in ("W", "W_speed", "hbias_speed", "vbias_speed"):
         got, want = getattr(rbm, name).get_value(), getattr(st, name)
         assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), name
+
+
+def test_many_rows_gather_and_forward(hip_engine):
+    """More rows than one grid dimension holds (65 535): chunked gather (indexed and identity)
+    and a forward pass / free energy over 70 001 rows."""
+    import mdbn_amd
+    e = hip_engine
+    N, V, H = 70001, 12, 20
+    rs = np.random.RandomState(0)
+    x = rs.normal(size=(N, V)).astype(np.float32)
+    sx = mdbn_amd.shared(x, engine=e)
+    idx = rs.permutation(N).astype(np.int64)
+    got = sx[idx].get_value()
+    assert np.array_equal(got, x[idx])
+    assert np.array_equal(sx[idx.astype(np.int32)[:66000]].get_value(), x[idx[:66000]])
+    W, hb, vb, _ = make(V, H, 1, True, seed=1)
+    rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, W=W, hbias=hb, vbias=vb, engine=e)
+    mean = np.asarray(rbm.propup(sx)[1])
+    s = state64(W, hb, vb, True)
+    assert np.abs(mean - rbm_np.propup(s, x.astype(np.float64))[1]).max() <= 2e-6
+    F = rbm.free_energy(sx).get_value()
+    assert np.abs(F - rbm_np.free_energy(s, x.astype(np.float64))).max() <= 1e-4
+    # identity minibatch (indexes=None) over all rows through the step function
+    _, up = rbm.get_cost_updates(lr=1e-4, k=1, lambda_2=0.1)
+    c = float(mdbn_amd.function(up, sx, data_parallel=None)())
+    c_o = rbm_np.cd_step(s, x, PhiloxDraws(rbm.theano_rng.seed, rbm.stream_id, 0), lr=1e-4, k=1, lambda_2=0.1)
+    assert abs(c - c_o) <= 1e-4 * abs(c_o)
