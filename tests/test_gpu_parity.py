@@ -545,3 +545,30 @@ def test_many_rows_gather_and_forward(hip_engine):
     c = float(mdbn_amd.function(up, sx, data_parallel=None)())
     c_o = rbm_np.cd_step(s, x, PhiloxDraws(rbm.theano_rng.seed, rbm.stream_id, 0), lr=1e-4, k=1, lambda_2=0.1)
     assert abs(c - c_o) <= 1e-4 * abs(c_o)
+
+
+def test_bitwise_determinism_and_race_screen(hip_engine):
+    """No atomics anywhere, fixed summation orders: the same 30 steps run three times give
+    bit-identical parameters (also a race screen for the producer / consumer GEMM, whose LDS
+    double buffer would show up here as run-to-run differences).  Both headline-sized and ragged."""
+    import mdbn_amd
+    for V, H, B, k, gauss in ((4096, 1024, 512, 1, True), (777, 333, 50, 2, False)):
+        rs = np.random.RandomState(1)
+        N = 4 * B
+        data = rs.normal(size=(N, V)).astype(np.float32) if gauss else (rs.uniform(size=(N, V)) < 0.3).astype(np.float32)
+        sx = mdbn_amd.shared(data, engine=hip_engine)
+        finals = []
+        for rep in range(3):
+            cls = mdbn_amd.GRBM if gauss else mdbn_amd.RBM
+            rbm = cls(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123), theano_rng=mdbn_amd.RandomStreams(5),
+                      engine=hip_engine)
+            hp = dict(lr=0.001, lambda_2=0.1) if gauss else dict(lr=0.05, weightcost=2e-4)
+            _, up = rbm.get_cost_updates(k=k, batch_size=B, **hp)
+            fn = mdbn_amd.function(up, sx, data_parallel=None)
+            perm = np.random.RandomState(2).permutation(N)
+            costs = [float(fn(indexes=perm[(t % 4) * B:(t % 4 + 1) * B], momentum=0.5)) for t in range(30)]
+            finals.append((rbm.W.get_value(), rbm.W_speed.get_value(), rbm.vbias.get_value(), costs))
+        for other in finals[1:]:
+            assert np.array_equal(finals[0][0], other[0]) and np.array_equal(finals[0][1], other[1])
+            assert np.array_equal(finals[0][2], other[2]) and finals[0][3] == other[3]
+        assert np.isfinite(finals[0][0]).all()
