@@ -64,6 +64,9 @@ static int g_opt_gemm_bk = 0;          // mdbn_set_option("gemm_bk"): 0 = auto, 
 // stream under the statistics GEMM.  Measured (profile r01j): the fork/join events cost more than
 // the ~12 us they hide (278.7 vs 259.6 us per step), so it is off by default.
 static int g_opt_update_overlap = 0;
+// mdbn_set_option("fused_epilogue"): apply the activation epilogue on the MFMA accumulators when a
+// GEMM needs no split-K (default on)
+static int g_opt_fused_epilogue = 1;
 constexpr int kTargetJobs = 256;       // one 8-wave tile job per CU (MI355X: 256 CUs)
 constexpr int kMinSplitK = 128;        // >= 4 slices of BK = 32 per split
 
@@ -231,8 +234,13 @@ int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_
     while (r0 < a.rows) {
         int64_t R = a.rows - r0;
         Plan p = plan_gemm(R, Ndim, Kdim);
-        while (p.slab_floats(R, a.ldo) > ws.slab_floats) {
-            if (R <= 4) return fail(MDBN_ENOSPC, "workspace cannot hold one 4-row slab");
+        bool fuse = false;
+        for (;;) {      // shrink the chunk until its slabs (unfused) and cost partials fit
+            fuse = g_opt_fused_epilogue && p.splitk == 1;
+            const bool slabs_fit = fuse || p.slab_floats(R, a.ldo) <= ws.slab_floats;
+            const int64_t need_cost = !a.want_cost ? 0 : fuse ? (int64_t)p.tiles_m * p.tiles_n : epilogue_blocks(R, a.ldo);
+            if (slabs_fit && n_cost + need_cost <= ws.cost_floats) break;
+            if (R <= 4) return fail(MDBN_ENOSPC, "workspace cannot hold one 4-row chunk");
             R = std::max<int64_t>(4, (R / 2 + 3) & ~int64_t(3));
             p = plan_gemm(R, Ndim, Kdim);
         }
@@ -243,7 +251,7 @@ int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_
         g.slab_stride = R * a.ldo;
         g.M = (int)R; g.N = (int)Ndim; g.K = (int)Kdim; g.Nst = (int)a.ldo;
         p.fill(g);
-        HIP_OK(timed_gemm(LAY_K, a.dir == 0 ? LAY_MN : LAY_K, g, s));
+        g.fused = 0;
 
         EpiArgs e;
         e.slabs = ws.slabs; e.slab_stride = g.slab_stride; e.nsplit = p.splitk;
@@ -255,9 +263,9 @@ int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_
         e.mean_scale = a.mean_scale; e.gauss = a.gauss;
         e.target = a.target ? a.target + r0 * a.ld_target : nullptr;
         e.ld_target = a.ld_target;
-        const int nb = epilogue_blocks(R, a.ldo);
         e.colsum = a.colsum ? a.colsum + (r0 / 4) * a.ldo : nullptr;
         e.colsum_kind = a.colsum_kind;
+        const int nb = fuse ? p.tiles_m * p.tiles_n : epilogue_blocks(R, a.ldo);
         e.cost_partials = nullptr;
         if (a.want_cost) {
             if (n_cost + nb > ws.cost_floats) return fail(MDBN_ENOSPC, "cost scratch exhausted");
@@ -269,7 +277,14 @@ int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_
         const mdbn_rng& rr = a.rng ? *a.rng : zero;
         e.rng = make_key(rr, a.draw);
         e.rng.row_offset = rr.row_offset + (uint64_t)r0;
-        HIP_OK(launch_act_epilogue(e, s));
+        if (fuse) {                 // activation on the accumulators: no slabs, one launch
+            g.fused = 1;
+            g.epi = e;
+            HIP_OK(timed_gemm(LAY_K, a.dir == 0 ? LAY_MN : LAY_K, g, s));
+        } else {
+            HIP_OK(timed_gemm(LAY_K, a.dir == 0 ? LAY_MN : LAY_K, g, s));
+            HIP_OK(launch_act_epilogue(e, s));
+        }
         r0 += R;
     }
     if (n_cost_out) *n_cost_out = n_cost;
@@ -343,6 +358,10 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "epilogue_cw") == 0) {
         REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "epilogue_cw must be 0 (auto), 1, 2 or 4");
         set_epilogue_cw((int)value);
+        return MDBN_OK;
+    }
+    if (strcmp(name, "fused_epilogue") == 0) {
+        g_opt_fused_epilogue = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "update_overlap") == 0) {
@@ -493,6 +512,7 @@ int mdbn_cd_stats(mdbn_ctx* ctx, void* stream, const float* V2, const float* P2,
     g.ldc = ldh; g.slab_stride = V * ldh;
     g.M = (int)V; g.N = (int)H; g.K = (int)(2 * B); g.Nst = (int)ldh;
     p.fill(g);
+    g.fused = 0;
     if (p.splitk == 1) {
         g.C = S;
         HIP_OK(timed_gemm(LAY_MN, LAY_MN, g, s));
@@ -631,6 +651,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
     g.ldc = ldh; g.slab_stride = V * ldh;
     g.M = (int)V; g.N = (int)H; g.K = (int)(2 * B); g.Nst = (int)ldh;
     p.fill(g);
+    g.fused = 0;
     if (p.splitk == 1) {
         g.C = S;
         HIP_OK(timed_gemm(LAY_MN, LAY_MN, g, s));
@@ -689,6 +710,7 @@ int mdbn_free_energy(mdbn_ctx* ctx, void* stream, const float* x, int64_t N, int
         g.slab_stride = R * ldh;
         g.M = (int)R; g.N = (int)H; g.K = (int)V; g.Nst = (int)ldh;
         p.fill(g);
+        g.fused = 0;
         HIP_OK(timed_gemm(LAY_K, LAY_MN, g, s));
         HIP_OK(launch_free_energy(ws.slabs, p.splitk, g.slab_stride, ldh, (int)H, hbias, x + r0 * ldv, ldv,
                                   (int)V, vbias, gauss, R, out + r0, s));

@@ -9,22 +9,6 @@ namespace mdbn {
 
 enum { LAY_K = 0, LAY_MN = 1 };   // operand's fastest dimension: reduction index / output index
 
-struct GemmArgs {
-    const float* A;        // LAY_K: [M][lda] ; LAY_MN: [K][lda]
-    const float* B;        // LAY_K: [N][ldb] ; LAY_MN: [K][ldb]
-    float* C;              // slabs: [splitk][M][ldc]
-    int64_t lda, ldb, ldc;
-    int64_t slab_stride;   // floats between consecutive split-K slabs
-    int M, N, K;           // logical extents (loads beyond them read as zero)
-    int Nst;               // columns stored (>= N; pad columns receive exact zeros)
-    int kchunk;            // reduction extent per split, multiple of 32
-    int splitk, tiles_m, tiles_n;
-    int bn;                // block tile is 128 x bn (128 or 64)
-    int bk;                // slice depth along the reduction index (32 or 64; 64 only with bn = 128)
-    int inner_m;           // work-list order inside one split: 1 = tile_m fastest
-    unsigned long long* stamps;   // diagnostic builds only (-DMDBN_STAMP); NULL otherwise
-};
-
 struct EpiArgs {
     const float* slabs;
     int64_t slab_stride;
@@ -44,6 +28,26 @@ struct EpiArgs {
     int colsum_kind;       // 0: sum of stored (scaled) mean ; 1: sum of (target - mean) ; 2: sum of (target - sample)
     PhiloxKey rng;
 };
+
+struct GemmArgs {
+    const float* A;        // LAY_K: [M][lda] ; LAY_MN: [K][lda]
+    const float* B;        // LAY_K: [N][ldb] ; LAY_MN: [K][ldb]
+    float* C;              // slabs: [splitk][M][ldc]
+    int64_t lda, ldb, ldc;
+    int64_t slab_stride;   // floats between consecutive split-K slabs
+    int M, N, K;           // logical extents (loads beyond them read as zero)
+    int Nst;               // columns stored (>= N; pad columns receive exact zeros)
+    int kchunk;            // reduction extent per split, multiple of 32
+    int splitk, tiles_m, tiles_n;
+    int bn;                // block tile is 128 x bn (128 or 64)
+    int bk;                // slice depth along the reduction index (32 or 64; 64 only with bn = 128)
+    int inner_m;           // work-list order inside one split: 1 = tile_m fastest
+    unsigned long long* stamps;   // diagnostic builds only (-DMDBN_STAMP); NULL otherwise
+    int fused;             // 1: no split-K and the activation epilogue runs on the accumulators
+    EpiArgs epi;           // ... with these arguments (slabs / nsplit unused; one cost partial per block)
+};
+
+
 
 // blocks (= cost partials) the activation epilogue launches for a [rows, ld] output
 int epilogue_blocks(int64_t rows, int64_t ld);

@@ -166,6 +166,9 @@ __device__ __forceinline__ float frag(const float* __restrict__ T, int mn, int k
 // slice next to a partner wave's MFMAs and the matrix pipe idled 26-38% of the time.)
 // ----------------------------------------------------------------------------------
 constexpr int GEMM_THREADS = 512;
+
+template <int BM, int BN>
+__device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, int m0, int n0);
 #ifndef ABLATE_STORE
 #define ABLATE_STORE 0    // diagnostic builds only: timing ablations of the producer
 #endif
@@ -295,7 +298,7 @@ __device__ __forceinline__ void gemm_consume(const GemmArgs& g, const float* __r
     }
 }
 
-template <int LA, int LB, int MI, int NI, int KB>
+template <int LA, int LB, int MI, int NI, int KB, bool FUSED>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
 {
     constexpr int BM = 64 * MI, BN = 64 * NI;
@@ -325,41 +328,60 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
         const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (kbeg + nt * KB <= g.K);
         if (interior) gemm_produce<LA, LB, MI, NI, KB, false>(g, smem, m0, n0, kbeg, kend, nt);
         else gemm_produce<LA, LB, MI, NI, KB, true>(g, smem, m0, n0, kbeg, kend, nt);
-        return;
-    }
+        if constexpr (!FUSED) return;
+        __builtin_amdgcn_s_setprio(0);
+    } else {
+        const int lane = threadIdx.x & 63;
+        const int i = lane & 31, h = lane >> 5;
+        const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * (32 * NI);
+        f32x16 acc[MI][NI];
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    const int lane = threadIdx.x & 63;
-    const int i = lane & 31, h = lane >> 5;
-    const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * (32 * NI);
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int a = 0; a < MI; ++a)
-#pragma unroll
-        for (int b = 0; b < NI; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-    gemm_consume<LA, LB, MI, NI, KB>(g, smem, acc, nt, wm, wn, i, h);
+        gemm_consume<LA, LB, MI, NI, KB>(g, smem, acc, nt, wm, wn, i, h);
 #if MFMA_AGPR
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA result -> v_accvgpr_read hazard (asm is opaque to hipcc)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA result -> v_accvgpr_read hazard (asm is opaque to hipcc)
 #endif
 
-    // accumulator (32x32): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-    float* C = g.C + (int64_t)ks * g.slab_stride;
+        // accumulator (32x32): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+        if constexpr (FUSED) {
+            // Park the tile in LDS (every read of the last slice ended at the loop's final barrier).
+            // Row stride BN + 8: lanes 32..63 (rows + 4) land 32 banks away from lanes 0..31.
+            constexpr int LDT = BN + 8;
 #pragma unroll
-    for (int a = 0; a < MI; ++a)
+            for (int a = 0; a < MI; ++a)
 #pragma unroll
-        for (int b = 0; b < NI; ++b) {
-            const int col = n0 + wn + 32 * b + i;
+                for (int b = 0; b < NI; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < g.M && col < g.Nst) C[(int64_t)row * g.ldc + col] = acc[a][b][e];
-            }
+                    for (int e = 0; e < 16; ++e)
+                        smem[(wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h) * LDT + wn + 32 * b + i] = acc[a][b][e];
+        } else {
+            float* C = g.C + (int64_t)ks * g.slab_stride;
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int b = 0; b < NI; ++b) {
+                    const int col = n0 + wn + 32 * b + i;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = m0 + wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (row < g.M && col < g.Nst) C[(int64_t)row * g.ldc + col] = acc[a][b][e];
+                    }
+                }
+            return;
         }
+    }
+    if constexpr (FUSED) {      // all 8 waves: bias + activation + sampling + cost / column partials
+        __syncthreads();
+        fused_tile_epilogue<BM, BN>(g.epi, smem, m0, n0);
+    }
 }
 
-template <int LA, int LB, int MI, int NI, int KB>
+template <int LA, int LB, int MI, int NI, int KB, bool FUSED>
 static hipError_t launch_gemm_t(const GemmArgs& g, hipStream_t s)
 {
     // The LDS request is padded past half of the CU's 160 KiB so that exactly one 8-wave
@@ -367,7 +389,7 @@ static hipError_t launch_gemm_t(const GemmArgs& g, hipStream_t s)
     constexpr int need_bytes = 2 * (64 * MI + 64 * NI) * (KB + 1) * (int)sizeof(float);
     constexpr int lds_bytes = need_bytes > 84 * 1024 ? need_bytes : 84 * 1024;
     static bool attr_set = false;
-    auto kern = gemm_splitk_kernel<LA, LB, MI, NI, KB>;
+    auto kern = gemm_splitk_kernel<LA, LB, MI, NI, KB, FUSED>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -379,20 +401,27 @@ static hipError_t launch_gemm_t(const GemmArgs& g, hipStream_t s)
     return hipGetLastError();
 }
 
-template <int LA, int LB>
+template <int LA, int LB, bool FUSED>
 static hipError_t launch_gemm_l(const GemmArgs& g, hipStream_t s)
 {
-    if (g.bn == 128 && g.bk == 64) return launch_gemm_t<LA, LB, 2, 2, 64>(g, s);
-    if (g.bn == 128 && g.bk == 32) return launch_gemm_t<LA, LB, 2, 2, 32>(g, s);
-    if (g.bn == 64 && g.bk == 32) return launch_gemm_t<LA, LB, 2, 1, 32>(g, s);
+    if (g.bn == 128 && g.bk == 64) return launch_gemm_t<LA, LB, 2, 2, 64, FUSED>(g, s);
+    if (g.bn == 128 && g.bk == 32) return launch_gemm_t<LA, LB, 2, 2, 32, FUSED>(g, s);
+    if (g.bn == 64 && g.bk == 32) return launch_gemm_t<LA, LB, 2, 1, 32, FUSED>(g, s);
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_gemm(int la, int lb, const GemmArgs& g, hipStream_t s)
 {
-    if (la == LAY_K && lb == LAY_MN) return launch_gemm_l<LAY_K, LAY_MN>(g, s);
-    if (la == LAY_K && lb == LAY_K) return launch_gemm_l<LAY_K, LAY_K>(g, s);
-    if (la == LAY_MN && lb == LAY_MN) return launch_gemm_l<LAY_MN, LAY_MN>(g, s);
+    if (g.fused) {      // only the two forward-pass operand layouts ever fuse (separate instantiations:
+                        // the unfused kernels keep their register allocation)
+        if (g.splitk != 1) return hipErrorInvalidValue;
+        if (la == LAY_K && lb == LAY_MN) return launch_gemm_l<LAY_K, LAY_MN, true>(g, s);
+        if (la == LAY_K && lb == LAY_K) return launch_gemm_l<LAY_K, LAY_K, true>(g, s);
+        return hipErrorInvalidValue;
+    }
+    if (la == LAY_K && lb == LAY_MN) return launch_gemm_l<LAY_K, LAY_MN, false>(g, s);
+    if (la == LAY_K && lb == LAY_K) return launch_gemm_l<LAY_K, LAY_K, false>(g, s);
+    if (la == LAY_MN && lb == LAY_MN) return launch_gemm_l<LAY_MN, LAY_MN, false>(g, s);
     return hipErrorInvalidValue;
 }
 
@@ -461,6 +490,74 @@ __device__ __forceinline__ float comp(const float4& v, int j)
 __device__ __forceinline__ void setc(float4& v, int j, float x)
 {
     if (j == 0) v.x = x; else if (j == 1) v.y = x; else if (j == 2) v.z = x; else v.w = x;
+}
+
+// ----------------------------------------------------------------------------------
+// Activation epilogue fused into the GEMM (jobs that need no split-K): the arithmetic of
+// act_epilogue_kernel below applied to the block's own 128 x BN tile, which the consumer waves
+// parked in LDS (row stride BN + 8); all 8 waves take part.  A thread owns one column and walks
+// 4-row groups -- one Philox4x32-10 block per (group, column), as everywhere.  One cost partial
+// per block (cost_partials[blockIdx.x]); column partials [row_group][col] as below.
+// ----------------------------------------------------------------------------------
+template <int BM, int BN>
+__device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, int m0, int n0)
+{
+    constexpr int LDT = BN + 8;
+    const bool need_u = e.sample != nullptr;
+    const bool need_z = need_u && e.gauss;
+    const int c = threadIdx.x & (BN - 1), rg0 = threadIdx.x / BN;
+    const int col = n0 + c;
+    const bool live = col < e.cols, incol = col < (int)e.ld;
+    const float bias = live ? e.bias[col] : 0.f;
+    float cost = 0.f;
+#pragma unroll 1
+    for (int rg = rg0; rg < BM / 4; rg += GEMM_THREADS / BN) {
+        const int r0 = m0 + 4 * rg;
+        if (r0 >= e.rows || !incol) continue;
+        uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
+        if (need_u) {
+            const uint64_t g0 = e.rng.row_offset + (uint64_t)r0;
+            philox_rows4(e.rng, e.rng.draw, g0, (uint32_t)col, wa);
+            if (need_z) philox_rows4(e.rng, e.rng.draw | MDBN_NORMAL_BIT, g0, (uint32_t)col, wb);
+        }
+        float csum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = r0 + j;
+            if (row < e.rows) {
+                const int64_t off = (int64_t)row * e.ld + col;
+                float x = T[(4 * rg + j) * LDT + c] + bias;
+                float m, sv = 0.f;
+                if (e.gauss) {
+                    m = x;
+                    if (need_u) {
+                        const float u1 = philox_u01(wa[j]), u2 = philox_u01(wb[j]);
+                        sv = m + sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+                    }
+                } else {
+                    m = sigmoidf_(x);
+                    if (need_u) sv = philox_u01(wa[j]) < m ? 1.0f : 0.0f;
+                }
+                float tg = 0.f;
+                if (e.target && live) {
+                    tg = e.target[(int64_t)row * e.ld_target + col];
+                    if (e.gauss) { const float d = sigmoidf_(x) - tg; cost += d * d; }
+                    else cost += tg * softplusf_(-x) + (1.0f - tg) * softplusf_(x);
+                }
+                if (!live) { m = 0.f; sv = 0.f; x = 0.f; }          // keep pad columns zero
+                const float ms = m * e.mean_scale;
+                if (e.pre) e.pre[off] = x;
+                if (e.mean) e.mean[off] = ms;
+                if (e.sample) e.sample[off] = sv;
+                if (live) csum += e.colsum_kind == 0 ? ms : (e.colsum_kind == 1 ? tg - m : tg - sv);
+            }
+        }
+        if (e.colsum) e.colsum[(int64_t)(r0 >> 2) * e.ld + col] = csum;
+    }
+    if (e.cost_partials) {
+        const float tot = block_sum(cost, T + BM * LDT);
+        if (threadIdx.x == 0) e.cost_partials[blockIdx.x] = tot;
+    }
 }
 
 // ----------------------------------------------------------------------------------

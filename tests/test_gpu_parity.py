@@ -572,3 +572,39 @@ def test_bitwise_determinism_and_race_screen(hip_engine):
             assert np.array_equal(finals[0][0], other[0]) and np.array_equal(finals[0][1], other[1])
             assert np.array_equal(finals[0][2], other[2]) and finals[0][3] == other[3]
         assert np.isfinite(finals[0][0]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,H,B", [(100, 260, 37), (200, 1024, 512), (37, 19, 5), (4096, 1024, 4096),
+                                   (130, 2050, 1030)])
+def test_fused_epilogue_equals_unfused(hip_engine, V, H, B):
+    """GEMMs that need no split-K apply bias + activation + Philox sampling on the MFMA
+    accumulators (fused_act_epilogue); the result must be BITWISE what the slab + epilogue pair
+    produces (same accumulation order, same Philox addressing), the cost equal up to summation
+    order, and a whole CD step's statistics bitwise too."""
+    eng = hip_engine
+    rs = np.random.RandomState(V + H + B)
+    W = eng.to_device((0.05 * rs.randn(V, H)).astype(np.float32))
+    hb = eng.to_device((0.1 * rs.randn(H)).astype(np.float32))
+    vb = eng.to_device((0.1 * rs.randn(V)).astype(np.float32))
+    v = eng.to_device(rs.randn(B, V).astype(np.float32))
+    hsrc = eng.to_device((rs.rand(B, H) < 0.5).astype(np.float32))
+    from mdbn_amd.engine import RngAddr
+    out = {}
+    try:
+        for fused in (1, 0):
+            eng.set_option("fused_epilogue", fused)
+            up = eng.propup(v, W, hb, rng=RngAddr(7, 1, 3, 0))
+            dn = eng.propdown(hsrc, W, vb, gauss=False, rng=RngAddr(7, 1, 3, 1), v0=(v > 0).float())
+            dg = eng.propdown(hsrc, W, vb, gauss=True, add_noise=True, rng=RngAddr(7, 1, 3, 1), v0=v)
+            out[fused] = [t.cpu().numpy() for t in up] + [t.cpu().numpy() for t in dn] + \
+                         [t.cpu().numpy() for t in dg[1:]]
+    finally:
+        eng.set_option("fused_epilogue", 1)
+    names = ["up.pre", "up.mean", "up.sample", "dn.pre", "dn.mean", "dn.sample", "dn.cost",
+             "dg.mean", "dg.sample", "dg.cost"]
+    for name, a, b in zip(names, out[1], out[0]):
+        if name.endswith("cost"):
+            assert abs(float(a) - float(b)) <= 2e-6 * abs(float(b)) + 1e-6, name
+        else:
+            assert np.array_equal(a, b), name
