@@ -67,6 +67,9 @@ static int g_opt_update_overlap = 0;
 // mdbn_set_option("fused_epilogue"): apply the activation epilogue on the MFMA accumulators when a
 // GEMM needs no split-K (default on)
 static int g_opt_fused_epilogue = 1;
+// mdbn_set_option("fused_update"): mdbn_cd_train_step applies the update inside the statistics GEMM
+// when that GEMM is not split (default on); the S block of `stats` is then not materialised
+static int g_opt_fused_update = 1;
 constexpr int kTargetJobs = 256;       // one 8-wave tile job per CU (MI355X: 256 CUs)
 constexpr int kMinSplitK = 128;        // >= 4 slices of BK = 32 per split
 
@@ -82,11 +85,13 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 struct Plan {
     int tiles_m, tiles_n, splitk, kchunk, bn, bk;
+    int skinny = 0;        // M <= 64: skinny_gemm_kernel (tiles_n = 32-column strips)
     int64_t slab_floats(int64_t M, int64_t ldc) const { return (int64_t)splitk * M * ldc; }
     void fill(GemmArgs& g) const
     {
         g.kchunk = kchunk; g.splitk = splitk; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.bn = bn; g.bk = bk;
         g.inner_m = tiles_m <= tiles_n;
+        g.skinny = skinny; g.fused = 0;
     }
 };
 
@@ -113,6 +118,32 @@ Plan plan_gemm(int64_t M, int64_t N, int64_t K)
     sk = std::max<int64_t>(1, (K + kchunk - 1) / kchunk);
     p.splitk = (int)sk;
     p.kchunk = (int)kchunk;
+    return p;
+}
+
+// mdbn_set_option("skinny_gemm"): route forward passes of <= 64 rows to skinny_gemm_kernel (default on)
+static int g_opt_skinny_gemm = 1;
+constexpr int kSkinnyTargetBlocks = 512;   // two 8-wave blocks per CU
+constexpr int kSkinnyMinK = 256;           // >= 4 octets per wave
+constexpr int kSkinnyFusedMaxK = 2048;     // up to here one block streams the whole K range
+
+// Plan of one forward pass (x[M, K] * op(W) -> [M, N], `ldo` columns stored).  M <= 64 (the
+// reference's batch_size = 20 regime): 32-column strips x K ranges for the skinny kernel.
+Plan plan_forward(int64_t M, int64_t N, int64_t K, int64_t ldo)
+{
+    if (!g_opt_skinny_gemm || M > 64) return plan_gemm(M, N, K);
+    Plan p;
+    p.skinny = 1;
+    p.tiles_m = 1;
+    p.tiles_n = (int)((ldo + 31) / 32);
+    p.bn = 32; p.bk = 8;
+    const int64_t want = std::max<int64_t>(1, kSkinnyTargetBlocks / p.tiles_n);
+    // a K range per block only pays once the per-wave stream (K / 8) is long: an extra epilogue
+    // launch costs ~5 us, 2048 of K cost a wave ~4 us of MFMA issue
+    const int64_t sk = K <= kSkinnyFusedMaxK ? 1 : std::min(want, std::max<int64_t>(1, K / kSkinnyMinK));
+    int64_t kchunk = ((K + sk - 1) / sk + 63) / 64 * 64;
+    p.kchunk = (int)kchunk;
+    p.splitk = (int)std::max<int64_t>(1, (K + kchunk - 1) / kchunk);
     return p;
 }
 
@@ -172,9 +203,16 @@ WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
     WsSizes s;
     const Plan up = plan_gemm(B, H, V), down = plan_gemm(B, V, H), st = plan_gemm(V, H, 2 * B);
     s.slab = std::max(up.slab_floats(B, ldh), down.slab_floats(B, ldv));
+    if (B <= 64) {      // either kernel may serve the pass (mdbn_set_option "skinny_gemm")
+        const Plan ups = plan_forward(B, H, V, ldh), downs = plan_forward(B, V, H, ldv);
+        s.slab = std::max(s.slab, std::max(ups.slab_floats(B, ldh), downs.slab_floats(B, ldv)));
+    }
     if (st.splitk > 1) s.slab = std::max(s.slab, st.slab_floats(V, ldh));
     s.slab = std::max<int64_t>(s.slab, 4 * std::max(ldv, ldh) * 8);
     s.cost = (((B + 3) / 4) * std::max(ldv, ldh) + 255) / 256 + 64;     // worst case: one column per thread
+    // fused epilogues write one partial per block: 128 x 64 tiles, or 32-column strips (skinny)
+    s.cost = std::max<int64_t>(s.cost, ((B + 127) / 128) * ((std::max(ldv, ldh) + 63) / 64) + 64);
+    s.cost = std::max<int64_t>(s.cost, (std::max(ldv, ldh) + 31) / 32 + 64);
     const int ng = row_groups(B);
     s.colP = 2 * (int64_t)ng * ldh;
     s.colV = (int64_t)ng * ldv;
@@ -233,7 +271,7 @@ int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_
     int64_t r0 = 0;
     while (r0 < a.rows) {
         int64_t R = a.rows - r0;
-        Plan p = plan_gemm(R, Ndim, Kdim);
+        Plan p = plan_forward(R, Ndim, Kdim, a.ldo);
         bool fuse = false;
         for (;;) {      // shrink the chunk until its slabs (unfused) and cost partials fit
             fuse = g_opt_fused_epilogue && p.splitk == 1;
@@ -242,7 +280,7 @@ int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_
             if (slabs_fit && n_cost + need_cost <= ws.cost_floats) break;
             if (R <= 4) return fail(MDBN_ENOSPC, "workspace cannot hold one 4-row chunk");
             R = std::max<int64_t>(4, (R / 2 + 3) & ~int64_t(3));
-            p = plan_gemm(R, Ndim, Kdim);
+            p = plan_forward(R, Ndim, Kdim, a.ldo);
         }
         GemmArgs g;
         g.A = a.x + r0 * a.ldx;  g.lda = a.ldx;
@@ -251,7 +289,6 @@ int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_
         g.slab_stride = R * a.ldo;
         g.M = (int)R; g.N = (int)Ndim; g.K = (int)Kdim; g.Nst = (int)a.ldo;
         p.fill(g);
-        g.fused = 0;
 
         EpiArgs e;
         e.slabs = ws.slabs; e.slab_stride = g.slab_stride; e.nsplit = p.splitk;
@@ -358,6 +395,14 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "epilogue_cw") == 0) {
         REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "epilogue_cw must be 0 (auto), 1, 2 or 4");
         set_epilogue_cw((int)value);
+        return MDBN_OK;
+    }
+    if (strcmp(name, "skinny_gemm") == 0) {
+        g_opt_skinny_gemm = value != 0;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "fused_update") == 0) {
+        g_opt_fused_update = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "fused_epilogue") == 0) {
@@ -478,7 +523,7 @@ int mdbn_propdown_sample(mdbn_ctx* ctx, void* stream, const float* h, int64_t B,
     }
     if (cost_sum)
         HIP_OK(launch_finalize_stats(nullptr, nullptr, nullptr, 0, 0, 0, ws.cost_partials, n_cost, nullptr,
-                                     nullptr, cost_sum, s));
+                                     nullptr, cost_sum, nullptr, s));
     return MDBN_OK;
 }
 
@@ -503,7 +548,7 @@ int mdbn_cd_stats(mdbn_ctx* ctx, void* stream, const float* V2, const float* P2,
     HIP_OK(launch_colsum_groups(P2, nullptr, (int)B, ldh, ws.colPpos, s));
     HIP_OK(launch_colsum_groups(P2 + B * ldh, nullptr, (int)B, ldh, ws.colPneg, s));
     HIP_OK(launch_colsum_groups(V2, V2 + B * ldv, (int)B, ldv, ws.colV, s));
-    HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, ng, ldh, ldv, nullptr, 0, s_h, s_v, cost, s));
+    HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, ng, ldh, ldv, nullptr, 0, s_h, s_v, cost, nullptr, s));
 
     // S = [v0 ; nv]^T [ph ; -nh]  : one GEMM over the stacked batch dimension (K = 2B)
     const Plan p = plan_gemm(V, H, 2 * B);
@@ -637,21 +682,39 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         HIP_OK(hipEventRecord(ctx->ev_fork, s));
         HIP_OK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
         HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials,
-                                     n_cost, s_h, s_v, cost, ctx->side));
+                                     n_cost, s_h, s_v, cost, nullptr, ctx->side));
         u.phase = 2;
         HIP_OK(launch_update(u, ctx->side));
         HIP_OK(hipEventRecord(ctx->ev_join, ctx->side));
-    } else {
-        HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials,
-                                     n_cost, s_h, s_v, cost, s));
     }
     const Plan p = plan_gemm(V, H, 2 * B);
+    // Single device, unsplit statistics GEMM: the GEMM applies the weight update to its own tiles
+    // (S never reaches HBM) and the bias / cost half rides on the finalize kernel -- no update launch.
+    const bool fuse_upd = upd && !overlap && g_opt_fused_update && p.splitk == 1;
+    if (!overlap) {
+        BiasUpd bu;
+        if (fuse_upd) {
+            bu.hb = u.hbias; bu.hbs = u.hbias_speed; bu.vb = u.vbias; bu.vbs = u.vbias_speed;
+            bu.H = H; bu.V = V; bu.lr = u.lr; bu.mu = u.momentum; bu.inv_rows = 1.0f / u.n_rows;
+            bu.cost_scale = u.cost_scale; bu.cost_out = u.cost_out;
+        }
+        HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials,
+                                     n_cost, s_h, s_v, cost, fuse_upd ? &bu : nullptr, s));
+    }
     GemmArgs g;
     g.A = a->V2; g.lda = ldv; g.B = a->P2; g.ldb = ldh;
     g.ldc = ldh; g.slab_stride = V * ldh;
     g.M = (int)V; g.N = (int)H; g.K = (int)(2 * B); g.Nst = (int)ldh;
     p.fill(g);
-    g.fused = 0;
+    if (fuse_upd) {
+        g.C = nullptr;
+        g.fused = 2;
+        g.upd.W = u.W; g.upd.Ws = u.W_speed; g.upd.W0 = u.W0; g.upd.ld = ldh; g.upd.rows = (int)V;
+        g.upd.lr = u.lr; g.upd.l1 = u.lambda_1; g.upd.l2 = u.lambda_2; g.upd.wc = u.weightcost;
+        g.upd.mu = u.momentum; g.upd.inv_bs = 1.0f / u.batch_size;
+        HIP_OK(timed_gemm(LAY_MN, LAY_MN, g, s));
+        return MDBN_OK;
+    }
     if (p.splitk == 1) {
         g.C = S;
         HIP_OK(timed_gemm(LAY_MN, LAY_MN, g, s));

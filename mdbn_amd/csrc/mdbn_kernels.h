@@ -29,6 +29,22 @@ struct EpiArgs {
     PhiloxKey rng;
 };
 
+// parameter update applied by the statistics GEMM to its own output tile (fused == 2)
+struct UpdEpi {
+    float* W; float* Ws; const float* W0;      // [rows][ld]; W0 nullable (then the live W)
+    int64_t ld;
+    int rows;
+    float lr, l1, l2, wc, mu, inv_bs;
+};
+
+// bias half of the update + monitoring cost, applied by finalize_stats_kernel
+struct BiasUpd {
+    float* hb; float* hbs; float* vb; float* vbs;
+    int64_t H, V;
+    float lr, mu, inv_rows, cost_scale;
+    float* cost_out;
+};
+
 struct GemmArgs {
     const float* A;        // LAY_K: [M][lda] ; LAY_MN: [K][lda]
     const float* B;        // LAY_K: [N][ldb] ; LAY_MN: [K][ldb]
@@ -43,8 +59,11 @@ struct GemmArgs {
     int bk;                // slice depth along the reduction index (32 or 64; 64 only with bn = 128)
     int inner_m;           // work-list order inside one split: 1 = tile_m fastest
     unsigned long long* stamps;   // diagnostic builds only (-DMDBN_STAMP); NULL otherwise
-    int fused;             // 1: no split-K and the activation epilogue runs on the accumulators
-    EpiArgs epi;           // ... with these arguments (slabs / nsplit unused; one cost partial per block)
+    int skinny;            // 1: M <= 64 -> skinny_gemm_kernel (tiles_n = 32-column strips, splitk = K ranges)
+    int fused;             // no split-K and an epilogue runs on the block's own output tile:
+                           //   1 = activation (epi), 2 = parameter update (upd; statistics GEMM, C is not written)
+    EpiArgs epi;           // fused == 1 (slabs / nsplit unused; one cost partial per block)
+    UpdEpi upd;            // fused == 2
 };
 
 
@@ -65,7 +84,7 @@ hipError_t launch_gather(const float* src, int64_t n_rows, int64_t cols_ld, int6
 hipError_t launch_colsum_groups(const float* X, const float* Y, int rows, int64_t ld, float* out, hipStream_t s);
 hipError_t launch_finalize_stats(const float* posP, const float* negP, const float* partV, int ngroups,
                                  int64_t ldh, int64_t ldv, const float* cost_partials, int n_cost,
-                                 float* s_h, float* s_v, float* cost, hipStream_t s);
+                                 float* s_h, float* s_v, float* cost, const BiasUpd* bias_update, hipStream_t s);
 hipError_t launch_update(const mdbn_update_args& a, hipStream_t s);
 hipError_t launch_free_energy(const float* slabs, int nsplit, int64_t slab_stride, int64_t ldh, int H,
                               const float* hbias, const float* x, int64_t ldv, int V, const float* vbias,

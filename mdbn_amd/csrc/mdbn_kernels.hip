@@ -11,6 +11,7 @@
 //     barrier per slice), split-K so that ~one block per CU is in flight.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstring>
 #include <stdint.h>
 #include "philox.h"
 #include "mdbn_kernels.h"
@@ -169,6 +170,8 @@ constexpr int GEMM_THREADS = 512;
 
 template <int BM, int BN>
 __device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, int m0, int n0);
+template <int BM, int BN>
+__device__ __forceinline__ void fused_update_epilogue(const UpdEpi& u, const float* T, int m0, int n0);
 #ifndef ABLATE_STORE
 #define ABLATE_STORE 0    // diagnostic builds only: timing ablations of the producer
 #endif
@@ -298,7 +301,7 @@ __device__ __forceinline__ void gemm_consume(const GemmArgs& g, const float* __r
     }
 }
 
-template <int LA, int LB, int MI, int NI, int KB, bool FUSED>
+template <int LA, int LB, int MI, int NI, int KB, int FUSED>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
 {
     constexpr int BM = 64 * MI, BN = 64 * NI;
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
         const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (kbeg + nt * KB <= g.K);
         if (interior) gemm_produce<LA, LB, MI, NI, KB, false>(g, smem, m0, n0, kbeg, kend, nt);
         else gemm_produce<LA, LB, MI, NI, KB, true>(g, smem, m0, n0, kbeg, kend, nt);
-        if constexpr (!FUSED) return;
+        if constexpr (FUSED == 0) return;
         __builtin_amdgcn_s_setprio(0);
     } else {
         const int lane = threadIdx.x & 63;
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
 #endif
 
         // accumulator (32x32): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-        if constexpr (FUSED) {
+        if constexpr (FUSED != 0) {
             // Park the tile in LDS (every read of the last slice ended at the loop's final barrier).
             // Row stride BN + 8: lanes 32..63 (rows + 4) land 32 banks away from lanes 0..31.
             constexpr int LDT = BN + 8;
@@ -375,13 +378,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
             return;
         }
     }
-    if constexpr (FUSED) {      // all 8 waves: bias + activation + sampling + cost / column partials
+    if constexpr (FUSED != 0) {     // all 8 waves work on the parked tile
         __syncthreads();
-        fused_tile_epilogue<BM, BN>(g.epi, smem, m0, n0);
+        if constexpr (FUSED == 1) fused_tile_epilogue<BM, BN>(g.epi, smem, m0, n0);   // activation + sampling
+        else fused_update_epilogue<BM, BN>(g.upd, smem, m0, n0);                       // parameter update
     }
 }
 
-template <int LA, int LB, int MI, int NI, int KB, bool FUSED>
+template <int LA, int LB, int MI, int NI, int KB, int FUSED>
 static hipError_t launch_gemm_t(const GemmArgs& g, hipStream_t s)
 {
     // The LDS request is padded past half of the CU's 160 KiB so that exactly one 8-wave
@@ -401,7 +405,7 @@ static hipError_t launch_gemm_t(const GemmArgs& g, hipStream_t s)
     return hipGetLastError();
 }
 
-template <int LA, int LB, bool FUSED>
+template <int LA, int LB, int FUSED>
 static hipError_t launch_gemm_l(const GemmArgs& g, hipStream_t s)
 {
     if (g.bn == 128 && g.bk == 64) return launch_gemm_t<LA, LB, 2, 2, 64, FUSED>(g, s);
@@ -410,18 +414,22 @@ static hipError_t launch_gemm_l(const GemmArgs& g, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
+hipError_t launch_skinny_gemm(int lb, const GemmArgs& g, hipStream_t s);
+
 hipError_t launch_gemm(int la, int lb, const GemmArgs& g, hipStream_t s)
 {
-    if (g.fused) {      // only the two forward-pass operand layouts ever fuse (separate instantiations:
-                        // the unfused kernels keep their register allocation)
+    if (g.skinny) return la == LAY_K ? launch_skinny_gemm(lb, g, s) : hipErrorInvalidValue;
+    if (g.fused) {      // forward passes fuse the activation, the statistics GEMM the update (separate
+                        // instantiations: the unfused kernels keep their register allocation)
         if (g.splitk != 1) return hipErrorInvalidValue;
-        if (la == LAY_K && lb == LAY_MN) return launch_gemm_l<LAY_K, LAY_MN, true>(g, s);
-        if (la == LAY_K && lb == LAY_K) return launch_gemm_l<LAY_K, LAY_K, true>(g, s);
+        if (g.fused == 1 && la == LAY_K && lb == LAY_MN) return launch_gemm_l<LAY_K, LAY_MN, 1>(g, s);
+        if (g.fused == 1 && la == LAY_K && lb == LAY_K) return launch_gemm_l<LAY_K, LAY_K, 1>(g, s);
+        if (g.fused == 2 && la == LAY_MN && lb == LAY_MN) return launch_gemm_l<LAY_MN, LAY_MN, 2>(g, s);
         return hipErrorInvalidValue;
     }
-    if (la == LAY_K && lb == LAY_MN) return launch_gemm_l<LAY_K, LAY_MN, false>(g, s);
-    if (la == LAY_K && lb == LAY_K) return launch_gemm_l<LAY_K, LAY_K, false>(g, s);
-    if (la == LAY_MN && lb == LAY_MN) return launch_gemm_l<LAY_MN, LAY_MN, false>(g, s);
+    if (la == LAY_K && lb == LAY_MN) return launch_gemm_l<LAY_K, LAY_MN, 0>(g, s);
+    if (la == LAY_K && lb == LAY_K) return launch_gemm_l<LAY_K, LAY_K, 0>(g, s);
+    if (la == LAY_MN && lb == LAY_MN) return launch_gemm_l<LAY_MN, LAY_MN, 0>(g, s);
     return hipErrorInvalidValue;
 }
 
@@ -499,12 +507,57 @@ __device__ __forceinline__ void setc(float4& v, int j, float x)
 // 4-row groups -- one Philox4x32-10 block per (group, column), as everywhere.  One cost partial
 // per block (cost_partials[blockIdx.x]); column partials [row_group][col] as below.
 // ----------------------------------------------------------------------------------
+// One (4-row group, column) of an activation epilogue: x[j] = pre-activation (bias included) of
+// row r0 + j.  Stores pre / mean / sample, the group's column partial, and adds to `cost`.
+__device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, float x2, float x3, int r0, int col, bool live, float& cost)
+{
+    const bool need_u = e.sample != nullptr;
+    const bool need_z = need_u && e.gauss;
+    uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
+    if (need_u) {
+        const uint64_t g0 = e.rng.row_offset + (uint64_t)r0;
+        philox_rows4(e.rng, e.rng.draw, g0, (uint32_t)col, wa);
+        if (need_z) philox_rows4(e.rng, e.rng.draw | MDBN_NORMAL_BIT, g0, (uint32_t)col, wb);
+    }
+    float csum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = r0 + j;
+        float xj = j == 0 ? x0 : (j == 1 ? x1 : (j == 2 ? x2 : x3));
+        if (row < e.rows) {
+            const int64_t off = (int64_t)row * e.ld + col;
+            float m, sv = 0.f;
+            if (e.gauss) {
+                m = xj;
+                if (need_u) {
+                    const float u1 = philox_u01(wa[j]), u2 = philox_u01(wb[j]);
+                    sv = m + sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+                }
+            } else {
+                m = sigmoidf_(xj);
+                if (need_u) sv = philox_u01(wa[j]) < m ? 1.0f : 0.0f;
+            }
+            float tg = 0.f;
+            if (e.target && live) {
+                tg = e.target[(int64_t)row * e.ld_target + col];
+                if (e.gauss) { const float d = sigmoidf_(xj) - tg; cost += d * d; }
+                else cost += tg * softplusf_(-xj) + (1.0f - tg) * softplusf_(xj);
+            }
+            if (!live) { m = 0.f; sv = 0.f; xj = 0.f; }          // keep pad columns zero
+            const float ms = m * e.mean_scale;
+            if (e.pre) e.pre[off] = xj;
+            if (e.mean) e.mean[off] = ms;
+            if (e.sample) e.sample[off] = sv;
+            if (live) csum += e.colsum_kind == 0 ? ms : (e.colsum_kind == 1 ? tg - m : tg - sv);
+        }
+    }
+    if (e.colsum) e.colsum[(int64_t)(r0 >> 2) * e.ld + col] = csum;
+}
+
 template <int BM, int BN>
 __device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, int m0, int n0)
 {
     constexpr int LDT = BN + 8;
-    const bool need_u = e.sample != nullptr;
-    const bool need_z = need_u && e.gauss;
     const int c = threadIdx.x & (BN - 1), rg0 = threadIdx.x / BN;
     const int col = n0 + c;
     const bool live = col < e.cols, incol = col < (int)e.ld;
@@ -514,50 +567,205 @@ __device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, 
     for (int rg = rg0; rg < BM / 4; rg += GEMM_THREADS / BN) {
         const int r0 = m0 + 4 * rg;
         if (r0 >= e.rows || !incol) continue;
-        uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
-        if (need_u) {
-            const uint64_t g0 = e.rng.row_offset + (uint64_t)r0;
-            philox_rows4(e.rng, e.rng.draw, g0, (uint32_t)col, wa);
-            if (need_z) philox_rows4(e.rng, e.rng.draw | MDBN_NORMAL_BIT, g0, (uint32_t)col, wb);
-        }
-        float csum = 0.f;
+        float x[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = r0 + j;
-            if (row < e.rows) {
-                const int64_t off = (int64_t)row * e.ld + col;
-                float x = T[(4 * rg + j) * LDT + c] + bias;
-                float m, sv = 0.f;
-                if (e.gauss) {
-                    m = x;
-                    if (need_u) {
-                        const float u1 = philox_u01(wa[j]), u2 = philox_u01(wb[j]);
-                        sv = m + sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
-                    }
-                } else {
-                    m = sigmoidf_(x);
-                    if (need_u) sv = philox_u01(wa[j]) < m ? 1.0f : 0.0f;
-                }
-                float tg = 0.f;
-                if (e.target && live) {
-                    tg = e.target[(int64_t)row * e.ld_target + col];
-                    if (e.gauss) { const float d = sigmoidf_(x) - tg; cost += d * d; }
-                    else cost += tg * softplusf_(-x) + (1.0f - tg) * softplusf_(x);
-                }
-                if (!live) { m = 0.f; sv = 0.f; x = 0.f; }          // keep pad columns zero
-                const float ms = m * e.mean_scale;
-                if (e.pre) e.pre[off] = x;
-                if (e.mean) e.mean[off] = ms;
-                if (e.sample) e.sample[off] = sv;
-                if (live) csum += e.colsum_kind == 0 ? ms : (e.colsum_kind == 1 ? tg - m : tg - sv);
-            }
-        }
-        if (e.colsum) e.colsum[(int64_t)(r0 >> 2) * e.ld + col] = csum;
+        for (int j = 0; j < 4; ++j) x[j] = T[(4 * rg + j) * LDT + c] + bias;
+        act_quad(e, x[0], x[1], x[2], x[3], r0, col, live, cost);
     }
     if (e.cost_partials) {
         const float tot = block_sum(cost, T + BM * LDT);
         if (threadIdx.x == 0) e.cost_partials[blockIdx.x] = tot;
     }
+}
+
+// ----------------------------------------------------------------------------------
+// Skinny GEMM: out[M <= 32*MI, N] = x[M, K] * op(W) for the small minibatches the reference
+// trains with (batch_size 20, dbn.py / MDBN.py).  At M <= 32 a weight is used by exactly ONE
+// MFMA, so staging W through LDS buys nothing and a 128-row tile wastes >= 75% of the matrix
+// pipe on zero rows (W then streams at 1/4 of the HBM rate).  Here a block owns a 32-column
+// strip and a K range; its 8 waves take interleaved K-octets, load the MFMA operands straight
+// from global memory (one float4 per lane per operand and octet; register double-buffered one
+// batch of 4 octets ahead), and their partial 32x32 accumulators are reduced through LDS in
+// wave order (deterministic).  MFMA rate at M <= 32 equals ~8.6 TB/s of W: the pass is bound
+// by HBM / L2, as a batched GEMV should be.
+//   A (x)  : [M][lda], K contiguous.    lane (i, h) <- x[i][k8 + 4h .. +3]
+//   B LAY_K : W[N][ldb], K contiguous.  lane (i, h) <- W[n0 + i][k8 + 4h .. +3]      (down pass)
+//   B LAY_MN: W[K][ldb], N contiguous.  lane (i, h) <- W[k8 + 4h + t][n0 + i], t<4   (up pass)
+// MFMA t of an octet multiplies the k-pair {k8 + t, k8 + 4 + t}.  Rows >= M / columns >= N read
+// a clamped (valid) address: they only ever reach accumulator rows / columns that are not
+// stored.  The K tail is zero-filled in both operands.
+// ----------------------------------------------------------------------------------
+constexpr int SKINNY_WAVES = 8, SKINNY_U = 4, SKINNY_LDT = 33;
+
+template <int LB, int MI>
+struct SkinnyRegs {
+    float4 a[SKINNY_U][MI];
+    float4 b[SKINNY_U];
+};
+
+template <int LB, int MI>
+__device__ __forceinline__ void skinny_load(const GemmArgs& g, const float* const (&arow)[MI], const float* bptr,
+                                            int k8, int kend, int h, float4 (&ra)[MI], float4& rb)
+{
+    const int k = k8 + 4 * h;
+    if (k8 + 8 <= kend) {
+#pragma unroll
+        for (int a = 0; a < MI; ++a) ra[a] = *reinterpret_cast<const float4*>(arow[a] + k);
+        if (LB == LAY_K) {
+            rb = *reinterpret_cast<const float4*>(bptr + k);
+        } else {
+            const float* p = bptr + (int64_t)k * g.ldb;
+            rb.x = p[0]; rb.y = p[g.ldb]; rb.z = p[2 * g.ldb]; rb.w = p[3 * g.ldb];
+        }
+    } else {        // K tail: component guards, zero fill
+        float va[MI][4], vb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool ok = k + t < kend;
+#pragma unroll
+            for (int a = 0; a < MI; ++a) va[a][t] = ok ? arow[a][k + t] : 0.f;
+            if (LB == LAY_K) vb[t] = ok ? bptr[k + t] : 0.f;
+            else vb[t] = ok ? bptr[(int64_t)(k + t) * g.ldb] : 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < MI; ++a) ra[a] = make_float4(va[a][0], va[a][1], va[a][2], va[a][3]);
+        rb = make_float4(vb[0], vb[1], vb[2], vb[3]);
+    }
+}
+
+template <int LB, int MI, bool FUSED>
+__global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmArgs g)
+{
+    constexpr int NW = SKINNY_WAVES, U = SKINNY_U, LDT = SKINNY_LDT, BM = 32 * MI;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [NW][BM][LDT] (+ 8)
+    const int strips = g.tiles_n;
+    const int ks = blockIdx.x / strips, st = blockIdx.x - ks * strips;
+    const int n0 = st * 32;
+    const int kbeg = ks * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int noct = (kend - kbeg + 7) >> 3;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+
+    const float* arow[MI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a) arow[a] = g.A + (int64_t)min(i + 32 * a, g.M - 1) * g.lda;
+    const int bn = min(n0 + i, g.N - 1);
+    const float* bptr = LB == LAY_K ? g.B + (int64_t)bn * g.ldb : g.B + bn;
+
+    f32x16 acc[MI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+
+    // batch = U octets of this wave (octets wave, wave + NW, ...); two register sets
+    SkinnyRegs<LB, MI> r0, r1;
+#define SKINNY_LOAD(R, OB)                                                                   \
+    do {                                                                                     \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                      \
+            const int o = (OB) + u * NW;                                                     \
+            if (o < noct) skinny_load<LB, MI>(g, arow, bptr, kbeg + 8 * o, kend, h, R.a[u], R.b[u]); \
+        }                                                                                    \
+    } while (0)
+#define SKINNY_MMA(R, OB)                                                                    \
+    do {                                                                                     \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                      \
+            if ((OB) + u * NW < noct) {                                                      \
+                _Pragma("unroll") for (int a = 0; a < MI; ++a) {                             \
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(R.a[u][a].x, R.b[u].x, acc[a], 0, 0, 0); \
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(R.a[u][a].y, R.b[u].y, acc[a], 0, 0, 0); \
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(R.a[u][a].z, R.b[u].z, acc[a], 0, 0, 0); \
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(R.a[u][a].w, R.b[u].w, acc[a], 0, 0, 0); \
+                }                                                                            \
+            }                                                                                \
+        }                                                                                    \
+    } while (0)
+
+    constexpr int STEP = NW * U;
+    SKINNY_LOAD(r0, wave);
+    for (int ob = wave; ob < noct; ob += 2 * STEP) {
+        SKINNY_LOAD(r1, ob + STEP);
+        SKINNY_MMA(r0, ob);
+        SKINNY_LOAD(r0, ob + 2 * STEP);
+        SKINNY_MMA(r1, ob + STEP);
+    }
+#undef SKINNY_LOAD
+#undef SKINNY_MMA
+
+    // park the partial accumulators, reduce over the waves in wave order
+    float* T = smem + wave * (BM * LDT);
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            T[(32 * a + (e & 3) + 8 * (e >> 2) + 4 * h) * LDT + i] = acc[a][e];
+    __syncthreads();
+
+    const int q = threadIdx.x;                 // quad = (row group, column) of the strip
+    const int rg = q >> 5, c = q & 31;
+    const int col = n0 + c;
+    float cost = 0.f;
+    if (rg < BM / 4) {
+        float x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += smem[w * (BM * LDT) + (4 * rg + j) * LDT + c];
+            x[j] = sum;
+        }
+        const int r0w = 4 * rg;
+        if (FUSED) {
+            const EpiArgs& e = g.epi;
+            const bool live = col < e.cols;
+            if (r0w < e.rows && col < (int)e.ld) {
+                const float bias = live ? e.bias[col] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] += bias;
+                act_quad(e, x[0], x[1], x[2], x[3], r0w, col, live, cost);
+            }
+        } else {
+            float* C = g.C + (int64_t)ks * g.slab_stride;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (r0w + j < g.M && col < g.Nst) C[(int64_t)(r0w + j) * g.ldc + col] = col < g.N ? x[j] : 0.f;
+        }
+    }
+    if (FUSED && g.epi.cost_partials) {
+        __syncthreads();
+        const float tot = block_sum(cost, smem);
+        if (threadIdx.x == 0) g.epi.cost_partials[blockIdx.x] = tot;
+    }
+}
+
+template <int LB, int MI, bool FUSED>
+static hipError_t launch_skinny_t(const GemmArgs& g, hipStream_t s)
+{
+    constexpr int lds_bytes = (SKINNY_WAVES * 32 * MI * SKINNY_LDT + 8) * (int)sizeof(float);
+    static bool attr_set = false;
+    auto kern = skinny_gemm_kernel<LB, MI, FUSED>;
+    if (!attr_set && lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.tiles_n * g.splitk), dim3(64 * SKINNY_WAVES), lds_bytes, s, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_skinny_gemm(int lb, const GemmArgs& g, hipStream_t s)
+{
+    if (g.M < 1 || g.M > 64 || g.kchunk % 8 != 0 || (g.fused && g.splitk != 1)) return hipErrorInvalidValue;
+    const int mi = g.M <= 32 ? 1 : 2;
+#define SKINNY_CASE(LBV, MIV, FV) if (lb == LBV && mi == MIV && (g.fused != 0) == FV) return launch_skinny_t<LBV, MIV, FV>(g, s)
+    SKINNY_CASE(LAY_K, 1, true);  SKINNY_CASE(LAY_K, 1, false);
+    SKINNY_CASE(LAY_K, 2, true);  SKINNY_CASE(LAY_K, 2, false);
+    SKINNY_CASE(LAY_MN, 1, true); SKINNY_CASE(LAY_MN, 1, false);
+    SKINNY_CASE(LAY_MN, 2, true); SKINNY_CASE(LAY_MN, 2, false);
+#undef SKINNY_CASE
+    return hipErrorInvalidValue;
 }
 
 // ----------------------------------------------------------------------------------
@@ -606,11 +814,13 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
         float pre[4][CW];
         const float* base = e.slabs + (int64_t)r0 * e.ld + c0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int j = 0; j < CW; ++j) pre[r][j] = 0.f;
-            if (r0 + r < e.rows) {
-                if (NS > 0) {
+        if (NS > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r0 + r < e.rows) {
                     float v[NS > 0 ? NS : 1][CW];
 #pragma unroll
                     for (int sidx = 0; sidx < NS; ++sidx)
@@ -619,18 +829,34 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
                     for (int sidx = 0; sidx < NS; ++sidx)
 #pragma unroll
                         for (int j = 0; j < CW; ++j) pre[r][j] += v[sidx][j];
-                } else {
-                    for (int sidx = 0; sidx < e.nsplit; ++sidx) {
-                        float v[CW];
-                        VecIO<CW>::load(base + (int64_t)r * e.ld + (int64_t)sidx * e.slab_stride, v);
-#pragma unroll
-                        for (int j = 0; j < CW; ++j) pre[r][j] += v[j];
-                    }
                 }
             }
+        } else {
+            // any split count: 8 slabs x 4 rows of loads in flight per round (a load-add-load-add
+            // chain costs one memory latency per slab: 76 us at 36 slabs), summed in slab order
+            for (int s0 = 0; s0 < e.nsplit; s0 += 8) {
+                float v[4][8][CW];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                        for (int j = 0; j < CW; ++j) v[r][u][j] = 0.f;
+                        if (r0 + r < e.rows && s0 + u < e.nsplit)
+                            VecIO<CW>::load(base + (int64_t)r * e.ld + (int64_t)(s0 + u) * e.slab_stride, v[r][u]);
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int j = 0; j < CW; ++j) pre[r][j] += v[r][u][j];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int j = 0; j < CW; ++j) pre[r][j] += bias[j];
-        }
         uint32_t wa[CW][4], wb[CW][4];       // [col][row]
         const bool need_u = e.sample != nullptr;
         const bool need_z = need_u && e.gauss;
@@ -740,9 +966,14 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * blockDim.x) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = 0; s < nsplit; ++s) {
-            const float4 v = reinterpret_cast<const float4*>(slabs + (int64_t)s * slab_stride)[i];
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        for (int s0 = 0; s0 < nsplit; s0 += 8) {      // 8 loads in flight, summed in slab order
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = s0 + u < nsplit ? reinterpret_cast<const float4*>(slabs + (int64_t)(s0 + u) * slab_stride)[i]
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
         }
         reinterpret_cast<float4*>(out)[i] = a;
     }
@@ -806,7 +1037,7 @@ __global__ __launch_bounds__(256) void finalize_stats_kernel(const float* __rest
                                                              int64_t ldh, int64_t ldv,
                                                              const float* __restrict__ cost_partials, int n_cost,
                                                              float* __restrict__ s_h, float* __restrict__ s_v,
-                                                             float* __restrict__ cost)
+                                                             float* __restrict__ cost, BiasUpd bu, int do_bias)
 {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -830,23 +1061,41 @@ __global__ __launch_bounds__(256) void finalize_stats_kernel(const float* __rest
             const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
             if (i < ldh) s_h[i] = t;
             else if (i < ldh + ldv) s_v[i - ldh] = t;
+            if (do_bias) {      // bias half of the update (rbm.py:356-365; same expressions as update_kernel)
+                if (i < bu.H) {
+                    const float sp = bu.hbs[i], g = t * bu.inv_rows;
+                    bu.hbs[i] = g + (sp - g) * bu.mu;
+                    bu.hb[i] = bu.hb[i] + sp * bu.lr;
+                } else if (i >= ldh && i - ldh < bu.V) {
+                    const int64_t j = i - ldh;
+                    const float sp = bu.vbs[j], g = t * bu.inv_rows;
+                    bu.vbs[j] = g + (sp - g) * bu.mu;
+                    bu.vb[j] = bu.vb[j] + sp * bu.lr;
+                }
+            }
         }
     } else if (cost_partials) {                 // the extra last block totals the cost
         __shared__ float cred[4];
         float a = 0.f;
         for (int k = threadIdx.x; k < n_cost; k += blockDim.x) a += cost_partials[k];
         const float t = block_sum(a, cred);
-        if (threadIdx.x == 0) { cost[0] = t; cost[1] = 0.f; cost[2] = 0.f; cost[3] = 0.f; }
+        if (threadIdx.x == 0) {
+            cost[0] = t; cost[1] = 0.f; cost[2] = 0.f; cost[3] = 0.f;
+            if (do_bias && bu.cost_out) bu.cost_out[0] = t * bu.cost_scale;
+        }
     }
 }
 
 hipError_t launch_finalize_stats(const float* posP, const float* negP, const float* partV, int ngroups,
                                  int64_t ldh, int64_t ldv, const float* cost_partials, int n_cost,
-                                 float* s_h, float* s_v, float* cost, hipStream_t s)
+                                 float* s_h, float* s_v, float* cost, const BiasUpd* bias_update, hipStream_t s)
 {
     const int grid = (int)((ldh + ldv + 63) / 64) + 1;
+    BiasUpd bu;
+    memset(&bu, 0, sizeof bu);
+    if (bias_update) bu = *bias_update;
     hipLaunchKernelGGL(finalize_stats_kernel, dim3(grid), dim3(256), 0, s, posP, negP, partV, ngroups,
-                       ldh, ldv, cost_partials, n_cost, s_h, s_v, cost);
+                       ldh, ldv, cost_partials, n_cost, s_h, s_v, cost, bu, bias_update ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -875,6 +1124,68 @@ hipError_t launch_colsum_groups(const float* X, const float* Y, int rows, int64_
 {
     hipLaunchKernelGGL(colsum_groups_kernel, dim3(epilogue_blocks(rows, ld)), dim3(256), 0, s, X, Y, rows, ld, out);
     return hipGetLastError();
+}
+
+// the whole update rule on 4 consecutive weights (shared by update_kernel and the fused epilogue of
+// the statistics GEMM: identical expressions, identical results)
+__device__ __forceinline__ void update_rule4(const float4& w, const float4& sp, const float4& st, const float4& wc0,
+                                             float inv_bs, float wc, float decay, float l1, float two_lr_l1,
+                                             float mu, float lr, float4& wn, float4& sn)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float wj = comp(w, j), spj = comp(sp, j);
+        float g = comp(st, j) * inv_bs - wc * comp(wc0, j);
+        float m = decay;
+        if (l1 != 0.0f) {
+            const float shrink = 1.0f + two_lr_l1 / (fabsf(wj) + 0.001f);
+            g = g / shrink;
+            m = decay / shrink;
+        }
+        setc(sn, j, g + (spj - g) * mu);
+        setc(wn, j, wj * m + spj * lr);
+    }
+}
+
+// Parameter update applied by the statistics GEMM to the tile it just computed (parked in LDS, row
+// stride BN + 8): W and W_speed are read and written once, S never touches HBM.  The GEMM reads
+// only V2 / P2, so updating W in place under it is safe.  A thread owns one float4 column group and
+// walks rows; 4 rows of loads are in flight per round.
+template <int BM, int BN>
+__device__ __forceinline__ void fused_update_epilogue(const UpdEpi& u, const float* T, int m0, int n0)
+{
+    constexpr int LDT = BN + 8, C4 = BN / 4, RSTEP = GEMM_THREADS / C4, RB = 4;
+    const int c4 = threadIdx.x % C4, rr = threadIdx.x / C4;
+    const int col = n0 + 4 * c4;
+    if (col >= (int)u.ld) return;
+    const float two_lr_l1 = 2.0f * u.lr * u.l1;
+    const float decay = 1.0f - 2.0f * u.lr * u.l2;
+#pragma unroll 1
+    for (int r = rr; r < BM; r += RSTEP * RB) {
+        float4 w[RB], sp[RB], w0[RB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int row = m0 + r + b * RSTEP;
+            if (r + b * RSTEP < BM && row < u.rows) {
+                const int64_t off = (int64_t)row * u.ld + col;
+                w[b] = *reinterpret_cast<const float4*>(u.W + off);
+                sp[b] = *reinterpret_cast<const float4*>(u.Ws + off);
+                w0[b] = u.W0 ? *reinterpret_cast<const float4*>(u.W0 + off) : w[b];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int row = m0 + r + b * RSTEP;
+            if (r + b * RSTEP < BM && row < u.rows) {
+                const int64_t off = (int64_t)row * u.ld + col;
+                const float4 st = *reinterpret_cast<const float4*>(T + (r + b * RSTEP) * LDT + 4 * c4);
+                float4 wn, sn;
+                update_rule4(w[b], sp[b], st, w0[b], u.inv_bs, u.wc, decay, u.l1, two_lr_l1, u.mu, u.lr, wn, sn);
+                *reinterpret_cast<float4*>(u.W + off) = wn;
+                *reinterpret_cast<float4*>(u.Ws + off) = sn;
+            }
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------
@@ -919,19 +1230,7 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
             const float4 w = W[i], st = S[i];
             const float4 wc0 = W0 ? W0[i] : w;
             float4 wn, sn;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float wj = comp(w, j), spj = comp(sp, j);
-                float g = comp(st, j) * inv_bs - wc * comp(wc0, j);
-                float m = decay;
-                if (l1 != 0.0f) {
-                    const float shrink = 1.0f + two_lr_l1 / (fabsf(wj) + 0.001f);
-                    g = g / shrink;
-                    m = decay / shrink;
-                }
-                setc(sn, j, g + (spj - g) * mu);
-                setc(wn, j, wj * m + spj * lr);
-            }
+            update_rule4(w, sp, st, wc0, inv_bs, wc, decay, l1, two_lr_l1, mu, lr, wn, sn);
             W[i] = wn;
             Ws[i] = sn;
         } else if constexpr (DO_PARAMS) {           // lambda_1 == 0 (checked by the host): m = decay

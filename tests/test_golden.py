@@ -60,17 +60,25 @@ TOL = dict(ph_mean=2e-6, nh_mean=5e-6, nv_mean=2e-5, s_h=2e-5, s_v=2e-4, W=2e-6,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused_update", [1, 0], ids=["fused_update", "separate_update"])
 @pytest.mark.parametrize("case", mg.CASES, ids=IDS)
-def test_device_matches_golden(hip_engine, case):
+def test_device_matches_golden(hip_engine, case, fused_update):
+    """Both forms of the single-device step: the update applied inside the statistics GEMM (default;
+    S is then never materialised, so it is only checked in the other mode) and as separate kernels."""
     name = case[0]
-    out = _run_device(hip_engine, case)
+    hip_engine.set_option("fused_update", fused_update)
+    try:
+        out = _run_device(hip_engine, case)
+    finally:
+        hip_engine.set_option("fused_update", 1)
     g = lambda k: GOLD["%s/%s" % (name, k)]
     if out["ph_sample"] is not None:
         assert np.array_equal(out["ph_sample"], g("ph_sample")), "Bernoulli samples differ"
     for key, tol in TOL.items():
         np.testing.assert_allclose(out[key], g(key), rtol=0, atol=tol * max(1.0, np.abs(g(key)).max()), err_msg=key)
-    S = g("S")
-    np.testing.assert_allclose(out["S"], S, rtol=0, atol=1e-5 * max(1.0, np.abs(S).max()), err_msg="S")
+    if not fused_update:
+        S = g("S")
+        np.testing.assert_allclose(out["S"], S, rtol=0, atol=1e-5 * max(1.0, np.abs(S).max()), err_msg="S")
     for t in range(mg.N_STEPS):
         assert abs(out["cost_%d" % t] - g("cost_%d" % t)) <= 1e-5 * abs(g("cost_%d" % t)) + 1e-7
     F = g("free_energy")

@@ -608,3 +608,74 @@ def test_fused_epilogue_equals_unfused(hip_engine, V, H, B):
             assert abs(float(a) - float(b)) <= 2e-6 * abs(float(b)) + 1e-6, name
         else:
             assert np.array_equal(a, b), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,H,B", [(784, 500, 20), (37, 19, 5), (1000, 130, 33), (2050, 70, 64), (300, 2049, 1),
+                                   (16384, 400, 20), (8, 8, 32)])
+def test_skinny_gemm_matches_oracle_and_tile_kernel(hip_engine, V, H, B):
+    """Forward passes of <= 64 rows run on skinny_gemm_kernel (no LDS staging, 8 waves split K,
+    in-block reduction; MI = 1 for <= 32 rows, 2 above).  Pre-activations must match the float64
+    oracle to the f32 accumulation tolerance and the 128-row tile kernel to the same; samples may
+    differ from the tile kernel's only where u is within that tolerance of the mean."""
+    eng = hip_engine
+    rs = np.random.RandomState(V * 7 + H * 3 + B)
+    Wn = (0.05 * rs.randn(V, H)).astype(np.float32)
+    hbn, vbn = (0.1 * rs.randn(H)).astype(np.float32), (0.1 * rs.randn(V)).astype(np.float32)
+    vn = rs.randn(B, V).astype(np.float32)
+    hn = (rs.rand(B, H) < 0.5).astype(np.float32)
+    W, hb, vb, v, hsrc = [eng.to_device(a) for a in (Wn, hbn, vbn, vn, hn)]
+    from mdbn_amd.engine import RngAddr
+    out = {}
+    try:
+        for skinny in (1, 0):
+            eng.set_option("skinny_gemm", skinny)
+            up = eng.propup(v, W, hb, rng=RngAddr(11, 2, 9, 0))
+            dn = eng.propdown(hsrc, W, vb, gauss=False, rng=RngAddr(11, 2, 9, 1), v0=(v > 0).float())
+            out[skinny] = [t.cpu().numpy() for t in up] + [t.cpu().numpy() for t in dn]
+    finally:
+        eng.set_option("skinny_gemm", 1)
+    pre_up = vn.astype(np.float64) @ Wn.astype(np.float64) + hbn
+    pre_dn = hn.astype(np.float64) @ Wn.astype(np.float64).T + vbn
+    tol_up = 4 * ptol(V) * max(1.0, np.abs(pre_up).max())     # pre-activation, not probability
+    tol_dn = 4 * ptol(H) * max(1.0, np.abs(pre_dn).max())
+    for kern in (1, 0):
+        assert np.abs(out[kern][0] - pre_up).max() <= tol_up
+        assert np.abs(out[kern][3] - pre_dn).max() <= tol_dn
+    # samples: identical Philox words; a flip needs u within the rounding band of the mean
+    for (m_i, s_i, tol) in ((1, 2, tol_up), (4, 5, tol_dn)):
+        flips = out[1][s_i] != out[0][s_i]
+        assert flips.mean() <= 1e-3
+        assert np.abs(out[1][m_i] - out[0][m_i]).max() <= tol
+    assert abs(float(out[1][6]) - float(out[0][6])) <= 1e-5 * abs(float(out[0][6])) + 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,H,B", [(4096, 1024, 512), (130, 70, 37), (784, 500, 20), (2050, 258, 64)])
+@pytest.mark.parametrize("hp", [dict(lambda_2=0.1), dict(lambda_1=0.01, lambda_2=0.01), dict(weightcost=2e-4, momentum=0.9)],
+                         ids=["l2", "l1l2", "wc_mu"])
+def test_fused_update_is_bitwise_the_separate_update(hip_engine, V, H, B, hp):
+    """mdbn_cd_train_step applies the weight update inside the statistics GEMM (tile parked in LDS) and
+    the bias / cost half in the finalize kernel; 5 steps must leave every parameter, speed and cost
+    BITWISE equal to the statistics GEMM -> S -> update_kernel sequence."""
+    import mdbn_amd
+    eng = hip_engine
+    rs = np.random.RandomState(5)
+    data = rs.randn(4 * B, V).astype(np.float32)
+    hp = dict(hp)
+    momentum = hp.pop("momentum", 0.5)
+    res = {}
+    try:
+        for fused in (1, 0):
+            eng.set_option("fused_update", fused)
+            rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123),
+                                theano_rng=mdbn_amd.RandomStreams(77), engine=eng)
+            _, up = rbm.get_cost_updates(lr=0.001, k=1, batch_size=B, **hp)
+            fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=eng), data_parallel=None)
+            costs = [float(fn(indexes=np.arange(B) + (t % 4) * B, momentum=momentum)) for t in range(5)]
+            res[fused] = [getattr(rbm, k).get_value() for k in
+                          ("W", "W_speed", "hbias", "hbias_speed", "vbias", "vbias_speed")] + [np.array(costs)]
+    finally:
+        eng.set_option("fused_update", 1)
+    for a, b in zip(res[1], res[0]):
+        assert np.array_equal(a, b)
