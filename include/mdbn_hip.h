@@ -106,7 +106,17 @@ int  mdbn_last_error(char *buf, size_t n);
 int  mdbn_ctx_create(mdbn_ctx **out, int device);
 int  mdbn_ctx_destroy(mdbn_ctx *ctx);
 
-/* Tuning knobs (process-wide).  "gemm_bk": GEMM slice depth, 0 = auto, 32 or 64.
+/* Tuning knobs (process-wide; results never change beyond fp32 summation order).
+ * "gemm_bk": GEMM slice depth, 0 = auto, 32 or 64.
+ * "epilogue_cw": columns per thread of the activation epilogue, 0 = auto, 1, 2 or 4.
+ * "fused_epilogue" (default 1): GEMMs that need no split-K apply bias + activation + sampling to
+ *   their own output tile instead of writing slabs for a second kernel (bitwise the same result).
+ * "fused_update" (default 1): mdbn_cd_train_step applies the weight update inside the statistics
+ *   GEMM when that GEMM is not split; the S block of a->stats is then NOT materialised (s_h, s_v
+ *   and cost_sum are).  Set 0 to get S (bitwise the same parameters either way).
+ * "skinny_gemm" (default 1): forward passes of <= 64 rows use the small-minibatch kernel;
+ *   "skinny_u" (4 | 8) octets per register batch, "skinny_fused_max_k" (default 1024) largest K one
+ *   block streams alone.
  * "update_overlap": 1 = mdbn_cd_train_step overlaps part of the update with the statistics GEMM
  * on a side stream (default 0: measured slower, see csrc/mdbn_capi.hip). */
 int  mdbn_set_option(mdbn_ctx *ctx, const char *name, int64_t value);
@@ -163,8 +173,10 @@ int  mdbn_apply_update(mdbn_ctx *ctx, void *stream, const mdbn_update_args *a);
 int  mdbn_cd_step(mdbn_ctx *ctx, void *stream, const mdbn_cd_args *a);
 
 /* The whole compiled step function for a single device (src/rbm.py:258-376): mdbn_cd_step
- * followed by the update, in one call; results are identical to mdbn_cd_step +
- * mdbn_apply_update.  upd->phase is ignored.  (Option "update_overlap" moves the bias / cost
+ * followed by the update, in one call; parameters, speeds and cost are bitwise identical to
+ * mdbn_cd_step + mdbn_apply_update.  upd->phase is ignored.  With option "fused_update" (default)
+ * the S block of a->stats is left unspecified when the update could be fused into the statistics
+ * GEMM; s_h, s_v and cost_sum are always written.  (Option "update_overlap" moves the bias / cost
  * finalisation and the parameter half of the update onto an internal side stream under the
  * statistics GEMM, which never reads W.) */
 int  mdbn_cd_train_step(mdbn_ctx *ctx, void *stream, const mdbn_cd_args *a,

@@ -125,7 +125,8 @@ Plan plan_gemm(int64_t M, int64_t N, int64_t K)
 static int g_opt_skinny_gemm = 1;
 constexpr int kSkinnyTargetBlocks = 512;   // two 8-wave blocks per CU
 constexpr int kSkinnyMinK = 256;           // >= 4 octets per wave
-constexpr int kSkinnyFusedMaxK = 2048;     // up to here one block streams the whole K range
+static int g_opt_skinny_fused_max_k = 1024;   // up to here one block streams the whole K range
+static int g_opt_skinny_u = 4;                // measured: 8 costs occupancy and loses 3-6%
 
 // Plan of one forward pass (x[M, K] * op(W) -> [M, N], `ldo` columns stored).  M <= 64 (the
 // reference's batch_size = 20 regime): 32-column strips x K ranges for the skinny kernel.
@@ -136,11 +137,12 @@ Plan plan_forward(int64_t M, int64_t N, int64_t K, int64_t ldo)
     p.skinny = 1;
     p.tiles_m = 1;
     p.tiles_n = (int)((ldo + 31) / 32);
-    p.bn = 32; p.bk = 8;
+    p.bn = 32; p.bk = g_opt_skinny_u;       // bk: octets per register batch (M <= 32 only)
     const int64_t want = std::max<int64_t>(1, kSkinnyTargetBlocks / p.tiles_n);
     // a K range per block only pays once the per-wave stream (K / 8) is long: an extra epilogue
     // launch costs ~5 us, 2048 of K cost a wave ~4 us of MFMA issue
-    const int64_t sk = K <= kSkinnyFusedMaxK ? 1 : std::min(want, std::max<int64_t>(1, K / kSkinnyMinK));
+    const bool one_launch = K <= g_opt_skinny_fused_max_k && K <= 64 * (int64_t)p.tiles_n;   // enough strips to spread over
+    const int64_t sk = one_launch ? 1 : std::min(want, std::max<int64_t>(1, K / kSkinnyMinK));
     int64_t kchunk = ((K + sk - 1) / sk + 63) / 64 * 64;
     p.kchunk = (int)kchunk;
     p.splitk = (int)std::max<int64_t>(1, (K + kchunk - 1) / kchunk);
@@ -209,7 +211,7 @@ WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
     }
     if (st.splitk > 1) s.slab = std::max(s.slab, st.slab_floats(V, ldh));
     s.slab = std::max<int64_t>(s.slab, 4 * std::max(ldv, ldh) * 8);
-    s.cost = (((B + 3) / 4) * std::max(ldv, ldh) + 255) / 256 + 64;     // worst case: one column per thread
+    s.cost = std::max<int64_t>(256, (((B + 3) / 4) * std::max(ldv, ldh) + 255) / 256) + 64;   // worst case: one column per thread
     // fused epilogues write one partial per block: 128 x 64 tiles, or 32-column strips (skinny)
     s.cost = std::max<int64_t>(s.cost, ((B + 127) / 128) * ((std::max(ldv, ldh) + 63) / 64) + 64);
     s.cost = std::max<int64_t>(s.cost, (std::max(ldv, ldh) + 31) / 32 + 64);
@@ -399,6 +401,15 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     }
     if (strcmp(name, "skinny_gemm") == 0) {
         g_opt_skinny_gemm = value != 0;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "skinny_fused_max_k") == 0) {
+        g_opt_skinny_fused_max_k = value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "skinny_u") == 0) {
+        if (value != 4 && value != 8) return fail(MDBN_EINVAL, "skinny_u must be 4 or 8");
+        g_opt_skinny_u = value;
         return MDBN_OK;
     }
     if (strcmp(name, "fused_update") == 0) {

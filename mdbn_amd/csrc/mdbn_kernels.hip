@@ -390,8 +390,14 @@ static hipError_t launch_gemm_t(const GemmArgs& g, hipStream_t s)
 {
     // The LDS request is padded past half of the CU's 160 KiB so that exactly one 8-wave
     // block lives on a CU: the jobs then spread evenly over the 256 CUs.
-    constexpr int need_bytes = 2 * (64 * MI + 64 * NI) * (KB + 1) * (int)sizeof(float);
-    constexpr int lds_bytes = need_bytes > 84 * 1024 ? need_bytes : 84 * 1024;
+    constexpr int tile_bytes = 2 * (64 * MI + 64 * NI) * (KB + 1) * (int)sizeof(float);
+    constexpr int park_bytes = FUSED != 0 ? (64 * MI * (64 * NI + 8) + 8) * (int)sizeof(float) : 0;
+    constexpr int need_bytes = tile_bytes > park_bytes ? tile_bytes : park_bytes;
+    // FUSED == 2 with 32-deep slices is the statistics GEMM of a small batch (K = 2B < 128): a few
+    // slices, then a long read-modify-write epilogue -- let two blocks share a CU so one block's
+    // epilogue overlaps the other's loads
+    constexpr bool two_per_cu = FUSED == 2 && KB == 32;
+    constexpr int lds_bytes = two_per_cu ? need_bytes : (need_bytes > 84 * 1024 ? need_bytes : 84 * 1024);
     static bool attr_set = false;
     auto kern = gemm_splitk_kernel<LA, LB, MI, NI, KB, FUSED>;
     if (!attr_set) {
@@ -595,12 +601,12 @@ __device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, 
 // a clamped (valid) address: they only ever reach accumulator rows / columns that are not
 // stored.  The K tail is zero-filled in both operands.
 // ----------------------------------------------------------------------------------
-constexpr int SKINNY_WAVES = 8, SKINNY_U = 4, SKINNY_LDT = 33;
+constexpr int SKINNY_WAVES = 8, SKINNY_LDT = 33;
 
-template <int LB, int MI>
+template <int MI, int U>
 struct SkinnyRegs {
-    float4 a[SKINNY_U][MI];
-    float4 b[SKINNY_U];
+    float4 a[U][MI];
+    float4 b[U];
 };
 
 template <int LB, int MI>
@@ -633,10 +639,10 @@ __device__ __forceinline__ void skinny_load(const GemmArgs& g, const float* cons
     }
 }
 
-template <int LB, int MI, bool FUSED>
+template <int LB, int MI, int U, bool FUSED>
 __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmArgs g)
 {
-    constexpr int NW = SKINNY_WAVES, U = SKINNY_U, LDT = SKINNY_LDT, BM = 32 * MI;
+    constexpr int NW = SKINNY_WAVES, LDT = SKINNY_LDT, BM = 32 * MI;
     extern __shared__ __attribute__((aligned(16))) float smem[];      // [NW][BM][LDT] (+ 8)
     const int strips = g.tiles_n;
     const int ks = blockIdx.x / strips, st = blockIdx.x - ks * strips;
@@ -660,7 +666,7 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmArgs
         for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
 
     // batch = U octets of this wave (octets wave, wave + NW, ...); two register sets
-    SkinnyRegs<LB, MI> r0, r1;
+    SkinnyRegs<MI, U> r0, r1;
 #define SKINNY_LOAD(R, OB)                                                                   \
     do {                                                                                     \
         _Pragma("unroll") for (int u = 0; u < U; ++u) {                                      \
@@ -739,12 +745,12 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmArgs
     }
 }
 
-template <int LB, int MI, bool FUSED>
+template <int LB, int MI, int U, bool FUSED>
 static hipError_t launch_skinny_t(const GemmArgs& g, hipStream_t s)
 {
     constexpr int lds_bytes = (SKINNY_WAVES * 32 * MI * SKINNY_LDT + 8) * (int)sizeof(float);
     static bool attr_set = false;
-    auto kern = skinny_gemm_kernel<LB, MI, FUSED>;
+    auto kern = skinny_gemm_kernel<LB, MI, U, FUSED>;
     if (!attr_set && lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -759,11 +765,15 @@ hipError_t launch_skinny_gemm(int lb, const GemmArgs& g, hipStream_t s)
 {
     if (g.M < 1 || g.M > 64 || g.kchunk % 8 != 0 || (g.fused && g.splitk != 1)) return hipErrorInvalidValue;
     const int mi = g.M <= 32 ? 1 : 2;
-#define SKINNY_CASE(LBV, MIV, FV) if (lb == LBV && mi == MIV && (g.fused != 0) == FV) return launch_skinny_t<LBV, MIV, FV>(g, s)
-    SKINNY_CASE(LAY_K, 1, true);  SKINNY_CASE(LAY_K, 1, false);
-    SKINNY_CASE(LAY_K, 2, true);  SKINNY_CASE(LAY_K, 2, false);
-    SKINNY_CASE(LAY_MN, 1, true); SKINNY_CASE(LAY_MN, 1, false);
-    SKINNY_CASE(LAY_MN, 2, true); SKINNY_CASE(LAY_MN, 2, false);
+    const int u = mi == 1 ? g.bk : 4;          // octets per register batch (plan: 4 or 8; MI = 2 has the registers for 4)
+#define SKINNY_CASE(LBV, MIV, UV, FV) \
+    if (lb == LBV && mi == MIV && u == UV && (g.fused != 0) == FV) return launch_skinny_t<LBV, MIV, UV, FV>(g, s)
+    SKINNY_CASE(LAY_K, 1, 4, true);  SKINNY_CASE(LAY_K, 1, 4, false);
+    SKINNY_CASE(LAY_K, 1, 8, true);  SKINNY_CASE(LAY_K, 1, 8, false);
+    SKINNY_CASE(LAY_K, 2, 4, true);  SKINNY_CASE(LAY_K, 2, 4, false);
+    SKINNY_CASE(LAY_MN, 1, 4, true); SKINNY_CASE(LAY_MN, 1, 4, false);
+    SKINNY_CASE(LAY_MN, 1, 8, true); SKINNY_CASE(LAY_MN, 1, 8, false);
+    SKINNY_CASE(LAY_MN, 2, 4, true); SKINNY_CASE(LAY_MN, 2, 4, false);
 #undef SKINNY_CASE
     return hipErrorInvalidValue;
 }
@@ -832,14 +842,15 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
                 }
             }
         } else {
-            // any split count: 8 slabs x 4 rows of loads in flight per round (a load-add-load-add
+            // any split count: 16 / CW slabs x 4 rows of loads in flight per round (a load-add-load-add
             // chain costs one memory latency per slab: 76 us at 36 slabs), summed in slab order
-            for (int s0 = 0; s0 < e.nsplit; s0 += 8) {
-                float v[4][8][CW];
+            constexpr int SB = 16 / CW;               // slabs per round: 64 loaded floats per thread in flight
+            for (int s0 = 0; s0 < e.nsplit; s0 += SB) {
+                float v[4][SB][CW];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < SB; ++u) {
 #pragma unroll
                         for (int j = 0; j < CW; ++j) v[r][u][j] = 0.f;
                         if (r0 + r < e.rows && s0 + u < e.nsplit)
@@ -848,7 +859,7 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
+                    for (int u = 0; u < SB; ++u)
 #pragma unroll
                         for (int j = 0; j < CW; ++j) pre[r][j] += v[r][u][j];
             }
@@ -922,23 +933,34 @@ void set_epilogue_cw(int cw) { g_epilogue_cw = cw; }
 int epilogue_cw(int64_t rows, int64_t ld)
 {
     if (g_epilogue_cw) return g_epilogue_cw;
-    // enough 4-wide threads to fill the chip several times over? then keep float4 traffic
-    const int64_t threads4 = ((rows + 3) / 4) * (ld / 4);
-    return threads4 >= 8 * 256 * 256 ? 4 : 2;
+    // enough 4-wide threads to fill the chip several times over? then keep float4 traffic;
+    // small outputs take narrower threads so that more CUs share the slab reads
+    const int64_t quads = (rows + 3) / 4;
+    if (quads * (ld / 4) >= 8 * 256 * 256) return 4;
+    return quads * (ld / 2) >= 64 * 256 ? 2 : 1;
+}
+
+// threads per block: a small output (a 20-row minibatch) is spread over 64-thread blocks -- with
+// 256-thread blocks 4 CUs would read all the split-K slabs (12 us for 37 slabs of 20 x 400)
+static int epilogue_threads(int64_t rows, int64_t ld)
+{
+    const int64_t n = ((rows + 3) / 4) * (ld / epilogue_cw(rows, ld));
+    return n <= 64 * 256 ? 64 : 256;
 }
 
 int epilogue_blocks(int64_t rows, int64_t ld)
 {
-    const int cw = epilogue_cw(rows, ld);
+    const int cw = epilogue_cw(rows, ld), t = epilogue_threads(rows, ld);
     const int64_t n = ((rows + 3) / 4) * (ld / cw);
-    return (int)((n + 255) / 256);
+    return (int)((n + t - 1) / t);
 }
 
 template <int CW>
 static void launch_act_epilogue_cw(const EpiArgs& e, hipStream_t s)
 {
     const int64_t n = ((int64_t)(e.rows + 3) / 4) * (e.ld / CW);
-    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    const int t = epilogue_threads(e.rows, e.ld);
+    const dim3 grid((unsigned)((n + t - 1) / t)), block(t);
     switch (e.nsplit) {
         case 1: hipLaunchKernelGGL((act_epilogue_kernel<1, CW>), grid, block, 0, s, e); break;
         case 2: hipLaunchKernelGGL((act_epilogue_kernel<2, CW>), grid, block, 0, s, e); break;

@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into per-kernel HBM bytes per launch.
+    python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <note>
+Correction (MI355X_MICROARCH.md, HBM / rocprofv3): gfx950 FETCH_SIZE reports half of wide coalesced
+streaming reads -> fetch bytes = 2 * FETCH_SIZE[KB] * 1024; WRITE_SIZE[KB] * 1024 as is."""
+import csv, json, re, sys, collections
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    per_dispatch = collections.defaultdict(float)
+    names = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        d = r["Dispatch_Id"]
+        per_dispatch[d] += float(r["Counter_Value"])
+        names[d] = r["Kernel_Name"]
+    for d, v in per_dispatch.items():
+        n = re.sub(r"\(.*$", "", names[d]).replace("void ", "")
+        acc[n][0] += v; acc[n][1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+out = {"source": sys.argv[4],
+       "correction": "gfx950: fetch bytes = 2 * FETCH_SIZE KB * 1024; write bytes = WRITE_SIZE KB * 1024 (MI355X_MICROARCH.md, HBM)",
+       "per_launch_bytes": {}}
+gemm_bytes = gemm_n = 0
+for k in sorted(set(fetch) | set(write)):
+    if not k.startswith("mdbn::"):
+        continue
+    f = 2 * 1024 * fetch.get(k, (0, 0))[0]
+    w = 1024 * write.get(k, (0, 0))[0]
+    n = max(fetch.get(k, (0, 0))[1], write.get(k, (0, 0))[1])
+    out["per_launch_bytes"][k] = {"fetch": f, "write": w, "total": f + w, "launches": n}
+    if "gemm" in k:
+        gemm_bytes += (f + w) * n; gemm_n += n
+out["gemm_avg_bytes_per_launch"] = gemm_bytes / max(gemm_n, 1)
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out, indent=1))
