@@ -114,9 +114,9 @@ int  mdbn_ctx_destroy(mdbn_ctx *ctx);
  * "fused_update" (default 1): mdbn_cd_train_step applies the weight update inside the statistics
  *   GEMM when that GEMM is not split; the S block of a->stats is then NOT materialised (s_h, s_v
  *   and cost_sum are).  Set 0 to get S (bitwise the same parameters either way).
- * "skinny_gemm" (default 1): forward passes of <= 64 rows use the small-minibatch kernel;
- *   "skinny_u" (4 | 8) octets per register batch, "skinny_fused_max_k" (default 1024) largest K one
- *   block streams alone.
+ * "skinny_gemm" (default 1): GEMMs of <= 64 output rows, and tiny GEMMs at any row count, use the
+ *   register-streaming kernel (no LDS staging); "skinny_fused_max_k" (default 1024) largest K one
+ *   block streams alone, "skinny_max_macs" (default 32 Mi) size limit above 64 rows.
  * "update_overlap": 1 = mdbn_cd_train_step overlaps part of the update with the statistics GEMM
  * on a side stream (default 0: measured slower, see csrc/mdbn_capi.hip). */
 int  mdbn_set_option(mdbn_ctx *ctx, const char *name, int64_t value);

@@ -85,13 +85,14 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 struct Plan {
     int tiles_m, tiles_n, splitk, kchunk, bn, bk;
-    int skinny = 0;        // M <= 64: skinny_gemm_kernel (tiles_n = 32-column strips)
+    int skinny = 0;        // skinny_gemm_kernel: tiles_m x tiles_n = (32*mi)-row tiles x 32-column strips
+    int mi = 1;
     int64_t slab_floats(int64_t M, int64_t ldc) const { return (int64_t)splitk * M * ldc; }
     void fill(GemmArgs& g) const
     {
         g.kchunk = kchunk; g.splitk = splitk; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.bn = bn; g.bk = bk;
         g.inner_m = tiles_m <= tiles_n;
-        g.skinny = skinny; g.fused = 0;
+        g.skinny = skinny; g.mi = mi; g.fused = 0;
     }
 };
 
@@ -121,32 +122,65 @@ Plan plan_gemm(int64_t M, int64_t N, int64_t K)
     return p;
 }
 
-// mdbn_set_option("skinny_gemm"): route forward passes of <= 64 rows to skinny_gemm_kernel (default on)
+// mdbn_set_option("skinny_gemm"): route GEMMs of <= 64 output rows, and small-layer GEMMs whose
+// operands are L2-resident, to the register-streaming skinny_gemm_kernel (default on)
 static int g_opt_skinny_gemm = 1;
 constexpr int kSkinnyTargetBlocks = 512;   // two 8-wave blocks per CU
 constexpr int kSkinnyMinK = 256;           // >= 4 octets per wave
 static int g_opt_skinny_fused_max_k = 1024;   // up to here one block streams the whole K range
-static int g_opt_skinny_u = 4;                // measured: 8 costs occupancy and loses 3-6%
+// Above 64 rows the streaming kernel only pays for problems so small that the chain of dependent
+// launches is the whole cost; every register batch exposes an L2 latency, so long per-wave K
+// streams (K > 512) get a third of the budget.  Measured at B = 512 (scripts/skinny_macs_ab.py):
+// 400->40 76 -> 52 us, 256->200 72 -> 48, 100->128 69 -> 41, 512->40 CD-5 164 -> 124; 1024->256
+// (134 M MACs per pass) 76 either way; 256x200 statistics over K = 1024 (52 M) 5 us slower.
+static int64_t g_opt_skinny_max_macs = 32ll << 20;
 
-// Plan of one forward pass (x[M, K] * op(W) -> [M, N], `ldo` columns stored).  M <= 64 (the
-// reference's batch_size = 20 regime): 32-column strips x K ranges for the skinny kernel.
-Plan plan_forward(int64_t M, int64_t N, int64_t K, int64_t ldo)
+// Skinny plan of out[M, N (ldo stored)] over K: (32*mi)-row tiles x 32-column strips x K ranges.
+Plan plan_skinny(int64_t M, int64_t K, int64_t ldo, bool allow_split)
 {
-    if (!g_opt_skinny_gemm || M > 64) return plan_gemm(M, N, K);
     Plan p;
     p.skinny = 1;
-    p.tiles_m = 1;
+    p.mi = M <= 32 ? 1 : 2;
+    p.tiles_m = (int)((M + 32 * p.mi - 1) / (32 * p.mi));
     p.tiles_n = (int)((ldo + 31) / 32);
-    p.bn = 32; p.bk = g_opt_skinny_u;       // bk: octets per register batch (M <= 32 only)
-    const int64_t want = std::max<int64_t>(1, kSkinnyTargetBlocks / p.tiles_n);
+    p.bn = 32; p.bk = 8;
+    const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
+    const int64_t want = std::max<int64_t>(1, kSkinnyTargetBlocks / blocks);
     // a K range per block only pays once the per-wave stream (K / 8) is long: an extra epilogue
-    // launch costs ~5 us, 2048 of K cost a wave ~4 us of MFMA issue
-    const bool one_launch = K <= g_opt_skinny_fused_max_k && K <= 64 * (int64_t)p.tiles_n;   // enough strips to spread over
+    // launch costs ~5 us, 1024 of K cost a wave ~2 us of MFMA issue
+    const bool one_launch = !allow_split || (K <= g_opt_skinny_fused_max_k && K <= 64 * blocks);
     const int64_t sk = one_launch ? 1 : std::min(want, std::max<int64_t>(1, K / kSkinnyMinK));
     int64_t kchunk = ((K + sk - 1) / sk + 63) / 64 * 64;
     p.kchunk = (int)kchunk;
     p.splitk = (int)std::max<int64_t>(1, (K + kchunk - 1) / kchunk);
     return p;
+}
+
+// Does the register-streaming kernel serve out[M, N] over K better than the LDS-tiled one?  Yes for
+// <= 64 rows (no operand reuse to stage for), and for tiny problems, where one launch with a fused
+// epilogue beats GEMM + slabs + epilogue kernel and every operand re-read stays in L2.
+bool prefer_skinny(int64_t M, int64_t N, int64_t K)
+{
+    if (!g_opt_skinny_gemm) return false;
+    if (M <= 64) return true;
+    if (K > g_opt_skinny_fused_max_k) return false;
+    const int64_t tiles_m = (M + 63) / 64, strips = (N + 31) / 32;
+    if (K > 64 * tiles_m * strips) return false;
+    return M * N * K <= (K <= 512 ? 3 : 1) * g_opt_skinny_max_macs;
+}
+
+// Plan of one forward pass (x[M, K] * op(W) -> [M, N], `ldo` columns stored).
+Plan plan_forward(int64_t M, int64_t N, int64_t K, int64_t ldo)
+{
+    if (!prefer_skinny(M, N, K)) return plan_gemm(M, N, K);
+    return plan_skinny(M, K, ldo, M <= 64);
+}
+
+// Plan of the statistics GEMM S[V, H] = V2^T P2 over K = 2B.
+Plan plan_stats(int64_t V, int64_t H, int64_t K2, int64_t ldh)
+{
+    if (!prefer_skinny(V, H, K2) || V <= 64) return plan_gemm(V, H, K2);
+    return plan_skinny(V, K2, ldh, false);
 }
 
 static unsigned long long* g_stamps = nullptr;     // diagnostic builds only
@@ -214,7 +248,7 @@ WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
     s.cost = std::max<int64_t>(256, (((B + 3) / 4) * std::max(ldv, ldh) + 255) / 256) + 64;   // worst case: one column per thread
     // fused epilogues write one partial per block: 128 x 64 tiles, or 32-column strips (skinny)
     s.cost = std::max<int64_t>(s.cost, ((B + 127) / 128) * ((std::max(ldv, ldh) + 63) / 64) + 64);
-    s.cost = std::max<int64_t>(s.cost, (std::max(ldv, ldh) + 31) / 32 + 64);
+    s.cost = std::max<int64_t>(s.cost, ((B + 63) / 64) * ((std::max(ldv, ldh) + 31) / 32) + 64);
     const int ng = row_groups(B);
     s.colP = 2 * (int64_t)ng * ldh;
     s.colV = (int64_t)ng * ldv;
@@ -407,9 +441,8 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
         g_opt_skinny_fused_max_k = value;
         return MDBN_OK;
     }
-    if (strcmp(name, "skinny_u") == 0) {
-        if (value != 4 && value != 8) return fail(MDBN_EINVAL, "skinny_u must be 4 or 8");
-        g_opt_skinny_u = value;
+    if (strcmp(name, "skinny_max_macs") == 0) {
+        g_opt_skinny_max_macs = value;
         return MDBN_OK;
     }
     if (strcmp(name, "fused_update") == 0) {
@@ -562,7 +595,7 @@ int mdbn_cd_stats(mdbn_ctx* ctx, void* stream, const float* V2, const float* P2,
     HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, ng, ldh, ldv, nullptr, 0, s_h, s_v, cost, nullptr, s));
 
     // S = [v0 ; nv]^T [ph ; -nh]  : one GEMM over the stacked batch dimension (K = 2B)
-    const Plan p = plan_gemm(V, H, 2 * B);
+    const Plan p = plan_stats(V, H, 2 * B, ldh);
     GemmArgs g;
     g.A = V2; g.lda = ldv; g.B = P2; g.ldb = ldh;
     g.ldc = ldh; g.slab_stride = V * ldh;
@@ -698,7 +731,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         HIP_OK(launch_update(u, ctx->side));
         HIP_OK(hipEventRecord(ctx->ev_join, ctx->side));
     }
-    const Plan p = plan_gemm(V, H, 2 * B);
+    const Plan p = plan_stats(V, H, 2 * B, ldh);
     // Single device, unsplit statistics GEMM: the GEMM applies the weight update to its own tiles
     // (S never reaches HBM) and the bias / cost half rides on the finalize kernel -- no update launch.
     const bool fuse_upd = upd && !overlap && g_opt_fused_update && p.splitk == 1;

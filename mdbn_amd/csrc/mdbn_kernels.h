@@ -59,7 +59,9 @@ struct GemmArgs {
     int bk;                // slice depth along the reduction index (32 or 64; 64 only with bn = 128)
     int inner_m;           // work-list order inside one split: 1 = tile_m fastest
     unsigned long long* stamps;   // diagnostic builds only (-DMDBN_STAMP); NULL otherwise
-    int skinny;            // 1: M <= 64 -> skinny_gemm_kernel (tiles_n = 32-column strips, splitk = K ranges)
+    int skinny;            // 1: skinny_gemm_kernel (tiles_n = 32-column strips, tiles_m = (32*mi)-row tiles,
+                           //    splitk = K ranges, kchunk % 8 == 0)
+    int mi;                // skinny: 32-row blocks per tile (1 | 2)
     int fused;             // no split-K and an epilogue runs on the block's own output tile:
                            //   1 = activation (epi), 2 = parameter update (upd; statistics GEMM, C is not written)
     EpiArgs epi;           // fused == 1 (slabs / nsplit unused; one cost partial per block)

@@ -420,11 +420,11 @@ static hipError_t launch_gemm_l(const GemmArgs& g, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_skinny_gemm(int lb, const GemmArgs& g, hipStream_t s);
+hipError_t launch_skinny_gemm(int la, int lb, const GemmArgs& g, hipStream_t s);
 
 hipError_t launch_gemm(int la, int lb, const GemmArgs& g, hipStream_t s)
 {
-    if (g.skinny) return la == LAY_K ? launch_skinny_gemm(lb, g, s) : hipErrorInvalidValue;
+    if (g.skinny) return launch_skinny_gemm(la, lb, g, s);
     if (g.fused) {      // forward passes fuse the activation, the statistics GEMM the update (separate
                         // instantiations: the unfused kernels keep their register allocation)
         if (g.splitk != 1) return hipErrorInvalidValue;
@@ -513,6 +513,75 @@ __device__ __forceinline__ void setc(float4& v, int j, float x)
 // 4-row groups -- one Philox4x32-10 block per (group, column), as everywhere.  One cost partial
 // per block (cost_partials[blockIdx.x]); column partials [row_group][col] as below.
 // ----------------------------------------------------------------------------------
+// The update rule (rbm.py:347-365) on 4 weights, shared by update_kernel and the fused epilogues of
+// the statistics GEMM.  Floating-point contraction is switched off inside these helpers (hipcc
+// otherwise fuses a*b+c into an fma or not depending on what the helper is inlined into -- the
+// __f*_rn intrinsics are plain operators to it), so every call site agrees bit for bit, and with the
+// float32 restatement, which rounds every operation.
+__device__ __forceinline__ float upd_grad(float st, float inv_bs, float wc, float w0)
+{
+#pragma clang fp contract(off)
+    const float a = st * inv_bs, b = wc * w0;
+    return a - b;
+}
+__device__ __forceinline__ float upd_speed(float g, float sp, float mu)     // g + (s - g) * mu
+{
+#pragma clang fp contract(off)
+    const float d = sp - g;
+    const float e = d * mu;
+    return g + e;
+}
+__device__ __forceinline__ float upd_param(float w, float m, float sp, float lr)   // w * m + s_old * lr
+{
+#pragma clang fp contract(off)
+    const float a = w * m, b = sp * lr;
+    return a + b;
+}
+__device__ __forceinline__ float upd_scale(float x, float s)
+{
+#pragma clang fp contract(off)
+    return x * s;
+}
+__device__ __forceinline__ float upd_decay(float lr, float l2)          // 1 - 2 lr l2
+{
+#pragma clang fp contract(off)
+    const float a = 2.0f * lr;
+    const float b = a * l2;
+    return 1.0f - b;
+}
+__device__ __forceinline__ float upd_two_lr_l1(float lr, float l1)
+{
+#pragma clang fp contract(off)
+    const float a = 2.0f * lr;
+    return a * l1;
+}
+__device__ __forceinline__ float upd_shrink(float two_lr_l1, float w)    // 1 + 2 lr l1 / (|w| + eps)
+{
+#pragma clang fp contract(off)
+    const float d = fabsf(w) + 0.001f;
+    const float q = __fdiv_rn(two_lr_l1, d);
+    return 1.0f + q;
+}
+
+__device__ __forceinline__ void update_rule4(const float4& w, const float4& sp, const float4& st, const float4& wc0,
+                                             float inv_bs, float wc, float decay, float l1, float two_lr_l1,
+                                             float mu, float lr, float4& wn, float4& sn)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float wj = comp(w, j), spj = comp(sp, j);
+        float g = upd_grad(comp(st, j), inv_bs, wc, comp(wc0, j));
+        float m = decay;
+        if (l1 != 0.0f) {
+            const float shrink = upd_shrink(two_lr_l1, wj);
+            g = __fdiv_rn(g, shrink);
+            m = __fdiv_rn(decay, shrink);
+        }
+        setc(sn, j, upd_speed(g, spj, mu));
+        setc(wn, j, upd_param(wj, m, spj, lr));
+    }
+}
+
 // One (4-row group, column) of an activation epilogue: x[j] = pre-activation (bias included) of
 // row r0 + j.  Stores pre / mean / sample, the group's column partial, and adds to `cost`.
 __device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, float x2, float x3, int r0, int col, bool live, float& cost)
@@ -585,77 +654,80 @@ __device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, 
 }
 
 // ----------------------------------------------------------------------------------
-// Skinny GEMM: out[M <= 32*MI, N] = x[M, K] * op(W) for the small minibatches the reference
-// trains with (batch_size 20, dbn.py / MDBN.py).  At M <= 32 a weight is used by exactly ONE
-// MFMA, so staging W through LDS buys nothing and a 128-row tile wastes >= 75% of the matrix
-// pipe on zero rows (W then streams at 1/4 of the HBM rate).  Here a block owns a 32-column
-// strip and a K range; its 8 waves take interleaved K-octets, load the MFMA operands straight
-// from global memory (one float4 per lane per operand and octet; register double-buffered one
-// batch of 4 octets ahead), and their partial 32x32 accumulators are reduced through LDS in
-// wave order (deterministic).  MFMA rate at M <= 32 equals ~8.6 TB/s of W: the pass is bound
-// by HBM / L2, as a batched GEMV should be.
-//   A (x)  : [M][lda], K contiguous.    lane (i, h) <- x[i][k8 + 4h .. +3]
-//   B LAY_K : W[N][ldb], K contiguous.  lane (i, h) <- W[n0 + i][k8 + 4h .. +3]      (down pass)
-//   B LAY_MN: W[K][ldb], N contiguous.  lane (i, h) <- W[k8 + 4h + t][n0 + i], t<4   (up pass)
-// MFMA t of an octet multiplies the k-pair {k8 + t, k8 + 4 + t}.  Rows >= M / columns >= N read
-// a clamped (valid) address: they only ever reach accumulator rows / columns that are not
-// stored.  The K tail is zero-filled in both operands.
+// Register-streaming ("skinny") GEMM: no LDS staging, operands go from global memory / L2
+// straight into the MFMA operand registers.  Two regimes use it:
+//  * minibatches of <= 64 rows (the reference trains with batch_size 20, dbn.py / MDBN.py): at
+//    M <= 32 a weight is used by exactly ONE MFMA, so staging W through LDS buys nothing and a
+//    128-row tile wastes >= 75% of the matrix pipe on zero rows (W then streams at 1/4 of the HBM
+//    rate).  MFMA issue at M <= 32 equals ~8.6 TB/s of W: the pass is HBM / latency bound, as a
+//    batched GEMV should be.
+//  * small layers at any batch size (operands L2-resident, too few 128x128 tiles to fill the chip
+//    without split-K): one launch with a fused epilogue replaces GEMM + slabs + epilogue kernel.
+// A block owns a (32*MI)-row x 32-column output tile and a K range; its 8 waves take interleaved
+// K-octets, keep one batch of 4 octets of loads in flight ahead of the MFMAs (two register sets),
+// and reduce their partial accumulators through LDS in wave order (deterministic).  Epilogues on
+// the reduced tile: none (split-K slab / plain C), FUSED 1 = bias + activation + sampling
+// (act_quad), FUSED 2 = the parameter update (statistics GEMM, update_rule4).
+//   LAY_K  operand X[rows][ld], K contiguous : lane (i, h) <- X[r0 + i][k8 + 4h .. +3]  (one float4)
+//   LAY_MN operand X[K][ld], rows contiguous : lane (i, h) <- X[k8 + 4h + t][r0 + i], t < 4
+// MFMA t of an octet multiplies the k-pair {k8 + t, k8 + 4 + t}.  Rows >= M / columns >= N read a
+// clamped (valid) address: they only reach accumulator rows / columns that are never stored.  The
+// K tail is zero-filled in both operands.
 // ----------------------------------------------------------------------------------
-constexpr int SKINNY_WAVES = 8, SKINNY_LDT = 33;
+constexpr int SKINNY_WAVES = 8, SKINNY_LDT = 33, SKINNY_U = 4;
 
-template <int MI, int U>
+template <int MI>
 struct SkinnyRegs {
-    float4 a[U][MI];
-    float4 b[U];
+    float4 a[SKINNY_U][MI];
+    float4 b[SKINNY_U];
 };
 
-template <int LB, int MI>
-__device__ __forceinline__ void skinny_load(const GemmArgs& g, const float* const (&arow)[MI], const float* bptr,
-                                            int k8, int kend, int h, float4 (&ra)[MI], float4& rb)
+template <int LAY>
+__device__ __forceinline__ float4 skinny_load_operand(const float* p, int64_t ld, int k, int kend, bool full)
 {
-    const int k = k8 + 4 * h;
-    if (k8 + 8 <= kend) {
-#pragma unroll
-        for (int a = 0; a < MI; ++a) ra[a] = *reinterpret_cast<const float4*>(arow[a] + k);
-        if (LB == LAY_K) {
-            rb = *reinterpret_cast<const float4*>(bptr + k);
+    float4 r;
+    if (full) {
+        if (LAY == LAY_K) {
+            r = *reinterpret_cast<const float4*>(p + k);
         } else {
-            const float* p = bptr + (int64_t)k * g.ldb;
-            rb.x = p[0]; rb.y = p[g.ldb]; rb.z = p[2 * g.ldb]; rb.w = p[3 * g.ldb];
+            const float* q = p + (int64_t)k * ld;
+            r.x = q[0]; r.y = q[ld]; r.z = q[2 * ld]; r.w = q[3 * ld];
         }
     } else {        // K tail: component guards, zero fill
-        float va[MI][4], vb[4];
+        float v[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const bool ok = k + t < kend;
-#pragma unroll
-            for (int a = 0; a < MI; ++a) va[a][t] = ok ? arow[a][k + t] : 0.f;
-            if (LB == LAY_K) vb[t] = ok ? bptr[k + t] : 0.f;
-            else vb[t] = ok ? bptr[(int64_t)(k + t) * g.ldb] : 0.f;
+            if (LAY == LAY_K) v[t] = ok ? p[k + t] : 0.f;
+            else v[t] = ok ? p[(int64_t)(k + t) * ld] : 0.f;
         }
-#pragma unroll
-        for (int a = 0; a < MI; ++a) ra[a] = make_float4(va[a][0], va[a][1], va[a][2], va[a][3]);
-        rb = make_float4(vb[0], vb[1], vb[2], vb[3]);
+        r = make_float4(v[0], v[1], v[2], v[3]);
     }
+    return r;
 }
 
-template <int LB, int MI, int U, bool FUSED>
+template <int LA, int LB, int MI, int FUSED>
 __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmArgs g)
 {
-    constexpr int NW = SKINNY_WAVES, LDT = SKINNY_LDT, BM = 32 * MI;
+    constexpr int NW = SKINNY_WAVES, U = SKINNY_U, LDT = SKINNY_LDT, BM = 32 * MI;
     extern __shared__ __attribute__((aligned(16))) float smem[];      // [NW][BM][LDT] (+ 8)
-    const int strips = g.tiles_n;
-    const int ks = blockIdx.x / strips, st = blockIdx.x - ks * strips;
-    const int n0 = st * 32;
+    // block -> (K range, row tile, 32-column strip), strips fastest
+    const int per_split = g.tiles_n * g.tiles_m;
+    const int ks = blockIdx.x / per_split, rem = blockIdx.x - ks * per_split;
+    const int tm = rem / g.tiles_n, st = rem - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = st * 32;
     const int kbeg = ks * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int noct = (kend - kbeg + 7) >> 3;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
 
-    const float* arow[MI];
+    const float* aptr[MI];
 #pragma unroll
-    for (int a = 0; a < MI; ++a) arow[a] = g.A + (int64_t)min(i + 32 * a, g.M - 1) * g.lda;
+    for (int a = 0; a < MI; ++a) {
+        const int am = min(m0 + i + 32 * a, g.M - 1);
+        aptr[a] = LA == LAY_K ? g.A + (int64_t)am * g.lda : g.A + am;
+    }
     const int bn = min(n0 + i, g.N - 1);
     const float* bptr = LB == LAY_K ? g.B + (int64_t)bn * g.ldb : g.B + bn;
 
@@ -666,12 +738,18 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmArgs
         for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
 
     // batch = U octets of this wave (octets wave, wave + NW, ...); two register sets
-    SkinnyRegs<MI, U> r0, r1;
+    SkinnyRegs<MI> r0, r1;
 #define SKINNY_LOAD(R, OB)                                                                   \
     do {                                                                                     \
         _Pragma("unroll") for (int u = 0; u < U; ++u) {                                      \
             const int o = (OB) + u * NW;                                                     \
-            if (o < noct) skinny_load<LB, MI>(g, arow, bptr, kbeg + 8 * o, kend, h, R.a[u], R.b[u]); \
+            if (o < noct) {                                                                  \
+                const int k8 = kbeg + 8 * o;                                                 \
+                const bool full = k8 + 8 <= kend;                                            \
+                _Pragma("unroll") for (int a = 0; a < MI; ++a)                               \
+                    R.a[u][a] = skinny_load_operand<LA>(aptr[a], g.lda, k8 + 4 * h, kend, full); \
+                R.b[u] = skinny_load_operand<LB>(bptr, g.ldb, k8 + 4 * h, kend, full);       \
+            }                                                                                \
         }                                                                                    \
     } while (0)
 #define SKINNY_MMA(R, OB)                                                                    \
@@ -708,7 +786,7 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmArgs
             T[(32 * a + (e & 3) + 8 * (e >> 2) + 4 * h) * LDT + i] = acc[a][e];
     __syncthreads();
 
-    const int q = threadIdx.x;                 // quad = (row group, column) of the strip
+    const int q = threadIdx.x;                 // quad = (row group, column) of the tile
     const int rg = q >> 5, c = q & 31;
     const int col = n0 + c;
     float cost = 0.f;
@@ -721,8 +799,8 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmArgs
             for (int w = 0; w < NW; ++w) sum += smem[w * (BM * LDT) + (4 * rg + j) * LDT + c];
             x[j] = sum;
         }
-        const int r0w = 4 * rg;
-        if (FUSED) {
+        const int r0w = m0 + 4 * rg;
+        if constexpr (FUSED == 1) {
             const EpiArgs& e = g.epi;
             const bool live = col < e.cols;
             if (r0w < e.rows && col < (int)e.ld) {
@@ -731,6 +809,31 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmArgs
                 for (int j = 0; j < 4; ++j) x[j] += bias;
                 act_quad(e, x[0], x[1], x[2], x[3], r0w, col, live, cost);
             }
+        } else if constexpr (FUSED == 2) {
+            const UpdEpi& u = g.upd;
+            if (r0w < u.rows && col < (int)u.ld) {
+                float wv[4], sv[4], w0v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = r0w + j < u.rows;
+                    const int64_t off = (int64_t)(ok ? r0w + j : r0w) * u.ld + col;
+                    wv[j] = u.W[off];
+                    sv[j] = u.Ws[off];
+                    w0v[j] = u.W0 ? u.W0[off] : wv[j];
+                    if (col >= g.N) x[j] = 0.f;            // pad columns: S is exactly zero there
+                }
+                float4 wn, sn;
+                update_rule4(make_float4(wv[0], wv[1], wv[2], wv[3]), make_float4(sv[0], sv[1], sv[2], sv[3]),
+                             make_float4(x[0], x[1], x[2], x[3]), make_float4(w0v[0], w0v[1], w0v[2], w0v[3]),
+                             u.inv_bs, u.wc, upd_decay(u.lr, u.l2), u.l1, upd_two_lr_l1(u.lr, u.l1), u.mu, u.lr, wn, sn);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (r0w + j < u.rows) {
+                        const int64_t off = (int64_t)(r0w + j) * u.ld + col;
+                        u.W[off] = comp(wn, j);
+                        u.Ws[off] = comp(sn, j);
+                    }
+            }
         } else {
             float* C = g.C + (int64_t)ks * g.slab_stride;
 #pragma unroll
@@ -738,42 +841,45 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmArgs
                 if (r0w + j < g.M && col < g.Nst) C[(int64_t)(r0w + j) * g.ldc + col] = col < g.N ? x[j] : 0.f;
         }
     }
-    if (FUSED && g.epi.cost_partials) {
-        __syncthreads();
-        const float tot = block_sum(cost, smem);
-        if (threadIdx.x == 0) g.epi.cost_partials[blockIdx.x] = tot;
+    if constexpr (FUSED == 1) {
+        if (g.epi.cost_partials) {
+            __syncthreads();
+            const float tot = block_sum(cost, smem);
+            if (threadIdx.x == 0) g.epi.cost_partials[blockIdx.x] = tot;
+        }
     }
 }
 
-template <int LB, int MI, int U, bool FUSED>
+template <int LA, int LB, int MI, int FUSED>
 static hipError_t launch_skinny_t(const GemmArgs& g, hipStream_t s)
 {
     constexpr int lds_bytes = (SKINNY_WAVES * 32 * MI * SKINNY_LDT + 8) * (int)sizeof(float);
     static bool attr_set = false;
-    auto kern = skinny_gemm_kernel<LB, MI, U, FUSED>;
+    auto kern = skinny_gemm_kernel<LA, LB, MI, FUSED>;
     if (!attr_set && lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(g.tiles_n * g.splitk), dim3(64 * SKINNY_WAVES), lds_bytes, s, g);
+    hipLaunchKernelGGL(kern, dim3(g.tiles_n * g.tiles_m * g.splitk), dim3(64 * SKINNY_WAVES), lds_bytes, s, g);
     return hipGetLastError();
 }
 
-hipError_t launch_skinny_gemm(int lb, const GemmArgs& g, hipStream_t s)
+hipError_t launch_skinny_gemm(int la, int lb, const GemmArgs& g, hipStream_t s)
 {
-    if (g.M < 1 || g.M > 64 || g.kchunk % 8 != 0 || (g.fused && g.splitk != 1)) return hipErrorInvalidValue;
-    const int mi = g.M <= 32 ? 1 : 2;
-    const int u = mi == 1 ? g.bk : 4;          // octets per register batch (plan: 4 or 8; MI = 2 has the registers for 4)
-#define SKINNY_CASE(LBV, MIV, UV, FV) \
-    if (lb == LBV && mi == MIV && u == UV && (g.fused != 0) == FV) return launch_skinny_t<LBV, MIV, UV, FV>(g, s)
-    SKINNY_CASE(LAY_K, 1, 4, true);  SKINNY_CASE(LAY_K, 1, 4, false);
-    SKINNY_CASE(LAY_K, 1, 8, true);  SKINNY_CASE(LAY_K, 1, 8, false);
-    SKINNY_CASE(LAY_K, 2, 4, true);  SKINNY_CASE(LAY_K, 2, 4, false);
-    SKINNY_CASE(LAY_MN, 1, 4, true); SKINNY_CASE(LAY_MN, 1, 4, false);
-    SKINNY_CASE(LAY_MN, 1, 8, true); SKINNY_CASE(LAY_MN, 1, 8, false);
-    SKINNY_CASE(LAY_MN, 2, 4, true); SKINNY_CASE(LAY_MN, 2, 4, false);
+    if (g.M < 1 || (g.mi != 1 && g.mi != 2) || (int64_t)g.tiles_m * 32 * g.mi < g.M || g.kchunk % 8 != 0 ||
+        (g.fused && g.splitk != 1))
+        return hipErrorInvalidValue;
+#define SKINNY_CASE(LAV, LBV, MIV, FV) \
+    if (la == LAV && lb == LBV && g.mi == MIV && g.fused == FV) return launch_skinny_t<LAV, LBV, MIV, FV>(g, s)
+    // forward passes: plain / activation epilogue
+    SKINNY_CASE(LAY_K, LAY_K, 1, 0);  SKINNY_CASE(LAY_K, LAY_K, 1, 1);
+    SKINNY_CASE(LAY_K, LAY_K, 2, 0);  SKINNY_CASE(LAY_K, LAY_K, 2, 1);
+    SKINNY_CASE(LAY_K, LAY_MN, 1, 0); SKINNY_CASE(LAY_K, LAY_MN, 1, 1);
+    SKINNY_CASE(LAY_K, LAY_MN, 2, 0); SKINNY_CASE(LAY_K, LAY_MN, 2, 1);
+    // statistics GEMM of small layers: plain / parameter update
+    SKINNY_CASE(LAY_MN, LAY_MN, 2, 0); SKINNY_CASE(LAY_MN, LAY_MN, 2, 2);
 #undef SKINNY_CASE
     return hipErrorInvalidValue;
 }
@@ -1085,14 +1191,14 @@ __global__ __launch_bounds__(256) void finalize_stats_kernel(const float* __rest
             else if (i < ldh + ldv) s_v[i - ldh] = t;
             if (do_bias) {      // bias half of the update (rbm.py:356-365; same expressions as update_kernel)
                 if (i < bu.H) {
-                    const float sp = bu.hbs[i], g = t * bu.inv_rows;
-                    bu.hbs[i] = g + (sp - g) * bu.mu;
-                    bu.hb[i] = bu.hb[i] + sp * bu.lr;
+                    const float sp = bu.hbs[i];
+                    bu.hbs[i] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
+                    bu.hb[i] = upd_param(bu.hb[i], 1.0f, sp, bu.lr);
                 } else if (i >= ldh && i - ldh < bu.V) {
                     const int64_t j = i - ldh;
-                    const float sp = bu.vbs[j], g = t * bu.inv_rows;
-                    bu.vbs[j] = g + (sp - g) * bu.mu;
-                    bu.vb[j] = bu.vb[j] + sp * bu.lr;
+                    const float sp = bu.vbs[j];
+                    bu.vbs[j] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
+                    bu.vb[j] = upd_param(bu.vb[j], 1.0f, sp, bu.lr);
                 }
             }
         }
@@ -1148,27 +1254,6 @@ hipError_t launch_colsum_groups(const float* X, const float* Y, int rows, int64_
     return hipGetLastError();
 }
 
-// the whole update rule on 4 consecutive weights (shared by update_kernel and the fused epilogue of
-// the statistics GEMM: identical expressions, identical results)
-__device__ __forceinline__ void update_rule4(const float4& w, const float4& sp, const float4& st, const float4& wc0,
-                                             float inv_bs, float wc, float decay, float l1, float two_lr_l1,
-                                             float mu, float lr, float4& wn, float4& sn)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float wj = comp(w, j), spj = comp(sp, j);
-        float g = comp(st, j) * inv_bs - wc * comp(wc0, j);
-        float m = decay;
-        if (l1 != 0.0f) {
-            const float shrink = 1.0f + two_lr_l1 / (fabsf(wj) + 0.001f);
-            g = g / shrink;
-            m = decay / shrink;
-        }
-        setc(sn, j, g + (spj - g) * mu);
-        setc(wn, j, wj * m + spj * lr);
-    }
-}
-
 // Parameter update applied by the statistics GEMM to the tile it just computed (parked in LDS, row
 // stride BN + 8): W and W_speed are read and written once, S never touches HBM.  The GEMM reads
 // only V2 / P2, so updating W in place under it is safe.  A thread owns one float4 column group and
@@ -1180,8 +1265,8 @@ __device__ __forceinline__ void fused_update_epilogue(const UpdEpi& u, const flo
     const int c4 = threadIdx.x % C4, rr = threadIdx.x / C4;
     const int col = n0 + 4 * c4;
     if (col >= (int)u.ld) return;
-    const float two_lr_l1 = 2.0f * u.lr * u.l1;
-    const float decay = 1.0f - 2.0f * u.lr * u.l2;
+    const float two_lr_l1 = upd_two_lr_l1(u.lr, u.l1);
+    const float decay = upd_decay(u.lr, u.l2);
 #pragma unroll 1
     for (int r = rr; r < BM; r += RSTEP * RB) {
         float4 w[RB], sp[RB], w0[RB];
@@ -1233,18 +1318,18 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
         const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         if (i < H) {
             const float sp = hbs[i];
-            if (do_speed) { const float g = s_h[i] * inv_rows; hbs[i] = g + (sp - g) * mu; }
-            if (do_params) hb[i] = hb[i] + sp * lr;
+            if (do_speed) hbs[i] = upd_speed(upd_scale(s_h[i], inv_rows), sp, mu);
+            if (do_params) hb[i] = upd_param(hb[i], 1.0f, sp, lr);
         } else if (i < H + V) {
             const int64_t j = i - H;
             const float sp = vbs[j];
-            if (do_speed) { const float g = s_v[j] * inv_rows; vbs[j] = g + (sp - g) * mu; }
-            if (do_params) vb[j] = vb[j] + sp * lr;
+            if (do_speed) vbs[j] = upd_speed(upd_scale(s_v[j], inv_rows), sp, mu);
+            if (do_params) vb[j] = upd_param(vb[j], 1.0f, sp, lr);
         }
         if (i == 0 && cost_out && do_speed) cost_out[0] = cost_sum[0] * cost_scale;
     }
-    const float two_lr_l1 = 2.0f * lr * l1;
-    const float decay = 1.0f - 2.0f * lr * l2;
+    const float two_lr_l1 = upd_two_lr_l1(lr, l1);
+    const float decay = upd_decay(lr, l2);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * blockDim.x) {
         const float4 sp = Ws[i];
@@ -1257,17 +1342,15 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
             Ws[i] = sn;
         } else if constexpr (DO_PARAMS) {           // lambda_1 == 0 (checked by the host): m = decay
             const float4 w = W[i];
-            W[i] = make_float4(w.x * decay + sp.x * lr, w.y * decay + sp.y * lr,
-                               w.z * decay + sp.z * lr, w.w * decay + sp.w * lr);
+            W[i] = make_float4(upd_param(w.x, decay, sp.x, lr), upd_param(w.y, decay, sp.y, lr),
+                               upd_param(w.z, decay, sp.z, lr), upd_param(w.w, decay, sp.w, lr));
         } else {                                    // speeds only; weight cost, if any, uses W0
             const float4 st = S[i];
-            float4 g = make_float4(st.x * inv_bs, st.y * inv_bs, st.z * inv_bs, st.w * inv_bs);
-            if (wc != 0.0f) {
-                const float4 w0 = W0[i];
-                g.x -= wc * w0.x; g.y -= wc * w0.y; g.z -= wc * w0.z; g.w -= wc * w0.w;
-            }
-            Ws[i] = make_float4(g.x + (sp.x - g.x) * mu, g.y + (sp.y - g.y) * mu,
-                                g.z + (sp.z - g.z) * mu, g.w + (sp.w - g.w) * mu);
+            const float4 w0 = wc != 0.0f ? W0[i] : make_float4(0.f, 0.f, 0.f, 0.f);     // host: W0 != NULL when wc != 0
+            Ws[i] = make_float4(upd_speed(upd_grad(st.x, inv_bs, wc, w0.x), sp.x, mu),
+                                upd_speed(upd_grad(st.y, inv_bs, wc, w0.y), sp.y, mu),
+                                upd_speed(upd_grad(st.z, inv_bs, wc, w0.z), sp.z, mu),
+                                upd_speed(upd_grad(st.w, inv_bs, wc, w0.w), sp.w, mu));
         }
     }
 }

@@ -112,7 +112,9 @@ def test_free_energy(hip_engine, V, H, B, gauss):
 
 
 @pytest.mark.parametrize("V,H,B,k", [(6, 4, 3, 1), (64, 32, 8, 3), (130, 70, 37, 2), (784, 500, 20, 1),
-                                     (4096, 1024, 512, 1)])
+                                     (4096, 1024, 512, 1),
+                                     # small layers at B > 64: register-streaming GEMM with row tiles
+                                     (1024, 256, 512, 1), (400, 40, 512, 1), (100, 128, 300, 2), (256, 200, 129, 1)])
 @pytest.mark.parametrize("gauss", [False, True])
 def test_cd_step_statistics(hip_engine, V, H, B, k, gauss):
     """Chain + statistics of one CD-k step vs the oracle.  The oracle's chain is started
@@ -412,7 +414,7 @@ def _sweep_shapes():
     rs = np.random.RandomState(2024)
     shapes = [(1, 1, 1), (2, 3, 1), (5, 7, 2), (31, 33, 3), (32, 32, 4), (33, 31, 5), (63, 65, 7), (64, 64, 1),
               (127, 129, 9), (129, 127, 130), (257, 61, 33), (61, 257, 65), (500, 784, 20), (1021, 509, 131),
-              (96, 2053, 17), (2053, 96, 260)]
+              (96, 2053, 17), (2053, 96, 260), (1024, 256, 512), (256, 200, 512), (100, 128, 512), (40, 400, 97)]
     for _ in range(8):
         shapes.append((int(rs.randint(1, 700)), int(rs.randint(1, 700)), int(rs.randint(1, 300))))
     return shapes
@@ -428,7 +430,7 @@ def test_shape_sweep_chain_and_update(hip_engine, V, H, B):
     # Chains are compared without teacher forcing here, so a Bernoulli draw within fp32 rounding
     # of its probability would fork device and oracle (test_cd_step_statistics handles that case
     # explicitly).  The Philox seed below was checked to have no such near-tie for these shapes.
-    seed = 78 if (V, H, B) == (1021, 509, 131) else 77
+    seed = 78 if (V, H, B) in ((1021, 509, 131), (256, 200, 512)) else 77
     for cls, gauss, hp, k in ((mdbn_amd.RBM, False, dict(lr=0.1, weightcost=2e-4), 2),
                               (mdbn_amd.GRBM, True, dict(lr=0.002, lambda_1=0.01, lambda_2=0.1), 1)):
         data = rs.normal(size=(N, V)).astype(np.float32) if gauss else (rs.uniform(size=(N, V)) < 0.4).astype(np.float32)
@@ -612,10 +614,12 @@ def test_fused_epilogue_equals_unfused(hip_engine, V, H, B):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("V,H,B", [(784, 500, 20), (37, 19, 5), (1000, 130, 33), (2050, 70, 64), (300, 2049, 1),
-                                   (16384, 400, 20), (8, 8, 32)])
+                                   (16384, 400, 20), (8, 8, 32),
+                                   (1024, 256, 512), (400, 40, 512), (100, 128, 300), (256, 200, 129)])
 def test_skinny_gemm_matches_oracle_and_tile_kernel(hip_engine, V, H, B):
-    """Forward passes of <= 64 rows run on skinny_gemm_kernel (no LDS staging, 8 waves split K,
-    in-block reduction; MI = 1 for <= 32 rows, 2 above).  Pre-activations must match the float64
+    """Forward passes of <= 64 rows, and of small layers at any batch size (operands L2-resident),
+    run on skinny_gemm_kernel (no LDS staging, 8 waves split K, in-block reduction; 32- or 64-row
+    tiles).  Pre-activations must match the float64
     oracle to the f32 accumulation tolerance and the 128-row tile kernel to the same; samples may
     differ from the tile kernel's only where u is within that tolerance of the mean."""
     eng = hip_engine
@@ -651,7 +655,8 @@ def test_skinny_gemm_matches_oracle_and_tile_kernel(hip_engine, V, H, B):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("V,H,B", [(4096, 1024, 512), (130, 70, 37), (784, 500, 20), (2050, 258, 64)])
+@pytest.mark.parametrize("V,H,B", [(4096, 1024, 512), (130, 70, 37), (784, 500, 20), (2050, 258, 64),
+                                   (1024, 256, 512), (100, 128, 300)])
 @pytest.mark.parametrize("hp", [dict(lambda_2=0.1), dict(lambda_1=0.01, lambda_2=0.01), dict(weightcost=2e-4, momentum=0.9)],
                          ids=["l2", "l1l2", "wc_mu"])
 def test_fused_update_is_bitwise_the_separate_update(hip_engine, V, H, B, hp):
