@@ -107,7 +107,8 @@ int  mdbn_ctx_create(mdbn_ctx **out, int device);
 int  mdbn_ctx_destroy(mdbn_ctx *ctx);
 
 /* Tuning knobs (process-wide; results never change beyond fp32 summation order).
- * "gemm_bk": GEMM slice depth, 0 = auto, 32 or 64.
+ * "gemm_bk": GEMM slice depth, 0 = auto, 32 or 64.  "gemm_cw": MFMA waves per SIMD of the tiled
+ *   GEMM, 0 = auto (2 for <= 512 rows), 1 or 2.
  * "epilogue_cw": columns per thread of the activation epilogue, 0 = auto, 1, 2 or 4.
  * "fused_epilogue" (default 1): GEMMs that need no split-K apply bias + activation + sampling to
  *   their own output tile instead of writing slabs for a second kernel (bitwise the same result).

@@ -60,6 +60,7 @@ int fail(int code, const char* fmt, ...)
     } while (0)
 
 static int g_opt_gemm_bk = 0;          // mdbn_set_option("gemm_bk"): 0 = auto, 32, 64
+static int g_opt_gemm_cw = 0;          // mdbn_set_option("gemm_cw"): MFMA waves per SIMD of the tiled GEMM, 0 = auto, 1, 2
 // mdbn_set_option("update_overlap"): run finalize + the parameter half of the update on a side
 // stream under the statistics GEMM.  Measured (profile r01j): the fork/join events cost more than
 // the ~12 us they hide (278.7 vs 259.6 us per step), so it is off by default.
@@ -87,12 +88,13 @@ struct Plan {
     int tiles_m, tiles_n, splitk, kchunk, bn, bk;
     int skinny = 0;        // skinny_gemm_kernel: tiles_m x tiles_n = (32*mi)-row tiles x 32-column strips
     int mi = 1;
+    int cw = 1;            // MFMA (consumer) waves per SIMD of the tiled kernel
     int64_t slab_floats(int64_t M, int64_t ldc) const { return (int64_t)splitk * M * ldc; }
     void fill(GemmArgs& g) const
     {
         g.kchunk = kchunk; g.splitk = splitk; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.bn = bn; g.bk = bk;
         g.inner_m = tiles_m <= tiles_n;
-        g.skinny = skinny; g.mi = mi; g.fused = 0;
+        g.skinny = skinny; g.mi = mi; g.fused = 0; g.cw = cw;
     }
 };
 
@@ -119,6 +121,10 @@ Plan plan_gemm(int64_t M, int64_t N, int64_t K)
     sk = std::max<int64_t>(1, (K + kchunk - 1) / kchunk);
     p.splitk = (int)sk;
     p.kchunk = (int)kchunk;
+    // Two MFMA waves per SIMD (eight 64x32 wave tiles) gain 1-3% on short jobs (M <= 512: c2 step
+    // 240.1 -> 234.0 us) and lose up to 10% in steady state (1.5 instead of 1.0 LDS fragment dwords
+    // per MFMA; a second wave does NOT hide the LDS-return cost): scripts/gemm_cw_ab.py.
+    p.cw = g_opt_gemm_cw ? g_opt_gemm_cw : (M <= 512 && p.bn == 128 ? 2 : 1);
     return p;
 }
 
@@ -439,6 +445,11 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     }
     if (strcmp(name, "skinny_fused_max_k") == 0) {
         g_opt_skinny_fused_max_k = value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "gemm_cw") == 0) {
+        if (value < 0 || value > 2) return fail(MDBN_EINVAL, "gemm_cw must be 0 (auto), 1 or 2");
+        g_opt_gemm_cw = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "skinny_max_macs") == 0) {

@@ -58,6 +58,7 @@ struct GemmArgs {
     int bn;                // block tile is 128 x bn (128 or 64)
     int bk;                // slice depth along the reduction index (32 or 64; 64 only with bn = 128)
     int inner_m;           // work-list order inside one split: 1 = tile_m fastest
+    int cw;                // MFMA waves per SIMD (1 | 2; 2 only for unfused 128-column tiles)
     unsigned long long* stamps;   // diagnostic builds only (-DMDBN_STAMP); NULL otherwise
     int skinny;            // 1: skinny_gemm_kernel (tiles_n = 32-column strips, tiles_m = (32*mi)-row tiles,
                            //    splitk = K ranges, kchunk % 8 == 0)

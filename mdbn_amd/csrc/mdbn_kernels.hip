@@ -231,11 +231,12 @@ __device__ __forceinline__ void gemm_produce(const GemmArgs& g, float* __restric
 #undef PRODUCER_LOAD
 }
 
-template <int LA, int LB, int MI, int NI, int KB>
+// BMI / BNI: block tile in 64-row / 64-column units (LDS image); MI / NI: this wave's 32x32 accumulators
+template <int LA, int LB, int BMI, int BNI, int MI, int NI, int KB>
 __device__ __forceinline__ void gemm_consume(const GemmArgs& g, const float* __restrict__ smem,
                                              f32x16 (&acc)[MI][NI], int nt, int wm, int wn, int i, int h)
 {
-    constexpr int BM = 64 * MI, BN = 64 * NI;
+    constexpr int BM = 64 * BMI, BN = 64 * BNI;
     constexpr int A_FLOATS = BM * (KB + 1), B_FLOATS = BN * (KB + 1), BUF = A_FLOATS + B_FLOATS;
     constexpr int KG = CONSUMER_KG, NG = KB / (2 * KG);   // groups of KG k-pairs per slice
     __syncthreads();                                // slice 0 staged
@@ -301,8 +302,11 @@ __device__ __forceinline__ void gemm_consume(const GemmArgs& g, const float* __r
     }
 }
 
-template <int LA, int LB, int MI, int NI, int KB, int FUSED>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
+// CW: consumer (MFMA) waves per SIMD.  1: four consumers with a 2x2 grid of (32*MI)x(32*NI) wave tiles.
+// 2: eight consumers, 2x4 grid of (32*MI)x(16*NI) wave tiles -- the two MFMA waves of a SIMD cover each
+// other's LDS-return stalls (needs NI == 2; unfused kernels only).
+template <int LA, int LB, int MI, int NI, int KB, int FUSED, int CW>
+__global__ __launch_bounds__(64 * (4 * CW + 4)) void gemm_splitk_kernel(GemmArgs g)
 {
     constexpr int BM = 64 * MI, BN = 64 * NI;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -325,7 +329,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
     const int nt = (kend - kbeg + KB - 1) / KB;     // >= 1: the host never plans an empty split
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave >= 4) {
+    constexpr int WMI = MI, WNI = CW == 2 ? NI / 2 : NI;       // this wave's accumulator grid
+    static_assert(CW == 1 || (CW == 2 && NI == 2 && FUSED == 0), "CW == 2 needs a 128-column unfused tile");
+    if (wave >= 4 * CW) {
         // the few staging instructions must not queue behind the partner wave's MFMA stream
         __builtin_amdgcn_s_setprio(PRODUCER_PRIO);
         const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (kbeg + nt * KB <= g.K);
@@ -336,16 +342,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
     } else {
         const int lane = threadIdx.x & 63;
         const int i = lane & 31, h = lane >> 5;
-        const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * (32 * NI);
-        f32x16 acc[MI][NI];
+        const int wm = CW == 2 ? (wave >> 2) * (32 * WMI) : (wave >> 1) * (32 * WMI);
+        const int wn = CW == 2 ? (wave & 3) * (32 * WNI) : (wave & 1) * (32 * WNI);
+        f32x16 acc[WMI][WNI];
 #pragma unroll
-        for (int a = 0; a < MI; ++a)
+        for (int a = 0; a < WMI; ++a)
 #pragma unroll
-            for (int b = 0; b < NI; ++b)
+            for (int b = 0; b < WNI; ++b)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-        gemm_consume<LA, LB, MI, NI, KB>(g, smem, acc, nt, wm, wn, i, h);
+        gemm_consume<LA, LB, MI, NI, WMI, WNI, KB>(g, smem, acc, nt, wm, wn, i, h);
 #if MFMA_AGPR
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA result -> v_accvgpr_read hazard (asm is opaque to hipcc)
 #endif
@@ -356,18 +363,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
             // Row stride BN + 8: lanes 32..63 (rows + 4) land 32 banks away from lanes 0..31.
             constexpr int LDT = BN + 8;
 #pragma unroll
-            for (int a = 0; a < MI; ++a)
+            for (int a = 0; a < WMI; ++a)
 #pragma unroll
-                for (int b = 0; b < NI; ++b)
+                for (int b = 0; b < WNI; ++b)
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
                         smem[(wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h) * LDT + wn + 32 * b + i] = acc[a][b][e];
         } else {
             float* C = g.C + (int64_t)ks * g.slab_stride;
 #pragma unroll
-            for (int a = 0; a < MI; ++a)
+            for (int a = 0; a < WMI; ++a)
 #pragma unroll
-                for (int b = 0; b < NI; ++b) {
+                for (int b = 0; b < WNI; ++b) {
                     const int col = n0 + wn + 32 * b + i;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(GemmArgs g)
     }
 }
 
-template <int LA, int LB, int MI, int NI, int KB, int FUSED>
+template <int LA, int LB, int MI, int NI, int KB, int FUSED, int CW = 1>
 static hipError_t launch_gemm_t(const GemmArgs& g, hipStream_t s)
 {
     // The LDS request is padded past half of the CU's 160 KiB so that exactly one 8-wave
@@ -399,7 +406,7 @@ static hipError_t launch_gemm_t(const GemmArgs& g, hipStream_t s)
     constexpr bool two_per_cu = FUSED == 2 && KB == 32;
     constexpr int lds_bytes = two_per_cu ? need_bytes : (need_bytes > 84 * 1024 ? need_bytes : 84 * 1024);
     static bool attr_set = false;
-    auto kern = gemm_splitk_kernel<LA, LB, MI, NI, KB, FUSED>;
+    auto kern = gemm_splitk_kernel<LA, LB, MI, NI, KB, FUSED, CW>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -407,13 +414,17 @@ static hipError_t launch_gemm_t(const GemmArgs& g, hipStream_t s)
         attr_set = true;
     }
     const int grid = g.tiles_m * g.tiles_n * g.splitk;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), lds_bytes, s, g);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (4 * CW + 4)), lds_bytes, s, g);
     return hipGetLastError();
 }
 
 template <int LA, int LB, int FUSED>
 static hipError_t launch_gemm_l(const GemmArgs& g, hipStream_t s)
 {
+    if constexpr (FUSED == 0) {
+        if (g.cw == 2 && g.bn == 128 && g.bk == 64) return launch_gemm_t<LA, LB, 2, 2, 64, 0, 2>(g, s);
+        if (g.cw == 2 && g.bn == 128 && g.bk == 32) return launch_gemm_t<LA, LB, 2, 2, 32, 0, 2>(g, s);
+    }
     if (g.bn == 128 && g.bk == 64) return launch_gemm_t<LA, LB, 2, 2, 64, FUSED>(g, s);
     if (g.bn == 128 && g.bk == 32) return launch_gemm_t<LA, LB, 2, 2, 32, FUSED>(g, s);
     if (g.bn == 64 && g.bk == 32) return launch_gemm_t<LA, LB, 2, 1, 32, FUSED>(g, s);
