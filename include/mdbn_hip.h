@@ -113,8 +113,9 @@ int  mdbn_ctx_destroy(mdbn_ctx *ctx);
  * "fused_epilogue" (default 1): GEMMs that need no split-K apply bias + activation + sampling to
  *   their own output tile instead of writing slabs for a second kernel (bitwise the same result).
  * "fused_update" (default 1): mdbn_cd_train_step applies the weight update inside the statistics
- *   GEMM when that GEMM is not split; the S block of a->stats is then NOT materialised (s_h, s_v
- *   and cost_sum are).  Set 0 to get S (bitwise the same parameters either way).
+ *   GEMM when that GEMM is not split (and lets the update kernel sum the split-K slabs when it
+ *   is); the S block of a->stats is then NOT materialised (s_h, s_v and cost_sum are).  Set 0 to
+ *   get S (bitwise the same parameters either way).
  * "skinny_gemm" (default 1): GEMMs of <= 64 output rows, and tiny GEMMs at any row count, use the
  *   register-streaming kernel (no LDS staging); "skinny_fused_max_k" (default 1024) largest K one
  *   block streams alone, "skinny_max_macs" (default 32 Mi) size limit above 64 rows.
@@ -176,8 +177,7 @@ int  mdbn_cd_step(mdbn_ctx *ctx, void *stream, const mdbn_cd_args *a);
 /* The whole compiled step function for a single device (src/rbm.py:258-376): mdbn_cd_step
  * followed by the update, in one call; parameters, speeds and cost are bitwise identical to
  * mdbn_cd_step + mdbn_apply_update.  upd->phase is ignored.  With option "fused_update" (default)
- * the S block of a->stats is left unspecified when the update could be fused into the statistics
- * GEMM; s_h, s_v and cost_sum are always written.  (Option "update_overlap" moves the bias / cost
+ * the S block of a->stats is left unspecified; s_h, s_v and cost_sum are always written.  (Option "update_overlap" moves the bias / cost
  * finalisation and the parameter half of the update onto an internal side stream under the
  * statistics GEMM, which never reads W.) */
 int  mdbn_cd_train_step(mdbn_ctx *ctx, void *stream, const mdbn_cd_args *a,

@@ -69,7 +69,8 @@ static int g_opt_update_overlap = 0;
 // GEMM needs no split-K (default on)
 static int g_opt_fused_epilogue = 1;
 // mdbn_set_option("fused_update"): mdbn_cd_train_step applies the update inside the statistics GEMM
-// when that GEMM is not split (default on); the S block of `stats` is then not materialised
+// when that GEMM is not split, and lets the update kernel sum the split-K slabs when it is
+// (default on); the S block of `stats` is then not materialised
 static int g_opt_fused_update = 1;
 constexpr int kTargetJobs = 256;       // one 8-wave tile job per CU (MI355X: 256 CUs)
 constexpr int kMinSplitK = 128;        // >= 4 slices of BK = 32 per split
@@ -121,10 +122,11 @@ Plan plan_gemm(int64_t M, int64_t N, int64_t K)
     sk = std::max<int64_t>(1, (K + kchunk - 1) / kchunk);
     p.splitk = (int)sk;
     p.kchunk = (int)kchunk;
-    // Two MFMA waves per SIMD (eight 64x32 wave tiles) gain 1-3% on short jobs (M <= 512: c2 step
-    // 240.1 -> 234.0 us) and lose up to 10% in steady state (1.5 instead of 1.0 LDS fragment dwords
-    // per MFMA; a second wave does NOT hide the LDS-return cost): scripts/gemm_cw_ab.py.
-    p.cw = g_opt_gemm_cw ? g_opt_gemm_cw : (M <= 512 && p.bn == 128 ? 2 : 1);
+    // Two MFMA waves per SIMD (eight 64x32 wave tiles) gain 1-3% on short jobs (<= 8 slices: faster
+    // ramp and drain; c2 step 240.1 -> 234.0 us) and lose up to 10% in steady state (1.5 instead of
+    // 1.0 LDS fragment dwords per MFMA; a second wave does NOT hide the LDS-return cost):
+    // scripts/gemm_cw_ab.py.
+    p.cw = g_opt_gemm_cw ? g_opt_gemm_cw : (p.bn == 128 && p.kchunk / p.bk <= 8 ? 2 : 1);
     return p;
 }
 
@@ -776,6 +778,13 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
     } else {
         g.C = ws.slabs;
         HIP_OK(timed_gemm(LAY_MN, LAY_MN, g, s));
+        if (upd && !overlap && g_opt_fused_update) {
+            // single device: the update sums the slabs itself (same order as sum_slabs_kernel, so the
+            // same bits); S is not materialised, as in the fused unsplit case
+            u.phase = 0;
+            HIP_OK(launch_update(u, s, ws.slabs, p.splitk, g.slab_stride));
+            return MDBN_OK;
+        }
         HIP_OK(launch_sum_slabs(ws.slabs, p.splitk, g.slab_stride, V * ldh, S, s));
     }
     if (upd) {

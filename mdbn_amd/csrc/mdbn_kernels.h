@@ -88,7 +88,9 @@ hipError_t launch_colsum_groups(const float* X, const float* Y, int rows, int64_
 hipError_t launch_finalize_stats(const float* posP, const float* negP, const float* partV, int ngroups,
                                  int64_t ldh, int64_t ldv, const float* cost_partials, int n_cost,
                                  float* s_h, float* s_v, float* cost, const BiasUpd* bias_update, hipStream_t s);
-hipError_t launch_update(const mdbn_update_args& a, hipStream_t s);
+// slabs != NULL (phase 0 only): the S block is read as the sum of `nslab` split-K slabs
+hipError_t launch_update(const mdbn_update_args& a, hipStream_t s, const float* slabs = nullptr, int nslab = 1,
+                         int64_t slab_stride = 0);
 hipError_t launch_free_energy(const float* slabs, int nsplit, int64_t slab_stride, int64_t ldh, int H,
                               const float* hbias, const float* x, int64_t ldv, int V, const float* vbias,
                               int gauss, int64_t rows, float* out, hipStream_t s);

@@ -1322,8 +1322,10 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
                                                      float* __restrict__ vb, float* __restrict__ vbs,
                                                      const float* __restrict__ s_v, int64_t V, float inv_rows,
                                                      const float* __restrict__ cost_sum, float cost_scale,
-                                                     float* __restrict__ cost_out)
+                                                     float* __restrict__ cost_out, int nslab, int64_t slab_stride4)
 {
+    // nslab > 1 (whole rule only): S points at the split-K slabs of the statistics GEMM, summed here
+    // in slab order exactly as sum_slabs_kernel would -- one launch and one pass over S fewer
     constexpr bool do_speed = DO_SPEED, do_params = DO_PARAMS;
     {   // biases, one element per thread of the leading blocks (multipliers are exactly 1, rbm.py:356)
         const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1345,7 +1347,21 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
          i += (int64_t)gridDim.x * blockDim.x) {
         const float4 sp = Ws[i];
         if constexpr (DO_SPEED && DO_PARAMS) {
-            const float4 w = W[i], st = S[i];
+            const float4 w = W[i];
+            float4 st;
+            if (nslab <= 1) {
+                st = S[i];
+            } else {
+                st = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int s0 = 0; s0 < nslab; s0 += 8) {
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        v[u] = s0 + u < nslab ? S[i + (int64_t)(s0 + u) * slab_stride4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { st.x += v[u].x; st.y += v[u].y; st.z += v[u].z; st.w += v[u].w; }
+                }
+            }
             const float4 wc0 = W0 ? W0[i] : w;
             float4 wn, sn;
             update_rule4(w, sp, st, wc0, inv_bs, wc, decay, l1, two_lr_l1, mu, lr, wn, sn);
@@ -1366,10 +1382,13 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
     }
 }
 
-hipError_t launch_update(const mdbn_update_args& a, hipStream_t s)
+hipError_t launch_update(const mdbn_update_args& a, hipStream_t s, const float* slabs, int nslab,
+                         int64_t slab_stride)
 {
     const int64_t n4 = (a.V * a.ldh) >> 2;
-    const float* S = a.stats;
+    if (slabs && (a.phase != 0 || (slab_stride & 3))) return hipErrorInvalidValue;
+    const float* S = slabs ? slabs : a.stats;
+    if (!slabs) nslab = 1;
     const float* s_h = a.stats + a.V * a.ldh;
     const float* s_v = s_h + a.ldh;
     const int grid = (int)std::max<int64_t>(std::min<int64_t>((n4 + 255) / 256, 4096), (a.H + a.V + 255) / 256);
@@ -1378,7 +1397,8 @@ hipError_t launch_update(const mdbn_update_args& a, hipStream_t s)
                        reinterpret_cast<float4*>(a.W_speed), reinterpret_cast<const float4*>(a.W0),    \
                        reinterpret_cast<const float4*>(S), n4, a.lr, a.lambda_1, a.lambda_2, a.weightcost, \
                        a.momentum, 1.0f / a.batch_size, a.hbias, a.hbias_speed, s_h, a.H, a.vbias,    \
-                       a.vbias_speed, s_v, a.V, 1.0f / a.n_rows, s_v + a.ldv, a.cost_scale, a.cost_out)
+                       a.vbias_speed, s_v, a.V, 1.0f / a.n_rows, s_v + a.ldv, a.cost_scale, a.cost_out, nslab, \
+                       slab_stride >> 2)
     if (a.phase == 1) LAUNCH_UPDATE(true, false);
     else if (a.phase == 2) LAUNCH_UPDATE(false, true);
     else LAUNCH_UPDATE(true, true);

@@ -656,7 +656,7 @@ def test_skinny_gemm_matches_oracle_and_tile_kernel(hip_engine, V, H, B):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("V,H,B", [(4096, 1024, 512), (130, 70, 37), (784, 500, 20), (2050, 258, 64),
-                                   (1024, 256, 512), (100, 128, 300)])
+                                   (1024, 256, 512), (100, 128, 300), (2048, 400, 512)])
 @pytest.mark.parametrize("hp", [dict(lambda_2=0.1), dict(lambda_1=0.01, lambda_2=0.01), dict(weightcost=2e-4, momentum=0.9)],
                          ids=["l2", "l1l2", "wc_mu"])
 def test_fused_update_is_bitwise_the_separate_update(hip_engine, V, H, B, hp):
