@@ -73,7 +73,7 @@ static int g_opt_fused_epilogue = 1;
 // (default on); the S block of `stats` is then not materialised
 static int g_opt_fused_update = 1;
 constexpr int kTargetJobs = 256;       // one 8-wave tile job per CU (MI355X: 256 CUs)
-constexpr int kMinSplitK = 128;        // >= 4 slices of BK = 32 per split
+static int kMinSplitK = 128;           // >= 4 slices of BK = 32 per split (mdbn_set_option "gemm_min_splitk")
 
 inline int64_t ru4(int64_t x) { return (x + 3) & ~int64_t(3); }
 // Leading-dimension policy (mdbn_padded_ld).  Padding 1-KiB-multiple rows by 64 floats (to spread
@@ -447,6 +447,11 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     }
     if (strcmp(name, "skinny_fused_max_k") == 0) {
         g_opt_skinny_fused_max_k = value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "gemm_min_splitk") == 0) {
+        if (value < 32) return fail(MDBN_EINVAL, "gemm_min_splitk must be >= 32");
+        kMinSplitK = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "gemm_cw") == 0) {
