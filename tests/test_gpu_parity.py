@@ -684,3 +684,36 @@ def test_fused_update_is_bitwise_the_separate_update(hip_engine, V, H, B, hp):
         eng.set_option("fused_update", 1)
     for a, b in zip(res[1], res[0]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,H,B", [(20000, 4000, 1024), (4097, 1031, 777), (16384, 400, 20), (3000, 3000, 4096),
+                                   (70000, 96, 40), (96, 70000, 40)])
+def test_large_shapes_against_rocblas(hip_engine, V, H, B):
+    """Sizes the CPU oracle cannot reach in seconds: pre-activations of both passes against
+    torch.matmul (rocBLAS, an independent f32 GEMM) on the same device, every kernel family
+    (LDS-tiled split / unsplit + fused epilogue, one and two MFMA waves per SIMD, register-streaming),
+    and the sampled values against the pre-activations they must derive from."""
+    import torch
+    eng = hip_engine
+    g = torch.Generator().manual_seed(V + H + B)
+    W = (0.02 * torch.randn((V, H), generator=g)).to(eng.device)
+    Wd = eng.alloc_matrix(V, H); Wd.copy_(W)
+    hb = (0.1 * torch.randn(H, generator=g)).to(eng.device)
+    vb = (0.1 * torch.randn(V, generator=g)).to(eng.device)
+    x = torch.randn((B, V), generator=g).to(eng.device)
+    h = (torch.rand((B, H), generator=g) < 0.5).float().to(eng.device)
+    from mdbn_amd.engine import RngAddr
+    pre, mean, sample = eng.propup(x, Wd, hb, rng=RngAddr(3, 0, 1, 0))
+    ref = x.double() @ W.double() + hb.double()
+    tol = 4 * ptol(V) * max(1.0, float(ref.abs().max()))
+    assert float((pre[:, :H].double() - ref).abs().max()) <= tol
+    assert float((mean[:, :H] - torch.sigmoid(pre[:, :H])).abs().max()) <= 2e-6
+    u = eng.rng_uniform(B, H, RngAddr(3, 0, 1, 0))
+    expect = (u[:, :H] < mean[:, :H]).float()
+    assert float((sample[:, :H] != expect).float().mean()) == 0.0
+    dpre, dmean, dsample = eng.propdown(h, Wd, vb, gauss=False, rng=RngAddr(3, 0, 1, 1))
+    dref = h.double() @ W.double().t() + vb.double()
+    dtol = 4 * ptol(H) * max(1.0, float(dref.abs().max()))
+    assert float((dpre[:, :V].double() - dref).abs().max()) <= dtol
+    assert float((dmean[:, :V] - torch.sigmoid(dpre[:, :V])).abs().max()) <= 2e-6
