@@ -138,6 +138,87 @@ __device__ __forceinline__ float frag(const float* __restrict__ T, int mn, int k
 #endif
 }
 
+// ----------------------------------------------------------------------------------
+// float4 component access and the parameter-update rule (used by the GEMM's fused epilogues too)
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ float comp(const float4& v, int j)
+{
+    return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
+}
+__device__ __forceinline__ void setc(float4& v, int j, float x)
+{
+    if (j == 0) v.x = x; else if (j == 1) v.y = x; else if (j == 2) v.z = x; else v.w = x;
+}
+
+// The update rule (rbm.py:347-365) on 4 weights, shared by update_kernel and the fused epilogues of
+// the statistics GEMM.  Floating-point contraction is switched off inside these helpers (hipcc
+// otherwise fuses a*b+c into an fma or not depending on what the helper is inlined into -- the
+// __f*_rn intrinsics are plain operators to it), so every call site agrees bit for bit, and with the
+// float32 restatement, which rounds every operation.
+__device__ __forceinline__ float upd_grad(float st, float inv_bs, float wc, float w0)
+{
+#pragma clang fp contract(off)
+    const float a = st * inv_bs, b = wc * w0;
+    return a - b;
+}
+__device__ __forceinline__ float upd_speed(float g, float sp, float mu)     // g + (s - g) * mu
+{
+#pragma clang fp contract(off)
+    const float d = sp - g;
+    const float e = d * mu;
+    return g + e;
+}
+__device__ __forceinline__ float upd_param(float w, float m, float sp, float lr)   // w * m + s_old * lr
+{
+#pragma clang fp contract(off)
+    const float a = w * m, b = sp * lr;
+    return a + b;
+}
+__device__ __forceinline__ float upd_scale(float x, float s)
+{
+#pragma clang fp contract(off)
+    return x * s;
+}
+__device__ __forceinline__ float upd_decay(float lr, float l2)          // 1 - 2 lr l2
+{
+#pragma clang fp contract(off)
+    const float a = 2.0f * lr;
+    const float b = a * l2;
+    return 1.0f - b;
+}
+__device__ __forceinline__ float upd_two_lr_l1(float lr, float l1)
+{
+#pragma clang fp contract(off)
+    const float a = 2.0f * lr;
+    return a * l1;
+}
+__device__ __forceinline__ float upd_shrink(float two_lr_l1, float w)    // 1 + 2 lr l1 / (|w| + eps)
+{
+#pragma clang fp contract(off)
+    const float d = fabsf(w) + 0.001f;
+    const float q = __fdiv_rn(two_lr_l1, d);
+    return 1.0f + q;
+}
+
+__device__ __forceinline__ void update_rule4(const float4& w, const float4& sp, const float4& st, const float4& wc0,
+                                             float inv_bs, float wc, float decay, float l1, float two_lr_l1,
+                                             float mu, float lr, float4& wn, float4& sn)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float wj = comp(w, j), spj = comp(sp, j);
+        float g = upd_grad(comp(st, j), inv_bs, wc, comp(wc0, j));
+        float m = decay;
+        if (l1 != 0.0f) {
+            const float shrink = upd_shrink(two_lr_l1, wj);
+            g = __fdiv_rn(g, shrink);
+            m = __fdiv_rn(decay, shrink);
+        }
+        setc(sn, j, upd_speed(g, spj, mu));
+        setc(wn, j, upd_param(wj, m, spj, lr));
+    }
+}
+
 #ifdef MDBN_STAMP
 // diagnostic build: s_memtime stamps of one block's phases (never compiled into the product)
 #define STAMP(slot)                                                                          \
@@ -185,9 +266,13 @@ __device__ __forceinline__ void fused_update_epilogue(const UpdEpi& u, const flo
 #define ABLATE_LOAD 0
 #endif
 
-template <int LA, int LB, int MI, int NI, int KB, bool GUARD>
+// PF (fused update, 128x128x64 interior tiles): the producers have nothing left to stage during the
+// last slice and their 128 staging registers are free, so they fetch the tile's W / W_speed (16 + 16
+// float4 per thread) while the consumers finish the MFMAs, and apply the update themselves once the
+// tile is parked -- the read half of the read-modify-write is hidden behind the matrix pipe.
+template <int LA, int LB, int MI, int NI, int KB, bool GUARD, bool PF = false>
 __device__ __forceinline__ void gemm_produce(const GemmArgs& g, float* __restrict__ smem, int m0, int n0,
-                                             int kbeg, int kend, int nt)
+                                             int kbeg, int kend, int nt, bool pf = false)
 {
     constexpr int BM = 64 * MI, BN = 64 * NI;
     constexpr int A_FLOATS = BM * (KB + 1), B_FLOATS = BN * (KB + 1), BUF = A_FLOATS + B_FLOATS;
@@ -222,13 +307,44 @@ __device__ __forceinline__ void gemm_produce(const GemmArgs& g, float* __restric
     if (nt > 1) PRODUCER_LOAD(ra0, rb0, 1);         // slices 1 and 2 stay in flight across the barrier
     if (nt > 2) PRODUCER_LOAD(ra1, rb1, 2);
     __syncthreads();
-    for (int it = 0; it < nt; ++it) {
+    const int nloop = (PF && pf) ? nt - 1 : nt;     // PF: the last step (no store, no load) is peeled below
+    for (int it = 0; it < nloop; ++it) {
         PRODUCER_STEP(ra0, rb0);
-        if (++it >= nt) break;
+        if (++it >= nloop) break;
         PRODUCER_STEP(ra1, rb1);
     }
 #undef PRODUCER_STEP
 #undef PRODUCER_LOAD
+    if constexpr (PF) {
+        if (pf) {
+            static_assert(!PF || (BM == 128 && BN == 128), "PF is written for the 128x128 tile");
+            constexpr int LDT = BN + 8, ROWS_PER_PASS = NTHREADS / (BN / 4), NP = BM / ROWS_PER_PASS;
+            const UpdEpi& u = g.upd;
+            const int tid = threadIdx.x & (NTHREADS - 1);
+            const int c4 = tid % (BN / 4), rr = tid / (BN / 4);
+            const int64_t base = (int64_t)(m0 + rr) * u.ld + n0 + 4 * c4;
+            float4 w[NP], sp[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int64_t off = base + (int64_t)(ROWS_PER_PASS * p) * u.ld;
+                w[p] = *reinterpret_cast<const float4*>(u.W + off);
+                sp[p] = *reinterpret_cast<const float4*>(u.Ws + off);
+            }
+            __syncthreads();                // end of the last slice
+            __syncthreads();                // the consumers parked the tile
+            const float two_lr_l1 = upd_two_lr_l1(u.lr, u.l1);
+            const float decay = upd_decay(u.lr, u.l2);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int64_t off = base + (int64_t)(ROWS_PER_PASS * p) * u.ld;
+                const float4 st = *reinterpret_cast<const float4*>(smem + (rr + ROWS_PER_PASS * p) * LDT + 4 * c4);
+                float4 wn, sn;
+                update_rule4(w[p], sp[p], st, w[p], u.inv_bs, u.wc, decay, u.l1, two_lr_l1, u.mu, u.lr, wn, sn);
+                *reinterpret_cast<float4*>(u.W + off) = wn;
+                *reinterpret_cast<float4*>(u.Ws + off) = sn;
+            }
+        }
+    }
 }
 
 // BMI / BNI: block tile in 64-row / 64-column units (LDS image); MI / NI: this wave's 32x32 accumulators
@@ -331,13 +447,17 @@ __global__ __launch_bounds__(64 * (4 * CW + 4)) void gemm_splitk_kernel(GemmArgs
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int WMI = MI, WNI = CW == 2 ? NI / 2 : NI;       // this wave's accumulator grid
     static_assert(CW == 1 || (CW == 2 && NI == 2 && FUSED == 0), "CW == 2 needs a 128-column unfused tile");
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (kbeg + nt * KB <= g.K);
+    // producer-prefetched update (see gemm_produce): full 128x128x64 tiles, live weight cost only
+    constexpr bool PF = FUSED == 2 && KB == 64 && MI == 2 && NI == 2;
+    const bool pf = PF && interior && g.upd.W0 == nullptr;
     if (wave >= 4 * CW) {
         // the few staging instructions must not queue behind the partner wave's MFMA stream
         __builtin_amdgcn_s_setprio(PRODUCER_PRIO);
-        const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (kbeg + nt * KB <= g.K);
-        if (interior) gemm_produce<LA, LB, MI, NI, KB, false>(g, smem, m0, n0, kbeg, kend, nt);
+        if (interior) gemm_produce<LA, LB, MI, NI, KB, false, PF>(g, smem, m0, n0, kbeg, kend, nt, pf);
         else gemm_produce<LA, LB, MI, NI, KB, true>(g, smem, m0, n0, kbeg, kend, nt);
         if constexpr (FUSED == 0) return;
+        if (pf) return;                     // this thread already applied its share of the update
         __builtin_amdgcn_s_setprio(0);
     } else {
         const int lane = threadIdx.x & 63;
@@ -387,6 +507,7 @@ __global__ __launch_bounds__(64 * (4 * CW + 4)) void gemm_splitk_kernel(GemmArgs
     }
     if constexpr (FUSED != 0) {     // all 8 waves work on the parked tile
         __syncthreads();
+        if (pf) return;             // (consumers) the producers hold W / W_speed in registers and finish
         if constexpr (FUSED == 1) fused_tile_epilogue<BM, BN>(g.epi, smem, m0, n0);   // activation + sampling
         else fused_update_epilogue<BM, BN>(g.upd, smem, m0, n0);                       // parameter update
     }
@@ -508,15 +629,6 @@ __device__ __forceinline__ void philox_rows4(const PhiloxKey& k, uint32_t draw, 
     }
 }
 
-__device__ __forceinline__ float comp(const float4& v, int j)
-{
-    return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
-}
-__device__ __forceinline__ void setc(float4& v, int j, float x)
-{
-    if (j == 0) v.x = x; else if (j == 1) v.y = x; else if (j == 2) v.z = x; else v.w = x;
-}
-
 // ----------------------------------------------------------------------------------
 // Activation epilogue fused into the GEMM (jobs that need no split-K): the arithmetic of
 // act_epilogue_kernel below applied to the block's own 128 x BN tile, which the consumer waves
@@ -524,75 +636,6 @@ __device__ __forceinline__ void setc(float4& v, int j, float x)
 // 4-row groups -- one Philox4x32-10 block per (group, column), as everywhere.  One cost partial
 // per block (cost_partials[blockIdx.x]); column partials [row_group][col] as below.
 // ----------------------------------------------------------------------------------
-// The update rule (rbm.py:347-365) on 4 weights, shared by update_kernel and the fused epilogues of
-// the statistics GEMM.  Floating-point contraction is switched off inside these helpers (hipcc
-// otherwise fuses a*b+c into an fma or not depending on what the helper is inlined into -- the
-// __f*_rn intrinsics are plain operators to it), so every call site agrees bit for bit, and with the
-// float32 restatement, which rounds every operation.
-__device__ __forceinline__ float upd_grad(float st, float inv_bs, float wc, float w0)
-{
-#pragma clang fp contract(off)
-    const float a = st * inv_bs, b = wc * w0;
-    return a - b;
-}
-__device__ __forceinline__ float upd_speed(float g, float sp, float mu)     // g + (s - g) * mu
-{
-#pragma clang fp contract(off)
-    const float d = sp - g;
-    const float e = d * mu;
-    return g + e;
-}
-__device__ __forceinline__ float upd_param(float w, float m, float sp, float lr)   // w * m + s_old * lr
-{
-#pragma clang fp contract(off)
-    const float a = w * m, b = sp * lr;
-    return a + b;
-}
-__device__ __forceinline__ float upd_scale(float x, float s)
-{
-#pragma clang fp contract(off)
-    return x * s;
-}
-__device__ __forceinline__ float upd_decay(float lr, float l2)          // 1 - 2 lr l2
-{
-#pragma clang fp contract(off)
-    const float a = 2.0f * lr;
-    const float b = a * l2;
-    return 1.0f - b;
-}
-__device__ __forceinline__ float upd_two_lr_l1(float lr, float l1)
-{
-#pragma clang fp contract(off)
-    const float a = 2.0f * lr;
-    return a * l1;
-}
-__device__ __forceinline__ float upd_shrink(float two_lr_l1, float w)    // 1 + 2 lr l1 / (|w| + eps)
-{
-#pragma clang fp contract(off)
-    const float d = fabsf(w) + 0.001f;
-    const float q = __fdiv_rn(two_lr_l1, d);
-    return 1.0f + q;
-}
-
-__device__ __forceinline__ void update_rule4(const float4& w, const float4& sp, const float4& st, const float4& wc0,
-                                             float inv_bs, float wc, float decay, float l1, float two_lr_l1,
-                                             float mu, float lr, float4& wn, float4& sn)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float wj = comp(w, j), spj = comp(sp, j);
-        float g = upd_grad(comp(st, j), inv_bs, wc, comp(wc0, j));
-        float m = decay;
-        if (l1 != 0.0f) {
-            const float shrink = upd_shrink(two_lr_l1, wj);
-            g = __fdiv_rn(g, shrink);
-            m = __fdiv_rn(decay, shrink);
-        }
-        setc(sn, j, upd_speed(g, spj, mu));
-        setc(wn, j, upd_param(wj, m, spj, lr));
-    }
-}
-
 // One (4-row group, column) of an activation epilogue: x[j] = pre-activation (bias included) of
 // row r0 + j.  Stores pre / mean / sample, the group's column partial, and adds to `cost`.
 __device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, float x2, float x3, int r0, int col, bool live, float& cost)
