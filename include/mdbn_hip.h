@@ -116,6 +116,8 @@ int  mdbn_ctx_destroy(mdbn_ctx *ctx);
  *   GEMM when that GEMM is not split (and lets the update kernel sum the split-K slabs when it
  *   is); the S block of a->stats is then NOT materialised (s_h, s_v and cost_sum are).  Set 0 to
  *   get S (bitwise the same parameters either way).
+ * "fused_finalize" (default 1): with fused_update, the bias statistics / cost / bias update run
+ *   inside the statistics GEMM as well (no finalize launch).
  * "skinny_gemm" (default 1): GEMMs of <= 64 output rows, and tiny GEMMs at any row count, use the
  *   register-streaming kernel (no LDS staging); "skinny_fused_max_k" (default 1024) largest K one
  *   block streams alone, "skinny_max_macs" (default 32 Mi) size limit above 64 rows.

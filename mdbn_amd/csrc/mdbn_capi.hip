@@ -72,6 +72,8 @@ static int g_opt_fused_epilogue = 1;
 // when that GEMM is not split, and lets the update kernel sum the split-K slabs when it is
 // (default on); the S block of `stats` is then not materialised
 static int g_opt_fused_update = 1;
+// mdbn_set_option("fused_finalize"): ... and runs the bias statistics / cost / bias update inside that GEMM too
+static int g_opt_fused_finalize = 1;
 constexpr int kTargetJobs = 256;       // one 8-wave tile job per CU (MI355X: 256 CUs)
 static int kMinSplitK = 128;           // >= 4 slices of BK = 32 per split (mdbn_set_option "gemm_min_splitk")
 
@@ -95,7 +97,7 @@ struct Plan {
     {
         g.kchunk = kchunk; g.splitk = splitk; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.bn = bn; g.bk = bk;
         g.inner_m = tiles_m <= tiles_n;
-        g.skinny = skinny; g.mi = mi; g.fused = 0; g.cw = cw;
+        g.skinny = skinny; g.mi = mi; g.fused = 0; g.cw = cw; g.fin_enabled = 0;
     }
 };
 
@@ -463,6 +465,10 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
         g_opt_skinny_max_macs = value;
         return MDBN_OK;
     }
+    if (strcmp(name, "fused_finalize") == 0) {
+        g_opt_fused_finalize = value != 0;
+        return MDBN_OK;
+    }
     if (strcmp(name, "fused_update") == 0) {
         g_opt_fused_update = value != 0;
         return MDBN_OK;
@@ -753,24 +759,32 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
     // Single device, unsplit statistics GEMM: the GEMM applies the weight update to its own tiles
     // (S never reaches HBM) and the bias / cost half rides on the finalize kernel -- no update launch.
     const bool fuse_upd = upd && !overlap && g_opt_fused_update && p.splitk == 1;
-    if (!overlap) {
-        BiasUpd bu;
-        if (fuse_upd) {
-            bu.hb = u.hbias; bu.hbs = u.hbias_speed; bu.vb = u.vbias; bu.vbs = u.vbias_speed;
-            bu.H = H; bu.V = V; bu.lr = u.lr; bu.mu = u.momentum; bu.inv_rows = 1.0f / u.n_rows;
-            bu.cost_scale = u.cost_scale; bu.cost_out = u.cost_out;
-        }
+    // ... and in the LDS-tiled kernel even the finalize units run inside the GEMM (its MFMA waves are
+    // idle while the first slice is in flight): no finalize launch either
+    const bool fin_in_gemm = fuse_upd && !p.skinny && g_opt_fused_finalize;
+    BiasUpd bu;
+    if (fuse_upd) {
+        bu.hb = u.hbias; bu.hbs = u.hbias_speed; bu.vb = u.vbias; bu.vbs = u.vbias_speed;
+        bu.H = H; bu.V = V; bu.lr = u.lr; bu.mu = u.momentum; bu.inv_rows = 1.0f / u.n_rows;
+        bu.cost_scale = u.cost_scale; bu.cost_out = u.cost_out;
+    }
+    if (!overlap && !fin_in_gemm)
         HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials,
                                      n_cost, s_h, s_v, cost, fuse_upd ? &bu : nullptr, s));
-    }
     GemmArgs g;
     g.A = a->V2; g.lda = ldv; g.B = a->P2; g.ldb = ldh;
     g.ldc = ldh; g.slab_stride = V * ldh;
     g.M = (int)V; g.N = (int)H; g.K = (int)(2 * B); g.Nst = (int)ldh;
     p.fill(g);
+    g.fin_enabled = 0;
     if (fuse_upd) {
         g.C = nullptr;
         g.fused = 2;
+        if (fin_in_gemm) {
+            g.fin_enabled = 1;
+            g.fin = make_fin_args(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials, n_cost,
+                                  s_h, s_v, cost, &bu);
+        }
         g.upd.W = u.W; g.upd.Ws = u.W_speed; g.upd.W0 = u.W0; g.upd.ld = ldh; g.upd.rows = (int)V;
         g.upd.lr = u.lr; g.upd.l1 = u.lambda_1; g.upd.l2 = u.lambda_2; g.upd.wc = u.weightcost;
         g.upd.mu = u.momentum; g.upd.inv_bs = 1.0f / u.batch_size;

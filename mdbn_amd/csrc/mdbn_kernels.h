@@ -45,6 +45,17 @@ struct BiasUpd {
     float* cost_out;
 };
 
+// bias statistics + cost total (+ bias half of the update): finalize_stats_kernel, or the consumer
+// waves of the fused statistics GEMM during their ramp-up (fin_enabled)
+struct FinArgs {
+    const float* posP; const float* negP; const float* partV;   // [ngroups][ldh], [ngroups][ldh], [ngroups][ldv]
+    int ngroups;
+    int64_t ldh, ldv;
+    const float* cost_partials; int n_cost;
+    float* s_h; float* s_v; float* cost;
+    BiasUpd bu; int do_bias;
+};
+
 struct GemmArgs {
     const float* A;        // LAY_K: [M][lda] ; LAY_MN: [K][lda]
     const float* B;        // LAY_K: [N][ldb] ; LAY_MN: [K][ldb]
@@ -67,6 +78,8 @@ struct GemmArgs {
                            //   1 = activation (epi), 2 = parameter update (upd; statistics GEMM, C is not written)
     EpiArgs epi;           // fused == 1 (slabs / nsplit unused; one cost partial per block)
     UpdEpi upd;            // fused == 2
+    int fin_enabled;       // fused == 2: the consumer waves also run the finalize units before the first slice
+    FinArgs fin;
 };
 
 
@@ -85,6 +98,9 @@ hipError_t launch_gather(const float* src, int64_t n_rows, int64_t cols_ld, int6
                          const void* idx, int idx64, int64_t n_idx, float* dst, int64_t ld_dst,
                          hipStream_t s);
 hipError_t launch_colsum_groups(const float* X, const float* Y, int rows, int64_t ld, float* out, hipStream_t s);
+FinArgs make_fin_args(const float* posP, const float* negP, const float* partV, int ngroups, int64_t ldh, int64_t ldv,
+                      const float* cost_partials, int n_cost, float* s_h, float* s_v, float* cost,
+                      const BiasUpd* bias_update);
 hipError_t launch_finalize_stats(const float* posP, const float* negP, const float* partV, int ngroups,
                                  int64_t ldh, int64_t ldv, const float* cost_partials, int n_cost,
                                  float* s_h, float* s_v, float* cost, const BiasUpd* bias_update, hipStream_t s);

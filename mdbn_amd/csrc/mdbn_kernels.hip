@@ -219,6 +219,64 @@ __device__ __forceinline__ void update_rule4(const float4& w, const float4& sp, 
     }
 }
 
+// ----------------------------------------------------------------------------------
+// Bias statistics (rbm.py:416-417) from the epilogues' 4-row column partials, the cost total, and the
+// bias half of the update, in units one WAVE computes on its own (no LDS, no barrier): unit u < n_units
+// = 16 columns x 4 group quarters (lane = 4 * column + quarter; quarter sums run over ascending groups,
+// combined as (q0 + q1) + (q2 + q3)); unit n_units = the cost total.  Fixed order: deterministic, and
+// identical whether finalize_stats_kernel or the statistics GEMM's consumer waves run the units.
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ int fin_units(const FinArgs& f) { return (int)((f.ldh + f.ldv + 15) / 16); }
+
+__device__ __forceinline__ void finalize_unit(const FinArgs& f, int unit, int lane)
+{
+    const int n_units = fin_units(f);
+    if (unit < n_units) {
+        const int cl = lane >> 2, qd = lane & 3;
+        const int64_t i = (int64_t)unit * 16 + cl;
+        const int per = (f.ngroups + 3) / 4;
+        const int gbeg = qd * per, gend = min(f.ngroups, gbeg + per);
+        float a = 0.f;
+        if (i < f.ldh) {
+#pragma unroll 16
+            for (int g = gbeg; g < gend; ++g) a += f.posP[(int64_t)g * f.ldh + i] + f.negP[(int64_t)g * f.ldh + i];
+        } else if (i < f.ldh + f.ldv) {
+            const int64_t j = i - f.ldh;
+#pragma unroll 16
+            for (int g = gbeg; g < gend; ++g) a += f.partV[(int64_t)g * f.ldv + j];
+        }
+        const int l0 = lane & ~3;
+        const float r0 = __shfl(a, l0, 64), r1 = __shfl(a, l0 + 1, 64), r2 = __shfl(a, l0 + 2, 64), r3 = __shfl(a, l0 + 3, 64);
+        const float t = (r0 + r1) + (r2 + r3);
+        if (qd == 0) {
+            if (i < f.ldh) f.s_h[i] = t;
+            else if (i < f.ldh + f.ldv) f.s_v[i - f.ldh] = t;
+            if (f.do_bias) {    // bias half of the update (rbm.py:356-365; same helpers as update_kernel)
+                const BiasUpd& bu = f.bu;
+                if (i < bu.H) {
+                    const float sp = bu.hbs[i];
+                    bu.hbs[i] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
+                    bu.hb[i] = upd_param(bu.hb[i], 1.0f, sp, bu.lr);
+                } else if (i >= f.ldh && i - f.ldh < bu.V) {
+                    const int64_t j = i - f.ldh;
+                    const float sp = bu.vbs[j];
+                    bu.vbs[j] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
+                    bu.vb[j] = upd_param(bu.vb[j], 1.0f, sp, bu.lr);
+                }
+            }
+        }
+    } else if (unit == n_units && f.cost_partials) {
+        float a = 0.f;
+        for (int k = lane; k < f.n_cost; k += 64) a += f.cost_partials[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+        if (lane == 0) {
+            f.cost[0] = a; f.cost[1] = 0.f; f.cost[2] = 0.f; f.cost[3] = 0.f;
+            if (f.do_bias && f.bu.cost_out) f.bu.cost_out[0] = a * f.bu.cost_scale;
+        }
+    }
+}
+
 #ifdef MDBN_STAMP
 // diagnostic build: s_memtime stamps of one block's phases (never compiled into the product)
 #define STAMP(slot)                                                                          \
@@ -472,6 +530,16 @@ __global__ __launch_bounds__(64 * (4 * CW + 4)) void gemm_splitk_kernel(GemmArgs
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+        if constexpr (FUSED == 2) {
+            // bias statistics, cost and bias update ride on the consumers' idle ramp-up (the first slice
+            // is still on its way from HBM): wave-sized units spread over all blocks, wave 0 of every
+            // block first
+            if (g.fin_enabled) {
+                const int nu = fin_units(g.fin);
+                for (int unit = wave * (int)gridDim.x + (int)blockIdx.x; unit <= nu; unit += 4 * (int)gridDim.x)
+                    finalize_unit(g.fin, unit, lane);
+            }
+        }
         gemm_consume<LA, LB, MI, NI, WMI, WNI, KB>(g, smem, acc, nt, wm, wn, i, h);
 #if MFMA_AGPR
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA result -> v_accvgpr_read hazard (asm is opaque to hipcc)
@@ -1210,74 +1278,34 @@ hipError_t launch_gather(const float* src, int64_t n_rows, int64_t cols_ld, int6
 }
 
 // ----------------------------------------------------------------------------------
-// bias statistics (rbm.py:416-417) from the epilogues' 4-row partials, fixed summation
-// order (deterministic):  s_h = sum_g (posP[g] + negP[g]),  s_v = sum_g partV[g];
-// also totals the reconstruction-cost partials.  One block = 64 columns x 4 group slices.
+// bias statistics / cost total / bias update as a kernel of its own (finalize_unit above): one unit
+// per wave.  The single-device fused step runs the same units inside the statistics GEMM instead.
 // ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void finalize_stats_kernel(const float* __restrict__ posP, const float* __restrict__ negP,
-                                                             const float* __restrict__ partV, int ngroups,
-                                                             int64_t ldh, int64_t ldv,
-                                                             const float* __restrict__ cost_partials, int n_cost,
-                                                             float* __restrict__ s_h, float* __restrict__ s_v,
-                                                             float* __restrict__ cost, BiasUpd bu, int do_bias)
+__global__ __launch_bounds__(256) void finalize_stats_kernel(FinArgs f)
 {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-    const int nblk_cols = (int)((ldh + ldv + 63) / 64);
-    if ((int)blockIdx.x < nblk_cols) {
-        float a = 0.f;
-        const int per = (ngroups + 3) / 4;
-        const int gbeg = wave * per, gend = min(ngroups, gbeg + per);
-        if (i < ldh) {
-#pragma unroll 8
-            for (int g = gbeg; g < gend; ++g) a += posP[(int64_t)g * ldh + i] + negP[(int64_t)g * ldh + i];
-        } else if (i < ldh + ldv) {
-            const int64_t j = i - ldh;
-#pragma unroll 8
-            for (int g = gbeg; g < gend; ++g) a += partV[(int64_t)g * ldv + j];
-        }
-        red[wave][lane] = a;
-        __syncthreads();
-        if (wave == 0) {
-            const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-            if (i < ldh) s_h[i] = t;
-            else if (i < ldh + ldv) s_v[i - ldh] = t;
-            if (do_bias) {      // bias half of the update (rbm.py:356-365; same expressions as update_kernel)
-                if (i < bu.H) {
-                    const float sp = bu.hbs[i];
-                    bu.hbs[i] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
-                    bu.hb[i] = upd_param(bu.hb[i], 1.0f, sp, bu.lr);
-                } else if (i >= ldh && i - ldh < bu.V) {
-                    const int64_t j = i - ldh;
-                    const float sp = bu.vbs[j];
-                    bu.vbs[j] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
-                    bu.vb[j] = upd_param(bu.vb[j], 1.0f, sp, bu.lr);
-                }
-            }
-        }
-    } else if (cost_partials) {                 // the extra last block totals the cost
-        __shared__ float cred[4];
-        float a = 0.f;
-        for (int k = threadIdx.x; k < n_cost; k += blockDim.x) a += cost_partials[k];
-        const float t = block_sum(a, cred);
-        if (threadIdx.x == 0) {
-            cost[0] = t; cost[1] = 0.f; cost[2] = 0.f; cost[3] = 0.f;
-            if (do_bias && bu.cost_out) bu.cost_out[0] = t * bu.cost_scale;
-        }
-    }
+    finalize_unit(f, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+FinArgs make_fin_args(const float* posP, const float* negP, const float* partV, int ngroups, int64_t ldh, int64_t ldv,
+                      const float* cost_partials, int n_cost, float* s_h, float* s_v, float* cost,
+                      const BiasUpd* bias_update)
+{
+    FinArgs f;
+    memset(&f, 0, sizeof f);
+    f.posP = posP; f.negP = negP; f.partV = partV; f.ngroups = ngroups; f.ldh = ldh; f.ldv = ldv;
+    f.cost_partials = cost_partials; f.n_cost = n_cost; f.s_h = s_h; f.s_v = s_v; f.cost = cost;
+    if (bias_update) { f.bu = *bias_update; f.do_bias = 1; }
+    return f;
 }
 
 hipError_t launch_finalize_stats(const float* posP, const float* negP, const float* partV, int ngroups,
                                  int64_t ldh, int64_t ldv, const float* cost_partials, int n_cost,
                                  float* s_h, float* s_v, float* cost, const BiasUpd* bias_update, hipStream_t s)
 {
-    const int grid = (int)((ldh + ldv + 63) / 64) + 1;
-    BiasUpd bu;
-    memset(&bu, 0, sizeof bu);
-    if (bias_update) bu = *bias_update;
-    hipLaunchKernelGGL(finalize_stats_kernel, dim3(grid), dim3(256), 0, s, posP, negP, partV, ngroups,
-                       ldh, ldv, cost_partials, n_cost, s_h, s_v, cost, bu, bias_update ? 1 : 0);
+    const FinArgs f = make_fin_args(posP, negP, partV, ngroups, ldh, ldv, cost_partials, n_cost, s_h, s_v, cost,
+                                    bias_update);
+    const int units = (int)((ldh + ldv + 15) / 16) + 1;         // + the cost unit
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3((units + 3) / 4), dim3(256), 0, s, f);
     return hipGetLastError();
 }
 
