@@ -91,7 +91,8 @@ typedef struct mdbn_update_args {
     float n_rows;                   /* divisor of s_h, s_v: rows actually present (rbm.py:416-417) */
     float cost_scale;               /* monitoring cost = stats.cost_sum * cost_scale ...          */
     float *cost_out;                /* ... written here (device scalar) if not NULL               */
-    int32_t phase;                  /* 0 = whole rule; 1 = speeds (+cost) only; 2 = parameters only.
+    int32_t phase;                  /* 0 = whole rule; 1 = speeds (+cost) only; 2 = parameters only;
+                                     * 3 = 1 then 2 in one pass (parameters from the NEW speeds).
                                      * Because the parameter step uses the OLD speed (rbm.py:364-365),
                                      * theta(t+1) never depends on step t's gradient: a data-parallel
                                      * run applies phase 2 at once and phase 1 when the all-reduced

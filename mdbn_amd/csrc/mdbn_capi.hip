@@ -658,7 +658,7 @@ static int check_update_args(const mdbn_update_args* a)
     REQUIRE(a->stats != nullptr && aligned16(a->stats), "stats not aligned");
     REQUIRE(a->hbias && a->hbias_speed && a->vbias && a->vbias_speed, "bias pointers are NULL");
     REQUIRE(a->batch_size > 0.f && a->n_rows > 0.f, "bad divisors");
-    REQUIRE(a->phase >= 0 && a->phase <= 2, "phase must be 0, 1 or 2");
+    REQUIRE(a->phase >= 0 && a->phase <= 3, "phase must be 0, 1, 2 or 3");
     REQUIRE(a->phase == 0 || (a->lambda_1 == 0.f && (a->weightcost == 0.f || a->W0 != nullptr)),
             "split update phases need lambda_1 == 0 and weightcost == 0 or a frozen W0");
     return MDBN_OK;
@@ -768,7 +768,9 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         bu.H = H; bu.V = V; bu.lr = u.lr; bu.mu = u.momentum; bu.inv_rows = 1.0f / u.n_rows;
         bu.cost_scale = u.cost_scale; bu.cost_out = u.cost_out;
     }
-    if (!overlap && !fin_in_gemm)
+    // the unfused LDS-tiled statistics GEMM (data-parallel step) runs the plain finalize units the same way
+    const bool fin_in_plain_gemm = !fuse_upd && !overlap && !p.skinny && g_opt_fused_finalize;
+    if (!overlap && !fin_in_gemm && !fin_in_plain_gemm)
         HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials,
                                      n_cost, s_h, s_v, cost, fuse_upd ? &bu : nullptr, s));
     GemmArgs g;
@@ -790,6 +792,11 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         g.upd.mu = u.momentum; g.upd.inv_bs = 1.0f / u.batch_size;
         HIP_OK(timed_gemm(LAY_MN, LAY_MN, g, s));
         return MDBN_OK;
+    }
+    if (fin_in_plain_gemm) {
+        g.fin_enabled = 1;
+        g.fin = make_fin_args(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials, n_cost,
+                              s_h, s_v, cost, nullptr);
     }
     if (p.splitk == 1) {
         g.C = S;

@@ -530,13 +530,13 @@ __global__ __launch_bounds__(64 * (4 * CW + 4)) void gemm_splitk_kernel(GemmArgs
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-        if constexpr (FUSED == 2) {
-            // bias statistics, cost and bias update ride on the consumers' idle ramp-up (the first slice
-            // is still on its way from HBM): wave-sized units spread over all blocks, wave 0 of every
-            // block first
+        if constexpr (FUSED == 2 || (FUSED == 0 && LA == LAY_MN)) {
+            // statistics GEMM: bias statistics, cost (and, fused step, the bias update) ride on the
+            // consumers' idle ramp-up (the first slice is still on its way from HBM): wave-sized units
+            // spread over all blocks, wave 0 of every block first
             if (g.fin_enabled) {
                 const int nu = fin_units(g.fin);
-                for (int unit = wave * (int)gridDim.x + (int)blockIdx.x; unit <= nu; unit += 4 * (int)gridDim.x)
+                for (int unit = wave * (int)gridDim.x + (int)blockIdx.x; unit <= nu; unit += 4 * CW * (int)gridDim.x)
                     finalize_unit(g.fin, unit, lane);
             }
         }
@@ -1383,7 +1383,9 @@ __device__ __forceinline__ void fused_update_epilogue(const UpdEpi& u, const flo
 //   W'  = W * (1 - 2 lr l2) / (1 + 2 lr l1 / (|W| + eps)) + W_speed(old) * lr
 //   Ws' = g + (W_speed - g) * momentum
 // ----------------------------------------------------------------------------------
-template <bool DO_SPEED, bool DO_PARAMS>
+// NEWSPEED (with both halves): the parameters take the speed computed in this very pass -- phase 1 of
+// step t-1 followed by phase 2 of step t of the overlapped data-parallel order, in one launch
+template <bool DO_SPEED, bool DO_PARAMS, bool NEWSPEED = false>
 __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, float4* __restrict__ Ws,
                                                      const float4* __restrict__ W0, const float4* __restrict__ S,
                                                      int64_t n4, float lr, float l1, float l2, float wc,
@@ -1401,13 +1403,21 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
     {   // biases, one element per thread of the leading blocks (multipliers are exactly 1, rbm.py:356)
         const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         if (i < H) {
-            const float sp = hbs[i];
-            if (do_speed) hbs[i] = upd_speed(upd_scale(s_h[i], inv_rows), sp, mu);
+            float sp = hbs[i];
+            if (do_speed) {
+                const float sn = upd_speed(upd_scale(s_h[i], inv_rows), sp, mu);
+                hbs[i] = sn;
+                if (NEWSPEED) sp = sn;
+            }
             if (do_params) hb[i] = upd_param(hb[i], 1.0f, sp, lr);
         } else if (i < H + V) {
             const int64_t j = i - H;
-            const float sp = vbs[j];
-            if (do_speed) vbs[j] = upd_speed(upd_scale(s_v[j], inv_rows), sp, mu);
+            float sp = vbs[j];
+            if (do_speed) {
+                const float sn = upd_speed(upd_scale(s_v[j], inv_rows), sp, mu);
+                vbs[j] = sn;
+                if (NEWSPEED) sp = sn;
+            }
             if (do_params) vb[j] = upd_param(vb[j], 1.0f, sp, lr);
         }
         if (i == 0 && cost_out && do_speed) cost_out[0] = cost_sum[0] * cost_scale;
@@ -1417,7 +1427,19 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * blockDim.x) {
         const float4 sp = Ws[i];
-        if constexpr (DO_SPEED && DO_PARAMS) {
+        if constexpr (DO_SPEED && DO_PARAMS && NEWSPEED) {      // lambda_1 == 0; weight cost, if any, uses W0
+            const float4 w = W[i], st = S[i];
+            const float4 w0 = wc != 0.0f ? W0[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 sn, wn;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float snj = upd_speed(upd_grad(comp(st, j), inv_bs, wc, comp(w0, j)), comp(sp, j), mu);
+                setc(sn, j, snj);
+                setc(wn, j, upd_param(comp(w, j), decay, snj, lr));
+            }
+            Ws[i] = sn;
+            W[i] = wn;
+        } else if constexpr (DO_SPEED && DO_PARAMS) {
             const float4 w = W[i];
             float4 st;
             if (nslab <= 1) {
@@ -1463,17 +1485,22 @@ hipError_t launch_update(const mdbn_update_args& a, hipStream_t s, const float* 
     const float* s_h = a.stats + a.V * a.ldh;
     const float* s_v = s_h + a.ldh;
     const int grid = (int)std::max<int64_t>(std::min<int64_t>((n4 + 255) / 256, 4096), (a.H + a.V + 255) / 256);
-#define LAUNCH_UPDATE(SP, PA)                                                                          \
-    hipLaunchKernelGGL((update_kernel<SP, PA>), dim3(grid), dim3(256), 0, s, reinterpret_cast<float4*>(a.W), \
+#define LAUNCH_UPDATE_(SP, PA, NS)                                                                     \
+    hipLaunchKernelGGL((update_kernel<SP, PA, NS>), dim3(grid), dim3(256), 0, s, reinterpret_cast<float4*>(a.W), \
                        reinterpret_cast<float4*>(a.W_speed), reinterpret_cast<const float4*>(a.W0),    \
                        reinterpret_cast<const float4*>(S), n4, a.lr, a.lambda_1, a.lambda_2, a.weightcost, \
                        a.momentum, 1.0f / a.batch_size, a.hbias, a.hbias_speed, s_h, a.H, a.vbias,    \
                        a.vbias_speed, s_v, a.V, 1.0f / a.n_rows, s_v + a.ldv, a.cost_scale, a.cost_out, nslab, \
                        slab_stride >> 2)
+#define LAUNCH_UPDATE(SP, PA) LAUNCH_UPDATE_(SP, PA, false)
+#define LAUNCH_UPDATE3() LAUNCH_UPDATE_(true, true, true)
     if (a.phase == 1) LAUNCH_UPDATE(true, false);
     else if (a.phase == 2) LAUNCH_UPDATE(false, true);
+    else if (a.phase == 3) LAUNCH_UPDATE3();
     else LAUNCH_UPDATE(true, true);
 #undef LAUNCH_UPDATE
+#undef LAUNCH_UPDATE3
+#undef LAUNCH_UPDATE_
     return hipGetLastError();
 }
 

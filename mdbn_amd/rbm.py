@@ -206,9 +206,19 @@ class StepFunction(object):
 
         if self.overlap:
             work = self.group.all_reduce_sum_async(stats)
-            self._complete_pending()            # speeds(t) from the statistics of step t-1 ...
-            eng.apply_update(*args, stats, lr, p.lambda_1, p.lambda_2, p.weightcost, momentum,
-                             batch_size, n_global, cost_scale, phase=2, ldv=data.stride(0))   # ... then theta(t+1)
+            if self._pending is not None:
+                # speeds from the reduced statistics of step t-1, then theta(t+1) from those speeds:
+                # phases 1 and 2 back to back touch the same arrays, so they run as ONE pass (phase 3;
+                # the speed half keeps step t-1's momentum and divisors, the parameter half this lr)
+                pwork, pstats, hp, plazy = self._pending
+                self._pending = None
+                pwork.wait()
+                plazy._value = eng.apply_update(*args, pstats, lr, p.lambda_1, p.lambda_2, p.weightcost,
+                                                hp["momentum"], hp["batch_size"], hp["n_rows"],
+                                                hp["cost_scale"], phase=3, ldv=hp["ldv"])
+            else:
+                eng.apply_update(*args, stats, lr, p.lambda_1, p.lambda_2, p.weightcost, momentum,
+                                 batch_size, n_global, cost_scale, phase=2, ldv=data.stride(0))   # theta(t+1)
             lazy = LazyCost(self, self._n_calls)
             self._pending = (work, stats, dict(lr=lr, momentum=momentum, batch_size=batch_size,
                                                n_rows=n_global, cost_scale=cost_scale, ldv=data.stride(0)), lazy)

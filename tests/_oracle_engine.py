@@ -139,6 +139,12 @@ class OracleEngine(object):
 
     def apply_update(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats,
                      lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale, phase=0, ldv=None):
+        if phase == 3:      # speeds, then parameters from the NEW speeds (mdbn_update_args.phase)
+            cost = self.apply_update(W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats, lr, lambda_1,
+                                     lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale, 1, ldv)
+            self.apply_update(W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats, lr, lambda_1,
+                              lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale, 2, ldv)
+            return cost
         V, H = W.shape
         s = rbm_np.RBMState(V, H, W=W.numpy(), hbias=hbias.numpy(), vbias=vbias.numpy(),
                             dtype=self.np_dtype)

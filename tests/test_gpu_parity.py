@@ -717,3 +717,43 @@ def test_large_shapes_against_rocblas(hip_engine, V, H, B):
     dtol = 4 * ptol(H) * max(1.0, float(dref.abs().max()))
     assert float((dpre[:, :V].double() - dref).abs().max()) <= dtol
     assert float((dmean[:, :V] - torch.sigmoid(dpre[:, :V])).abs().max()) <= 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,H", [(130, 70), (4096, 1024)])
+@pytest.mark.parametrize("wc", [0.0, 2e-4])
+def test_update_phase3_is_phase1_then_phase2(hip_engine, V, H, wc):
+    """mdbn_update_args.phase = 3 (the overlapped data-parallel step: speeds of step t-1 from the reduced
+    statistics, then the parameters of step t from those NEW speeds, one pass) must equal phase 1
+    followed by phase 2 bit for bit."""
+    eng = hip_engine
+    rs = np.random.RandomState(V + H)
+    def fresh():
+        W = eng.to_device((0.05 * rs.randn(V, H)).astype(np.float32))
+        return W
+    W_init = (0.05 * rs.randn(V, H)).astype(np.float32)
+    Ws_init = (0.01 * rs.randn(V, H)).astype(np.float32)
+    hb_i, hbs_i = (0.1 * rs.randn(H)).astype(np.float32), (0.01 * rs.randn(H)).astype(np.float32)
+    vb_i, vbs_i = (0.1 * rs.randn(V)).astype(np.float32), (0.01 * rs.randn(V)).astype(np.float32)
+    ldv, ldh = (V + 3) // 4 * 4, (H + 3) // 4 * 4
+    stats_np = np.zeros(V * ldh + ldh + ldv + 4, np.float32)
+    stats_np[:V * ldh].reshape(V, ldh)[:, :H] = rs.randn(V, H) * 30
+    stats_np[V * ldh:V * ldh + H] = rs.randn(H) * 10
+    stats_np[V * ldh + ldh:V * ldh + ldh + V] = rs.randn(V) * 10
+    stats_np[V * ldh + ldh + ldv] = 123.0
+    out = {}
+    for mode in ("split", "fused"):
+        W, Ws = eng.to_device(W_init), eng.to_device(Ws_init)
+        W0 = eng.to_device(W_init) if wc else None
+        hb, hbs, vb, vbs = [eng.to_device(a) for a in (hb_i, hbs_i, vb_i, vbs_i)]
+        stats = eng.to_device(stats_np)
+        args = (W, Ws, W0, hb, hbs, vb, vbs, stats, 0.01, 0.0, 0.1, wc, 0.9, 512.0, 500.0, 0.5)
+        if mode == "split":
+            c = eng.apply_update(*args, phase=1, ldv=ldv)
+            eng.apply_update(*args, phase=2, ldv=ldv)
+        else:
+            c = eng.apply_update(*args, phase=3, ldv=ldv)
+        out[mode] = [t.cpu().numpy() for t in (W, Ws, hb, hbs, vb, vbs)] + [np.float32(float(c))]
+    for a, b in zip(out["split"], out["fused"]):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(out["fused"][0], W_init)
