@@ -106,6 +106,13 @@ class StepFunction(object):
                             and (p.weightcost == 0.0 or p.W0 is not None))
         self._pending = None                # (work, stats, hyper-parameters, LazyCost) of the last step
         self._n_calls = 0
+        if self.group is not None and self.group.world_size > 1 and hasattr(self.engine, "set_option"):
+            # RCCL's all-reduce kernels run beside the next step's GEMMs.  A GEMM block with two MFMA
+            # waves per SIMD fills the CU's register file (3 x 168 VGPRs per SIMD), so a collective
+            # block could only get a CU of its own and the 256-job GEMMs would need a second round;
+            # with one MFMA wave per SIMD (2 x 152) the two kinds of block can share a CU.  Costs
+            # ~2.5% of the GEMMs; to be re-measured on a multi-GPU node.
+            self.engine.set_option("gemm_cw", 1)
         if self.overlap:
             for arr in self.rbm.params_speed:
                 arr._sync_hook = self.flush
