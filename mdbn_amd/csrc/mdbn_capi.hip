@@ -92,12 +92,13 @@ struct Plan {
     int skinny = 0;        // skinny_gemm_kernel: tiles_m x tiles_n = (32*mi)-row tiles x 32-column strips
     int mi = 1;
     int cw = 1;            // MFMA (consumer) waves per SIMD of the tiled kernel
+    int x6 = 0;            // statistics GEMM on the bf16 pipe (stats_bf16x6_kernel)
     int64_t slab_floats(int64_t M, int64_t ldc) const { return (int64_t)splitk * M * ldc; }
     void fill(GemmArgs& g) const
     {
         g.kchunk = kchunk; g.splitk = splitk; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.bn = bn; g.bk = bk;
         g.inner_m = tiles_m <= tiles_n;
-        g.skinny = skinny; g.mi = mi; g.fused = 0; g.cw = cw; g.fin_enabled = 0;
+        g.skinny = skinny; g.mi = mi; g.fused = 0; g.cw = cw; g.fin_enabled = 0; g.x6 = x6;
     }
 };
 
@@ -179,18 +180,41 @@ bool prefer_skinny(int64_t M, int64_t N, int64_t K)
     return M * N * K <= (K <= 512 ? 3 : 1) * g_opt_skinny_max_macs;
 }
 
+
+// mdbn_set_option("gemm_bf16x6"): GEMMs of full 128x128 tiles run on the bf16 matrix pipe with three-way
+// split operands (f32 accuracy, see gemm_bf16x6_kernel); bit 0 = statistics GEMM, bit 1 = forward
+// passes; default 3
+static int g_opt_gemm_bf16x6 = 3;
+
+// Turn an LDS-tiled plan into a bf16x6 plan when the problem is made of whole tiles and slices.
+bool try_bf16x6(Plan& p, int64_t M, int64_t N, int64_t K)
+{
+    if (p.skinny || p.bn != 128 || M % 128 || N % 128 || K % 32 || K < 64) return false;
+    int64_t kchunk = p.kchunk;
+    if (p.splitk > 1 && kchunk % 32) return false;
+    p.x6 = 1;
+    p.bk = 32; p.cw = 1;
+    p.tiles_m = (int)(M / 128); p.tiles_n = (int)(N / 128);
+    if (p.splitk == 1) p.kchunk = (int)K;
+    return true;
+}
+
 // Plan of one forward pass (x[M, K] * op(W) -> [M, N], `ldo` columns stored).
 Plan plan_forward(int64_t M, int64_t N, int64_t K, int64_t ldo)
 {
-    if (!prefer_skinny(M, N, K)) return plan_gemm(M, N, K);
-    return plan_skinny(M, K, ldo, M <= 64);
+    if (prefer_skinny(M, N, K)) return plan_skinny(M, K, ldo, M <= 64);
+    Plan p = plan_gemm(M, N, K);
+    if (g_opt_gemm_bf16x6 & 2) try_bf16x6(p, M, N, K);
+    return p;
 }
 
 // Plan of the statistics GEMM S[V, H] = V2^T P2 over K = 2B.
 Plan plan_stats(int64_t V, int64_t H, int64_t K2, int64_t ldh)
 {
-    if (!prefer_skinny(V, H, K2) || V <= 64) return plan_gemm(V, H, K2);
-    return plan_skinny(V, K2, ldh, false);
+    if (prefer_skinny(V, H, K2) && V > 64) return plan_skinny(V, K2, ldh, false);
+    Plan p = plan_gemm(V, H, K2);
+    if ((g_opt_gemm_bf16x6 & 1) && p.splitk == 1) try_bf16x6(p, V, H, K2);
+    return p;
 }
 
 static unsigned long long* g_stamps = nullptr;     // diagnostic builds only
@@ -320,7 +344,7 @@ int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_
         Plan p = plan_forward(R, Ndim, Kdim, a.ldo);
         bool fuse = false;
         for (;;) {      // shrink the chunk until its slabs (unfused) and cost partials fit
-            fuse = g_opt_fused_epilogue && p.splitk == 1;
+            fuse = g_opt_fused_epilogue && p.splitk == 1 && !p.x6;
             const bool slabs_fit = fuse || p.slab_floats(R, a.ldo) <= ws.slab_floats;
             const int64_t need_cost = !a.want_cost ? 0 : fuse ? (int64_t)p.tiles_m * p.tiles_n : epilogue_blocks(R, a.ldo);
             if (slabs_fit && n_cost + need_cost <= ws.cost_floats) break;
@@ -463,6 +487,10 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     }
     if (strcmp(name, "skinny_max_macs") == 0) {
         g_opt_skinny_max_macs = value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "gemm_bf16x6") == 0) {
+        g_opt_gemm_bf16x6 = (int)value & 3;
         return MDBN_OK;
     }
     if (strcmp(name, "fused_finalize") == 0) {

@@ -620,10 +620,278 @@ static hipError_t launch_gemm_l(const GemmArgs& g, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
+// ----------------------------------------------------------------------------------
+// GEMM on the bf16 matrix pipe at f32 accuracy ("bf16x6"): the tiled kernel's operands (f32 in HBM,
+// K-contiguous or row-contiguous) and outputs (split-K slabs, plain C, or the fused statistics epilogues).
+// Every f32 value is split into three bf16 pieces x = x1 + x2 + x3 (exact: bf16 keeps f32's exponent)
+// and the six piece products with i + j <= 4 run on v_mfma_f32_32x32x16_bf16 with f32 accumulation;
+// the dropped products are <= 3 * 2^-24 relative, the order of f32 rounding itself (measured against
+// float64: the same error as the exact-f32 kernel and rocBLAS, scripts/experiments/bf16x6_gemm.py).
+// Six 32-cycle MFMAs per 16 k replace eight 64-cycle ones.
+//
+// The split happens in the producer waves, together with the transposition the MFMA operand layout
+// needs (8 consecutive k per lane = one 16-byte LDS read): a producer thread loads 8 k-rows x 4
+// columns (8 coalesced float4), splits them with v_cvt_pk_bf16_f32 (4.5 VALU ops per element),
+// transposes in registers and writes, per column and piece, ONE ds_write_b128 of 8 k-values.  LDS
+// plane tile: [128 rows][32 k] bf16, 80-byte row pitch; the 16-byte k-chunk index is XOR-swizzled
+// with (row >> 4) & 3 so that both the transposing writes (rows 4 apart per lane) and the fragment
+// reads (rows 1 apart) are bank-conflict free.  Nothing upstream changes: operands stay f32 in HBM.
+// 128x128 block tile, 32-deep slices, 4 producer + 4 consumer waves (2x2 grid of 64x64 wave tiles),
+// double-buffered LDS; epilogues as the tiled kernel (split-K slab / plain store, or FUSED = 2: finalize
+// units in the consumers' ramp-up and the parameter update on the parked tile).  Requires M, N
+// multiples of 128 and K ranges of whole 32-slices (the host falls back to the f32 kernel).
+// ----------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+
+constexpr int X6_KB = 32, X6_ROWB = 80, X6_PLANE = 128 * X6_ROWB, X6_BUF = 6 * X6_PLANE;
+
+// split two floats into three packed-bf16 pairs (lo half = first value)
+__device__ __forceinline__ void x6_split2(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3)
+{
+    f32x2 v = {a, b};
+    const bf16x2 h1 = __builtin_convertvector(v, bf16x2);
+    v -= __builtin_convertvector(h1, f32x2);
+    const bf16x2 h2 = __builtin_convertvector(v, bf16x2);
+    v -= __builtin_convertvector(h2, f32x2);
+    const bf16x2 h3 = __builtin_convertvector(v, bf16x2);
+    p1 = __builtin_bit_cast(unsigned, h1);
+    p2 = __builtin_bit_cast(unsigned, h2);
+    p3 = __builtin_bit_cast(unsigned, h3);
+}
+
+// One operand's staging loop (two producer waves = 128 threads per operand).  LX = LAY_MN: P[k][ld],
+// rows contiguous -- a thread owns rows 4*mg..+3 and k-octet ko, loads 8 k-rows x float4 and transposes
+// in registers.  LX = LAY_K: P[row][ld], k contiguous -- a thread owns k-octet ko of rows rb + 32*jj and
+// loads two float4 per row.  Either way: 8 float4 per thread and slice, 12 ds_write_b128.
+template <int LX>
+__device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t ld, int row0, int kbeg, int nt,
+                                           unsigned char* __restrict__ planes /* this operand's 3 planes, buffer 0 */)
+{
+    constexpr int KB = X6_KB;
+    const int t = threadIdx.x & 127;
+    f32x4n r0[8], r1[8];                            // two register sets: two slices ahead
+    if constexpr (LX == LAY_MN) {
+        const int mg = t & 31, ko = t >> 5;
+        const float* src = P + row0 + 4 * mg + (int64_t)(kbeg + ko * 8) * ld;
+        unsigned char* const dst0 = planes + (4 * mg) * X6_ROWB + ((ko ^ ((mg >> 2) & 3)) << 4);
+#define X6_LOAD(R, SLICE)                                                                         \
+    _Pragma("unroll") for (int rr = 0; rr < 8; ++rr)                                              \
+        R[rr] = *reinterpret_cast<const f32x4n*>(src + (int64_t)((SLICE) * KB + rr) * ld)
+#define X6_STORE(R, BUF)                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+        u32x4 p1, p2, p3;                                                                         \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                        \
+            unsigned a1, a2, a3;                                                                  \
+            x6_split2(R[2 * kk][j], R[2 * kk + 1][j], a1, a2, a3);                                \
+            p1[kk] = a1; p2[kk] = a2; p3[kk] = a3;                                                \
+        }                                                                                         \
+        unsigned char* d = dst0 + (BUF) * X6_BUF + j * X6_ROWB;                                   \
+        *reinterpret_cast<u32x4*>(d) = p1;                                                        \
+        *reinterpret_cast<u32x4*>(d + X6_PLANE) = p2;                                             \
+        *reinterpret_cast<u32x4*>(d + 2 * X6_PLANE) = p3;                                         \
+    }
+#define X6_PIPELINE()                                                                             \
+    X6_LOAD(r0, 0);                                                                               \
+    X6_STORE(r0, 0);                                                                              \
+    if (nt > 1) { X6_LOAD(r0, 1); }                                                               \
+    if (nt > 2) { X6_LOAD(r1, 2); }                                                               \
+    __syncthreads();                                                                              \
+    for (int it = 0; it < nt; ++it) {                                                             \
+        if (it + 1 < nt) { X6_STORE(r0, (it + 1) & 1); }                                          \
+        if (it + 3 < nt) { X6_LOAD(r0, it + 3); }                                                 \
+        __syncthreads();                                                                          \
+        if (++it >= nt) break;                                                                    \
+        if (it + 1 < nt) { X6_STORE(r1, (it + 1) & 1); }                                          \
+        if (it + 3 < nt) { X6_LOAD(r1, it + 3); }                                                 \
+        __syncthreads();                                                                          \
+    }
+        X6_PIPELINE()
+#undef X6_LOAD
+#undef X6_STORE
+    } else {
+        const int ko = t & 3, rb = t >> 2;
+        const float* src = P + (int64_t)(row0 + rb) * ld + kbeg + ko * 8;
+        unsigned char* const dst0 = planes + rb * X6_ROWB;
+#define X6_LOAD(R, SLICE)                                                                         \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                            \
+        const float* sp = src + (int64_t)(32 * jj) * ld + (SLICE) * KB;                           \
+        R[2 * jj] = *reinterpret_cast<const f32x4n*>(sp);                                         \
+        R[2 * jj + 1] = *reinterpret_cast<const f32x4n*>(sp + 4);                                 \
+    }
+#define X6_STORE(R, BUF)                                                                          \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                            \
+        u32x4 p1, p2, p3;                                                                         \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                        \
+            unsigned a1, a2, a3;                                                                  \
+            x6_split2(R[2 * jj + (kk >> 1)][2 * (kk & 1)], R[2 * jj + (kk >> 1)][2 * (kk & 1) + 1], a1, a2, a3); \
+            p1[kk] = a1; p2[kk] = a2; p3[kk] = a3;                                                \
+        }                                                                                         \
+        const int row = rb + 32 * jj;                                                             \
+        unsigned char* d = dst0 + (BUF) * X6_BUF + (32 * jj) * X6_ROWB + ((ko ^ ((row >> 4) & 3)) << 4); \
+        *reinterpret_cast<u32x4*>(d) = p1;                                                        \
+        *reinterpret_cast<u32x4*>(d + X6_PLANE) = p2;                                             \
+        *reinterpret_cast<u32x4*>(d + 2 * X6_PLANE) = p3;                                         \
+    }
+        X6_PIPELINE()
+#undef X6_LOAD
+#undef X6_STORE
+#undef X6_PIPELINE
+    }
+}
+
+template <int LA, int LB, int FUSED>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
+{
+    constexpr int BM = 128, BN = 128, KB = X6_KB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char* const lds = reinterpret_cast<unsigned char*>(smem);
+
+    // XCD-aware (split, tile) order, as gemm_splitk_kernel
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int qq = nwg >> 3, rem = nwg & 7;
+    const int w = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + slot;
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int ks = w / tiles, t = w - ks * tiles;
+    int tm, tn;
+    if (g.inner_m) { tn = t / g.tiles_m; tm = t - tn * g.tiles_m; }
+    else           { tm = t / g.tiles_n; tn = t - tm * g.tiles_n; }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = ks * g.kchunk;
+    const int nt = (min(g.K, kbeg + g.kchunk) - kbeg) / KB;      // host: whole slices only
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    if (wave >= 4) {
+        __builtin_amdgcn_s_setprio(PRODUCER_PRIO);
+        if (wave < 6) x6_produce<LA>(g.A, g.lda, m0, kbeg, nt, lds);
+        else x6_produce<LB>(g.B, g.ldb, n0, kbeg, nt, lds + 3 * X6_PLANE);
+        if constexpr (FUSED == 0) return;
+        __builtin_amdgcn_s_setprio(0);
+    } else {
+        // ---- consumers
+        const int lane = threadIdx.x & 63, i = lane & 31, q = lane >> 5;
+        const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+        if constexpr (LA == LAY_MN) {
+            if (g.fin_enabled) {        // statistics GEMM: finalize units on the idle ramp-up
+                const int nu = fin_units(g.fin);
+                for (int unit = wave * (int)gridDim.x + (int)blockIdx.x; unit <= nu; unit += 4 * (int)gridDim.x)
+                    finalize_unit(g.fin, unit, lane);
+            }
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        // per-lane fragment addresses: row pitch 80 B, 16-byte chunk (2 s + q) ^ ((row >> 4) & 3)
+        int offA[2][2], offB[2][2];                 // [32-row block][k-step s]
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                const int ra = wm + 32 * a + i, rb = wn + 32 * a + i;
+                offA[a][sidx] = ra * X6_ROWB + (((2 * sidx + q) ^ ((ra >> 4) & 3)) << 4);
+                offB[a][sidx] = 3 * X6_PLANE + rb * X6_ROWB + (((2 * sidx + q) ^ ((rb >> 4) & 3)) << 4);
+            }
+        __syncthreads();
+        for (int it = 0; it < nt; ++it) {
+            const unsigned char* base = lds + (it & 1) * X6_BUF;
+#pragma unroll
+            for (int sidx = 0; sidx < KB / 16; ++sidx) {
+                bf16x8 af[3][2], bf[3][2];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        af[pl][a] = *reinterpret_cast<const bf16x8*>(base + pl * X6_PLANE + offA[a][sidx]);
+                        bf[pl][a] = *reinterpret_cast<const bf16x8*>(base + pl * X6_PLANE + offB[a][sidx]);
+                    }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {       // smallest products first
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bf[0][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[2][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[1][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[0][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[1][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[0][b], acc[a][b], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+        }
+        // accumulator (32x32): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+        if constexpr (FUSED != 0) {
+            constexpr int LDT = BN + 8;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        smem[(wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * q) * LDT + wn + 32 * b + i] = acc[a][b][e];
+        } else {
+            float* C = g.C + (int64_t)ks * g.slab_stride;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int col = n0 + wn + 32 * b + i;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = m0 + wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * q;
+                        C[(int64_t)row * g.ldc + col] = acc[a][b][e];
+                    }
+                }
+            return;
+        }
+    }
+    if constexpr (FUSED != 0) {
+        __syncthreads();
+        fused_update_epilogue<BM, BN>(g.upd, smem, m0, n0);
+    }
+}
+
+template <int LA, int LB, int FUSED>
+static hipError_t launch_bf16x6_t(const GemmArgs& g, hipStream_t s)
+{
+    constexpr int park = (128 * (128 + 8) + 8) * (int)sizeof(float);
+    constexpr int lds_bytes = 2 * X6_BUF > park ? 2 * X6_BUF : park;
+    static bool attr_set = false;
+    auto kern = gemm_bf16x6_kernel<LA, LB, FUSED>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n * g.splitk), dim3(GEMM_THREADS), lds_bytes, s, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_bf16x6(int la, int lb, const GemmArgs& g, hipStream_t s)
+{
+    if (g.M % 128 || g.N % 128 || g.K % X6_KB || g.kchunk % X6_KB || g.tiles_m != g.M / 128 ||
+        g.tiles_n != g.N / 128 || (g.lda & 3) || (g.ldb & 3) || (g.fused && g.splitk != 1))
+        return hipErrorInvalidValue;
+    if (la == LAY_MN && lb == LAY_MN && g.fused == 2) return launch_bf16x6_t<LAY_MN, LAY_MN, 2>(g, s);
+    if (la == LAY_MN && lb == LAY_MN && g.fused == 0) return launch_bf16x6_t<LAY_MN, LAY_MN, 0>(g, s);
+    if (la == LAY_K && lb == LAY_MN && g.fused == 0) return launch_bf16x6_t<LAY_K, LAY_MN, 0>(g, s);
+    if (la == LAY_K && lb == LAY_K && g.fused == 0) return launch_bf16x6_t<LAY_K, LAY_K, 0>(g, s);
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_skinny_gemm(int la, int lb, const GemmArgs& g, hipStream_t s);
 
 hipError_t launch_gemm(int la, int lb, const GemmArgs& g, hipStream_t s)
 {
+    if (g.x6) return launch_gemm_bf16x6(la, lb, g, s);
     if (g.skinny) return launch_skinny_gemm(la, lb, g, s);
     if (g.fused) {      // forward passes fuse the activation, the statistics GEMM the update (separate
                         // instantiations: the unfused kernels keep their register allocation)

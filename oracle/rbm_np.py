@@ -223,16 +223,19 @@ def apply_update(s, g_W, g_hb, g_vb, lr, lambda_1, lambda_2, momentum):
 
 def cd_step(s, v0, draws, lr=0.1, k=1, lambda_1=0.0, lambda_2=0.0, weightcost=0.0,
             batch_size=None, momentum=0.0, persistent=False, strict_reference=True,
-            return_extras=False, symbolic_grad=False):
+            return_extras=False, symbolic_grad=False, chain_start=None):
     """One call of the compiled step function of rbm.py:258-376 (get_cost_updates +
     theano.function with updates): mutates ``s`` and returns the monitoring cost.
 
     ``persistent=True`` = PCD with the chain kept in ``s.persistent`` (rbm.py:367-371).
+    ``chain_start`` (tests only): start the CD chain from these hidden samples instead of the
+    oracle's own positive-phase sample -- teacher forcing, so that a Bernoulli draw within fp32
+    rounding of its probability on the device cannot fork the two chains.
     """
     v0 = np.asarray(v0, dtype=s.dtype)
     if batch_size is None:
         batch_size = v0.shape[0]
-    chain0 = s.persistent if persistent else None
+    chain0 = s.persistent if persistent else chain_start
     ph_mean, ph_sample, out = cd_chain(s, v0, draws, k, chain0)
     pre_nv, nv_mean, nv_sample, pre_nh, nh_mean, nh_sample = out
     if symbolic_grad:

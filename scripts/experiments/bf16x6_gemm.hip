@@ -65,13 +65,13 @@ __global__ __launch_bounds__(512) void bf16x6_gemm_kernel(const uint16_t* __rest
     // ---- consumers
     const int lane = threadIdx.x & 63, i = lane & 31, q = lane >> 5;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], lo[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+            for (int e = 0; e < 16; ++e) { acc[a][b][e] = 0.f; lo[a][b][e] = 0.f; }
 
     __syncthreads();
     for (int it = 0; it < nt; ++it) {
@@ -92,13 +92,23 @@ __global__ __launch_bounds__(512) void bf16x6_gemm_kernel(const uint16_t* __rest
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    // smallest terms first
+#ifdef X6_TWO_ACC
+                    // the five small products go to their own accumulator: an MFMA adds its 16 products to C
+                    // with the alignment of the largest addend, so small terms added to a large C lose bits
+                    lo[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb][2][a], bf[cb][0][b], lo[a][b], 0, 0, 0);
+                    lo[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb][0][a], bf[cb][2][b], lo[a][b], 0, 0, 0);
+                    lo[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb][1][a], bf[cb][1][b], lo[a][b], 0, 0, 0);
+                    lo[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb][1][a], bf[cb][0][b], lo[a][b], 0, 0, 0);
+                    lo[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb][0][a], bf[cb][1][b], lo[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb][0][a], bf[cb][0][b], acc[a][b], 0, 0, 0);
+#else
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb][2][a], bf[cb][0][b], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb][0][a], bf[cb][2][b], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb][1][a], bf[cb][1][b], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb][1][a], bf[cb][0][b], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb][0][a], bf[cb][1][b], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb][0][a], bf[cb][0][b], acc[a][b], 0, 0, 0);
+#endif
                 }
             // one fragment read of the next step behind every second MFMA
 #pragma unroll
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(512) void bf16x6_gemm_kernel(const uint16_t* __rest
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                C[(int64_t)(m0 + wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * q) * N + n0 + wn + 32 * b + i] = acc[a][b][e];
+                C[(int64_t)(m0 + wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * q) * N + n0 + wn + 32 * b + i] = acc[a][b][e] + lo[a][b][e];
 }
 
 extern "C" int bf16x6_gemm(void* stream, const void* A, const void* B, float* C, int M, int N, int K)

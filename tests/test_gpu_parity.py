@@ -356,8 +356,16 @@ def test_config4_two_layer_dbn_full_width(hip_engine):
     idx = [np.arange(B), np.arange(B) + B]
     for t in range(2):                                   # layer 0: GRBM, lr 0.001 (stable), momentum 0
         c = float(fns[0](indexes=idx[t], momentum=0.0, lr=0.001))
-        c_o = rbm_np.cd_step(s0, x[idx[t]], PhiloxDraws(r0.theano_rng.seed, r0.stream_id, t), lr=0.001, k=1,
-                             lambda_2=0.1, batch_size=B)
+        # teacher forcing: the oracle's chain starts from the device's positive-phase sample, which must
+        # equal the oracle's own wherever the uniform is not within fp32 rounding of the probability
+        hs_dev = hip_engine.cd_scratch(B, 4096, 1024, False, fns[0]._data().stride(0), r0.W.tensor.stride(0)).hs
+        hs_dev = hs_dev.cpu().numpy()[:, :1024].astype(np.float64)
+        draws = PhiloxDraws(r0.theano_rng.seed, r0.stream_id, t)
+        p_o = rbm_np.propup(s0, x[idx[t]].astype(np.float64))[1]
+        u = draws.u(0, B, 1024)
+        flips = hs_dev != (u < p_o)
+        assert np.all(np.abs(u - p_o)[flips] < 1e-6) and flips.sum() <= 4, "sample differs away from a tie"
+        c_o = rbm_np.cd_step(s0, x[idx[t]], draws, lr=0.001, k=1, lambda_2=0.1, batch_size=B, chain_start=hs_dev)
         assert abs(c - c_o) <= 1e-4 * abs(c_o)
     assert np.abs(r0.W.get_value() - s0.W).max() <= 2e-6
     lower = rbm_np.mlp_forward([s0.W], [s0.hbias], x.astype(np.float64), 0)
