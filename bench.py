@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 V, H, B_PER_GPU, N_DATA, K_GIBBS = 4096, 1024, 512, 32768, 1
 LR, LAMBDA_1, LAMBDA_2 = 0.001, 0.0, 0.1          # lr 0.005 (MDBN.py:49) diverges on this synthetic shape; see DESIGN.md
 MFMA_F32_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md: f32-input MFMA, dense
+MFMA_BF16_PEAK_TFLOPS = 2500.0                    # MI355X_MICROARCH.md: bf16 MFMA, dense
 
 
 def gemm_traffic_bytes():
@@ -130,13 +131,33 @@ def main():
         elapsed = float(t.item())
     final_cost = float(cost)
 
-    # dominant kernel: the f32-MFMA GEMM (5 launches per CD-1 step, 2*B*V*H FLOP each);
-    # average duration from HIP events on the launch stream over the same K steps
+    # dominant kernel: the MFMA GEMM (4 launches per CD-1 step); average duration from HIP events on
+    # the launch stream over the same K steps
     eng.kernel_timing(True)
     run(args.steps, args.warmup + args.steps)
     torch.cuda.synchronize(dev)
     n_launch, gemm_ms = eng.kernel_timing_read()
     eng.kernel_timing(False)
+
+    # the same K steps with the GEMMs forced onto the exact-f32 MFMA (v_mfma_f32_32x32x2_f32): by default
+    # they run on the bf16 matrix pipe with three-way split operands and f32 accumulation (f32 accuracy,
+    # DESIGN.md section 3); both numbers are reported
+    exact_ms = exact_gemm_us = None
+    if world == 1:
+        eng.set_option("gemm_bf16x6", 0)
+        run(args.warmup, 0)
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps, args.warmup)
+        barrier()
+        exact_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+        eng.kernel_timing(True)
+        run(args.steps, args.warmup + args.steps)
+        torch.cuda.synchronize(dev)
+        n2, ms2 = eng.kernel_timing_read()
+        eng.kernel_timing(False)
+        exact_gemm_us = 1e3 * ms2 / max(n2, 1)
+        eng.set_option("gemm_bf16x6", 3)
 
     # free-energy parity of the trained model vs the float64 oracle (north star: <= 1e-4 rel)
     fe_rel = fe_rel_elem = None
@@ -171,6 +192,10 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "arithmetic": "f32 operands split exactly into 3 bf16 pieces, 6 products on v_mfma_f32_32x32x16_bf16, f32 accumulate "
+                      "(error vs float64 = rocBLAS sgemm's); exact_f32_mfma_* = the same step on v_mfma_f32_32x32x2_f32",
+        "exact_f32_mfma_ms_per_step": exact_ms,
+        "exact_f32_mfma_value": (B_global * K_GIBBS * 1e3 / exact_ms) if exact_ms else None,
         "config": {"workload": "GRBM 4096->1024 CD-1, batch %d per GPU, fp32, N(0,1) rows resident in HBM "
                                "(BASELINE configs[%d])" % (B_PER_GPU, 1 if world == 1 else 2),
                    "global_batch": B_global, "k": K_GIBBS, "n_data": N_DATA,
@@ -181,12 +206,20 @@ def main():
         "final_cost": final_cost,
         "free_energy_max_rel_err_vs_f64_oracle": fe_rel,
         "free_energy_max_elementwise_rel_err": fe_rel_elem,
-        "roofline": {"bound": "mfma", "kernel": "gemm_splitk_kernel (v_mfma_f32_32x32x2_f32)",
+        # achieved = ALGORITHMIC f32 FLOPs per launch / average launch duration; peak = the dense f32 MFMA
+        # peak (the dtype's).  The default kernel issues 6 bf16 products per algorithmic product on the
+        # bf16 pipe (2.5 PFLOP/s dense): pipe_frac prices that work against that pipe.
+        "roofline": {"bound": "mfma", "kernel": "gemm_bf16x6_kernel (v_mfma_f32_32x32x16_bf16, 3-way split operands)",
                      "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": (achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None,
                      "traffic": gemm_traffic_bytes(),
                      "launches_timed": n_launch, "launches_per_step": launches_per_step, "avg_launch_us": 1e6 * avg_gemm_s,
-                     "algorithmic_flop_per_launch": flop_per_gemm},
+                     "algorithmic_flop_per_launch": flop_per_gemm,
+                     "pipe": "bf16 MFMA", "pipe_flop_per_launch": 6 * flop_per_gemm, "pipe_peak": MFMA_BF16_PEAK_TFLOPS,
+                     "pipe_frac": (6 * achieved / MFMA_BF16_PEAK_TFLOPS) if achieved else None,
+                     "exact_f32_mfma_avg_launch_us": exact_gemm_us,
+                     "exact_f32_mfma_frac": (flop_per_gemm / (exact_gemm_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS)
+                                            if exact_gemm_us else None},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
