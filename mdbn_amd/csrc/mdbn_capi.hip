@@ -331,6 +331,9 @@ struct Affine {
     bool want_cost;
     const mdbn_rng* rng; uint32_t draw;
     float* colsum = nullptr; int colsum_kind = 0;
+    // x holds 0/1 samples written by our own epilogues (a Gibbs chain state): exactly representable
+    // in bf16, so the bf16x6 kernel needs one piece of it and three products instead of six
+    bool x_binary = false;
 };
 
 int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_out)
@@ -359,6 +362,7 @@ int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_
         g.slab_stride = R * a.ldo;
         g.M = (int)R; g.N = (int)Ndim; g.K = (int)Kdim; g.Nst = (int)a.ldo;
         p.fill(g);
+        if (p.x6 && a.x_binary) g.x6 = 2;
 
         EpiArgs e;
         e.slabs = ws.slabs; e.slab_stride = g.slab_stride; e.nsplit = p.splitk;
@@ -741,6 +745,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         Affine down{chain, B, ldh, a->W, V, H, ldh, 1, a->vbias, nullptr, samp_stats ? nullptr : nv,
                     a->gauss ? nullptr : (samp_stats ? nv : a->vs),
                     ldv, 1.0f, a->gauss, last ? v0 : nullptr, ldv, last, &a->rng, (uint32_t)(2 * t - 1)};
+        down.x_binary = chain == a->hs;         // our own 0/1 hidden samples (a caller's persistent chain may hold anything)
         if (last) { down.colsum = ws.colV; down.colsum_kind = samp_stats ? 2 : 1; }   // sum_rows (v0 - nv)
         CHECK(run_affine(down, ws, s, last ? &n_cost : nullptr));
         // h_t | v_t: from the mean for GRBM (rbm.py:669), from the sample for RBM (rbm.py:246)
@@ -748,6 +753,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         float* hdst = (last && a->persistent) ? a->persistent : a->hs;            // rbm.py:369
         Affine up{(a->gauss || samp_stats) ? nv : a->vs, B, ldv, a->W, V, H, ldh, 0, a->hbias, nullptr, nh,
                   need_sample ? hdst : nullptr, ldh, -1.0f, 0, nullptr, 0, false, &a->rng, (uint32_t)(2 * t)};
+        up.x_binary = !a->gauss;                // Bernoulli visibles: the chain feeds the 0/1 sample upward
         if (last) up.colsum = ws.colPneg;                               // sum_rows (-nh_mean)
         CHECK(run_affine(up, ws, s, nullptr));
     }

@@ -69,7 +69,8 @@ struct GemmArgs {
     int bn;                // block tile is 128 x bn (128 or 64)
     int bk;                // slice depth along the reduction index (32 or 64; 64 only with bn = 128)
     int inner_m;           // work-list order inside one split: 1 = tile_m fastest
-    int x6;                // 1: bf16 matrix pipe at f32 accuracy (gemm_bf16x6_kernel; full 128x128 tiles only)
+    int x6;                // 1: bf16 matrix pipe at f32 accuracy (gemm_bf16x6_kernel; full 128x128 tiles only);
+                           // 2: the same with a one-piece A operand (A holds 0/1 samples: 3 products instead of 6)
     int cw;                // MFMA waves per SIMD (1 | 2; 2 only for unfused 128-column tiles)
     unsigned long long* stamps;   // diagnostic builds only (-DMDBN_STAMP); NULL otherwise
     int skinny;            // 1: skinny_gemm_kernel (tiles_n = 32-column strips, tiles_m = (32*mi)-row tiles,

@@ -667,7 +667,9 @@ __device__ __forceinline__ void x6_split2(float a, float b, unsigned& p1, unsign
 // rows contiguous -- a thread owns rows 4*mg..+3 and k-octet ko, loads 8 k-rows x float4 and transposes
 // in registers.  LX = LAY_K: P[row][ld], k contiguous -- a thread owns k-octet ko of rows rb + 32*jj and
 // loads two float4 per row.  Either way: 8 float4 per thread and slice, 12 ds_write_b128.
-template <int LX>
+// NP = pieces stored (3, or 1 for an operand whose values are exactly representable in bf16: the 0/1
+// samples of a Gibbs chain -- the other two pieces would be zero)
+template <int LX, int NP = 3>
 __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t ld, int row0, int kbeg, int nt,
                                            unsigned char* __restrict__ planes /* this operand's 3 planes, buffer 0 */)
 {
@@ -691,8 +693,10 @@ __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t 
         }                                                                                         \
         unsigned char* d = dst0 + (BUF) * X6_BUF + j * X6_ROWB;                                   \
         *reinterpret_cast<u32x4*>(d) = p1;                                                        \
-        *reinterpret_cast<u32x4*>(d + X6_PLANE) = p2;                                             \
-        *reinterpret_cast<u32x4*>(d + 2 * X6_PLANE) = p3;                                         \
+        if (NP == 3) {                                                                            \
+            *reinterpret_cast<u32x4*>(d + X6_PLANE) = p2;                                         \
+            *reinterpret_cast<u32x4*>(d + 2 * X6_PLANE) = p3;                                     \
+        }                                                                                         \
     }
 #define X6_PIPELINE()                                                                             \
     X6_LOAD(r0, 0);                                                                               \
@@ -733,8 +737,10 @@ __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t 
         const int row = rb + 32 * jj;                                                             \
         unsigned char* d = dst0 + (BUF) * X6_BUF + (32 * jj) * X6_ROWB + ((ko ^ ((row >> 4) & 3)) << 4); \
         *reinterpret_cast<u32x4*>(d) = p1;                                                        \
-        *reinterpret_cast<u32x4*>(d + X6_PLANE) = p2;                                             \
-        *reinterpret_cast<u32x4*>(d + 2 * X6_PLANE) = p3;                                         \
+        if (NP == 3) {                                                                            \
+            *reinterpret_cast<u32x4*>(d + X6_PLANE) = p2;                                         \
+            *reinterpret_cast<u32x4*>(d + 2 * X6_PLANE) = p3;                                     \
+        }                                                                                         \
     }
         X6_PIPELINE()
 #undef X6_LOAD
@@ -743,7 +749,8 @@ __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t 
     }
 }
 
-template <int LA, int LB, int FUSED>
+// AP = pieces of the A operand (3, or 1 when A holds 0/1 samples: three products instead of six)
+template <int LA, int LB, int FUSED, int AP = 3>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
 {
     constexpr int BM = 128, BN = 128, KB = X6_KB;
@@ -767,7 +774,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
 
     if (wave >= 4) {
         __builtin_amdgcn_s_setprio(PRODUCER_PRIO);
-        if (wave < 6) x6_produce<LA>(g.A, g.lda, m0, kbeg, nt, lds);
+        if (wave < 6) x6_produce<LA, AP>(g.A, g.lda, m0, kbeg, nt, lds);
         else x6_produce<LB>(g.B, g.ldb, n0, kbeg, nt, lds + 3 * X6_PLANE);
         if constexpr (FUSED == 0) return;
         __builtin_amdgcn_s_setprio(0);
@@ -809,19 +816,25 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
-                        af[pl][a] = *reinterpret_cast<const bf16x8*>(base + pl * X6_PLANE + offA[a][sidx]);
+                        if (pl < AP) af[pl][a] = *reinterpret_cast<const bf16x8*>(base + pl * X6_PLANE + offA[a][sidx]);
                         bf[pl][a] = *reinterpret_cast<const bf16x8*>(base + pl * X6_PLANE + offB[a][sidx]);
                     }
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {       // smallest products first
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bf[0][b], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[2][b], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[1][b], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[0][b], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[1][b], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[0][b], acc[a][b], 0, 0, 0);
+                        if constexpr (AP == 3) {
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bf[0][b], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[2][b], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[1][b], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[0][b], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[1][b], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[0][b], acc[a][b], 0, 0, 0);
+                        } else {                        // A = a1 exactly: a1 b3 + a1 b2 + a1 b1 is the full product
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[2][b], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[1][b], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[0][b], acc[a][b], 0, 0, 0);
+                        }
                     }
             }
             __syncthreads();
@@ -858,13 +871,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
     }
 }
 
-template <int LA, int LB, int FUSED>
+template <int LA, int LB, int FUSED, int AP = 3>
 static hipError_t launch_bf16x6_t(const GemmArgs& g, hipStream_t s)
 {
     constexpr int park = (128 * (128 + 8) + 8) * (int)sizeof(float);
     constexpr int lds_bytes = 2 * X6_BUF > park ? 2 * X6_BUF : park;
     static bool attr_set = false;
-    auto kern = gemm_bf16x6_kernel<LA, LB, FUSED>;
+    auto kern = gemm_bf16x6_kernel<LA, LB, FUSED, AP>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -882,8 +895,10 @@ hipError_t launch_gemm_bf16x6(int la, int lb, const GemmArgs& g, hipStream_t s)
         return hipErrorInvalidValue;
     if (la == LAY_MN && lb == LAY_MN && g.fused == 2) return launch_bf16x6_t<LAY_MN, LAY_MN, 2>(g, s);
     if (la == LAY_MN && lb == LAY_MN && g.fused == 0) return launch_bf16x6_t<LAY_MN, LAY_MN, 0>(g, s);
-    if (la == LAY_K && lb == LAY_MN && g.fused == 0) return launch_bf16x6_t<LAY_K, LAY_MN, 0>(g, s);
+    if (la == LAY_K && lb == LAY_K && g.fused == 0 && g.x6 == 2) return launch_bf16x6_t<LAY_K, LAY_K, 0, 1>(g, s);
+    if (la == LAY_K && lb == LAY_MN && g.fused == 0 && g.x6 == 2) return launch_bf16x6_t<LAY_K, LAY_MN, 0, 1>(g, s);
     if (la == LAY_K && lb == LAY_K && g.fused == 0) return launch_bf16x6_t<LAY_K, LAY_K, 0>(g, s);
+    if (la == LAY_K && lb == LAY_MN && g.fused == 0) return launch_bf16x6_t<LAY_K, LAY_MN, 0>(g, s);
     return hipErrorInvalidValue;
 }
 
