@@ -806,39 +806,52 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
                 offA[a][sidx] = ra * X6_ROWB + (((2 * sidx + q) ^ ((ra >> 4) & 3)) << 4);
                 offB[a][sidx] = 3 * X6_PLANE + rb * X6_ROWB + (((2 * sidx + q) ^ ((rb >> 4) & 3)) << 4);
             }
-        __syncthreads();
+        // Software pipeline over the two 16-k steps of a slice, with the slice barrier BETWEEN them:
+        //   F1 <- fragments(step 1, slice it)         issued under the MFMAs of step 0
+        //   MFMAs(F0)
+        //   barrier: every consumer holds all of slice it in registers (its LDS buffer may be refilled),
+        //            the producers have finished slice it + 1
+        //   F0 <- fragments(step 0, slice it + 1)     issued under the MFMAs of step 1
+        //   MFMAs(F1)
+        // The F0 reload is unconditional: guarded by `it + 1 < nt` the kernel produced garbage (fragment
+        // registers reloaded in a separate basic block while MFMAs of the previous block still read them);
+        // on the last slice it reads the other (stale) buffer and the values are never used.
+        bf16x8 f0a[3][2], f0b[3][2], f1a[3][2], f1b[3][2];
+#define X6_FRAGS(FA, FB, BASE, SIDX)                                                              \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                              \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                           \
+            if (pl < AP) FA[pl][a] = *reinterpret_cast<const bf16x8*>((BASE) + pl * X6_PLANE + offA[a][SIDX]); \
+            FB[pl][a] = *reinterpret_cast<const bf16x8*>((BASE) + pl * X6_PLANE + offB[a][SIDX]);  \
+        }
+#define X6_MMA(FA, FB)                                                                            \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                 \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) {     /* smallest products first */         \
+            if constexpr (AP == 3) {                                                              \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[2][a], FB[0][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[2][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][a], FB[1][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][a], FB[0][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[1][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[0][b], acc[a][b], 0, 0, 0); \
+            } else {        /* A = a1 exactly: a1 b3 + a1 b2 + a1 b1 is the full product */       \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[2][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[1][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[0][b], acc[a][b], 0, 0, 0); \
+            }                                                                                     \
+        }
+        __syncthreads();                             // slice 0 staged
+        X6_FRAGS(f0a, f0b, lds, 0);
         for (int it = 0; it < nt; ++it) {
             const unsigned char* base = lds + (it & 1) * X6_BUF;
-#pragma unroll
-            for (int sidx = 0; sidx < KB / 16; ++sidx) {
-                bf16x8 af[3][2], bf[3][2];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        if (pl < AP) af[pl][a] = *reinterpret_cast<const bf16x8*>(base + pl * X6_PLANE + offA[a][sidx]);
-                        bf[pl][a] = *reinterpret_cast<const bf16x8*>(base + pl * X6_PLANE + offB[a][sidx]);
-                    }
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {       // smallest products first
-                        if constexpr (AP == 3) {
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bf[0][b], acc[a][b], 0, 0, 0);
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[2][b], acc[a][b], 0, 0, 0);
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[1][b], acc[a][b], 0, 0, 0);
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[0][b], acc[a][b], 0, 0, 0);
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[1][b], acc[a][b], 0, 0, 0);
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[0][b], acc[a][b], 0, 0, 0);
-                        } else {                        // A = a1 exactly: a1 b3 + a1 b2 + a1 b1 is the full product
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[2][b], acc[a][b], 0, 0, 0);
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[1][b], acc[a][b], 0, 0, 0);
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[0][b], acc[a][b], 0, 0, 0);
-                        }
-                    }
-            }
-            __syncthreads();
+            const unsigned char* next = lds + ((it + 1) & 1) * X6_BUF;
+            X6_FRAGS(f1a, f1b, base, 1);
+            X6_MMA(f0a, f0b);
+            __syncthreads();                         // (waits for F1: every read of this slice's buffer is done)
+            X6_FRAGS(f0a, f0b, next, 0);
+            X6_MMA(f1a, f1b);
         }
+#undef X6_FRAGS
+#undef X6_MMA
         // accumulator (32x32): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
         if constexpr (FUSED != 0) {
             constexpr int LDT = BN + 8;
