@@ -108,6 +108,9 @@ int  mdbn_ctx_create(mdbn_ctx **out, int device);
 int  mdbn_ctx_destroy(mdbn_ctx *ctx);
 
 /* Tuning knobs (process-wide; results never change beyond fp32 summation order).
+ * "gemm_bf16x6" (default 3): bit 0 = statistics GEMM, bit 1 = forward GEMMs run on the bf16 matrix pipe
+ *   with exactly split f32 operands and f32 accumulation (f32-grade results) when the problem is made of
+ *   whole 128x128 tiles; 0 = always the exact-f32 MFMA kernel.
  * "gemm_bk": GEMM slice depth, 0 = auto, 32 or 64.  "gemm_cw": MFMA waves per SIMD of the tiled
  *   GEMM, 0 = auto (2 for <= 512 rows), 1 or 2.
  * "epilogue_cw": columns per thread of the activation epilogue, 0 = auto, 1, 2 or 4.
