@@ -186,16 +186,25 @@ bool prefer_skinny(int64_t M, int64_t N, int64_t K)
 // passes; default 3
 static int g_opt_gemm_bf16x6 = 3;
 
-// Turn an LDS-tiled plan into a bf16x6 plan when the problem is made of whole tiles and slices.
-bool try_bf16x6(Plan& p, int64_t M, int64_t N, int64_t K)
+// Turn an LDS-tiled plan into a bf16x6 plan (128x128 tiles, 32-deep slices) when that leaves enough
+// jobs to spread over the chip; `unsplit` = the caller needs splitk == 1 (fused statistics epilogue).
+bool try_bf16x6(Plan& p, int64_t M, int64_t N, int64_t K, bool unsplit = false)
 {
-    if (p.skinny || p.bn != 128 || M % 128 || N % 128 || K % 32 || K < 64) return false;
-    int64_t kchunk = p.kchunk;
-    if (p.splitk > 1 && kchunk % 32) return false;
+    if (p.skinny || K < 64) return false;
+    const int64_t tm = (M + 127) / 128, tn = (N + 127) / 128, tiles = tm * tn;
+    int64_t sk = 1;
+    if (!unsplit) {
+        sk = std::min(std::max<int64_t>(1, kTargetJobs / tiles), std::max<int64_t>(1, K / kMinSplitK));
+    } else if (p.splitk != 1) {
+        return false;
+    }
+    if (tiles * sk < 96) return false;                 // too few jobs: the exact kernel's 128x64 tiles spread wider
+    int64_t kchunk = ((K + sk - 1) / sk + 31) / 32 * 32;
+    sk = (K + kchunk - 1) / kchunk;
     p.x6 = 1;
-    p.bk = 32; p.cw = 1;
-    p.tiles_m = (int)(M / 128); p.tiles_n = (int)(N / 128);
-    if (p.splitk == 1) p.kchunk = (int)K;
+    p.bn = 128; p.bk = 32; p.cw = 1;
+    p.tiles_m = (int)tm; p.tiles_n = (int)tn;
+    p.splitk = (int)sk; p.kchunk = (int)kchunk;
     return true;
 }
 
@@ -213,7 +222,7 @@ Plan plan_stats(int64_t V, int64_t H, int64_t K2, int64_t ldh)
 {
     if (prefer_skinny(V, H, K2) && V > 64) return plan_skinny(V, K2, ldh, false);
     Plan p = plan_gemm(V, H, K2);
-    if ((g_opt_gemm_bf16x6 & 1) && p.splitk == 1) try_bf16x6(p, V, H, K2);
+    if ((g_opt_gemm_bf16x6 & 1) && p.splitk == 1) try_bf16x6(p, V, H, K2, true);
     return p;
 }
 
@@ -273,7 +282,7 @@ WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
     WsSizes s;
     const Plan up = plan_gemm(B, H, V), down = plan_gemm(B, V, H), st = plan_gemm(V, H, 2 * B);
     s.slab = std::max(up.slab_floats(B, ldh), down.slab_floats(B, ldv));
-    if (B <= 64) {      // either kernel may serve the pass (mdbn_set_option "skinny_gemm")
+    {       // whichever kernel serves the pass under the current options (skinny / bf16x6 / exact tiles)
         const Plan ups = plan_forward(B, H, V, ldh), downs = plan_forward(B, V, H, ldv);
         s.slab = std::max(s.slab, std::max(ups.slab_floats(B, ldh), downs.slab_floats(B, ldv)));
     }

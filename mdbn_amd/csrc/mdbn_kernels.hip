@@ -638,8 +638,8 @@ static hipError_t launch_gemm_l(const GemmArgs& g, hipStream_t s)
 // reads (rows 1 apart) are bank-conflict free.  Nothing upstream changes: operands stay f32 in HBM.
 // 128x128 block tile, 32-deep slices, 4 producer + 4 consumer waves (2x2 grid of 64x64 wave tiles),
 // double-buffered LDS; epilogues as the tiled kernel (split-K slab / plain store, or FUSED = 2: finalize
-// units in the consumers' ramp-up and the parameter update on the parked tile).  Requires M, N
-// multiples of 128 and K ranges of whole 32-slices (the host falls back to the f32 kernel).
+// units in the consumers' ramp-up and the parameter update on the parked tile).  Edge tiles and the K
+// tail take a guarded producer (rows / k beyond the operand load as zero).
 // ----------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -669,10 +669,13 @@ __device__ __forceinline__ void x6_split2(float a, float b, unsigned& p1, unsign
 // loads two float4 per row.  Either way: 8 float4 per thread and slice, 12 ds_write_b128.
 // NP = pieces stored (3, or 1 for an operand whose values are exactly representable in bf16: the 0/1
 // samples of a Gibbs chain -- the other two pieces would be zero)
-template <int LX, int NP = 3>
+// GUARD: rows >= MN and k >= kend load as zero (edge tiles / K tail); false = interior fast path
+template <int LX, int NP = 3, bool GUARD = false>
 __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t ld, int row0, int kbeg, int nt,
-                                           unsigned char* __restrict__ planes /* this operand's 3 planes, buffer 0 */)
+                                           unsigned char* __restrict__ planes /* this operand's 3 planes, buffer 0 */,
+                                           int MN = 0, int kend = 0)
 {
+    const f32x4n zero4 = {0.f, 0.f, 0.f, 0.f};
     constexpr int KB = X6_KB;
     const int t = threadIdx.x & 127;
     f32x4n r0[8], r1[8];                            // two register sets: two slices ahead
@@ -680,9 +683,12 @@ __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t 
         const int mg = t & 31, ko = t >> 5;
         const float* src = P + row0 + 4 * mg + (int64_t)(kbeg + ko * 8) * ld;
         unsigned char* const dst0 = planes + (4 * mg) * X6_ROWB + ((ko ^ ((mg >> 2) & 3)) << 4);
+        const bool col_ok = !GUARD || row0 + 4 * mg < MN;      /* pad columns up to ld are zero in memory */
 #define X6_LOAD(R, SLICE)                                                                         \
-    _Pragma("unroll") for (int rr = 0; rr < 8; ++rr)                                              \
-        R[rr] = *reinterpret_cast<const f32x4n*>(src + (int64_t)((SLICE) * KB + rr) * ld)
+    _Pragma("unroll") for (int rr = 0; rr < 8; ++rr) {                                            \
+        const bool ok = !GUARD || (col_ok && kbeg + ko * 8 + (SLICE) * KB + rr < kend);           \
+        R[rr] = ok ? *reinterpret_cast<const f32x4n*>(src + (int64_t)((SLICE) * KB + rr) * ld) : zero4; \
+    }
 #define X6_STORE(R, BUF)                                                                          \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
         u32x4 p1, p2, p3;                                                                         \
@@ -723,8 +729,10 @@ __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t 
 #define X6_LOAD(R, SLICE)                                                                         \
     _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                            \
         const float* sp = src + (int64_t)(32 * jj) * ld + (SLICE) * KB;                           \
-        R[2 * jj] = *reinterpret_cast<const f32x4n*>(sp);                                         \
-        R[2 * jj + 1] = *reinterpret_cast<const f32x4n*>(sp + 4);                                 \
+        const int k0 = kbeg + ko * 8 + (SLICE) * KB;                                              \
+        const bool row_ok = !GUARD || row0 + rb + 32 * jj < MN;                                   \
+        R[2 * jj] = (row_ok && (!GUARD || k0 < kend)) ? *reinterpret_cast<const f32x4n*>(sp) : zero4;        \
+        R[2 * jj + 1] = (row_ok && (!GUARD || k0 + 4 < kend)) ? *reinterpret_cast<const f32x4n*>(sp + 4) : zero4; \
     }
 #define X6_STORE(R, BUF)                                                                          \
     _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                            \
@@ -769,13 +777,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
     else           { tm = t / g.tiles_n; tn = t - tm * g.tiles_n; }
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = ks * g.kchunk;
-    const int nt = (min(g.K, kbeg + g.kchunk) - kbeg) / KB;      // host: whole slices only
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nt = (kend - kbeg + KB - 1) / KB;                  // K tail: zero-filled by the guarded producer
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (kbeg + nt * KB <= g.K);
 
     if (wave >= 4) {
         __builtin_amdgcn_s_setprio(PRODUCER_PRIO);
-        if (wave < 6) x6_produce<LA, AP>(g.A, g.lda, m0, kbeg, nt, lds);
-        else x6_produce<LB>(g.B, g.ldb, n0, kbeg, nt, lds + 3 * X6_PLANE);
+        if (interior) {
+            if (wave < 6) x6_produce<LA, AP>(g.A, g.lda, m0, kbeg, nt, lds);
+            else x6_produce<LB>(g.B, g.ldb, n0, kbeg, nt, lds + 3 * X6_PLANE);
+        } else {
+            if (wave < 6) x6_produce<LA, AP, true>(g.A, g.lda, m0, kbeg, nt, lds, g.M, kend);
+            else x6_produce<LB, 3, true>(g.B, g.ldb, n0, kbeg, nt, lds + 3 * X6_PLANE, g.N, kend);
+        }
         if constexpr (FUSED == 0) return;
         __builtin_amdgcn_s_setprio(0);
     } else {
@@ -872,7 +887,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int row = m0 + wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * q;
-                        C[(int64_t)row * g.ldc + col] = acc[a][b][e];
+                        if (interior || (row < g.M && col < g.Nst)) C[(int64_t)row * g.ldc + col] = acc[a][b][e];
                     }
                 }
             return;
@@ -903,8 +918,8 @@ static hipError_t launch_bf16x6_t(const GemmArgs& g, hipStream_t s)
 
 hipError_t launch_gemm_bf16x6(int la, int lb, const GemmArgs& g, hipStream_t s)
 {
-    if (g.M % 128 || g.N % 128 || g.K % X6_KB || g.kchunk % X6_KB || g.tiles_m != g.M / 128 ||
-        g.tiles_n != g.N / 128 || (g.lda & 3) || (g.ldb & 3) || (g.fused && g.splitk != 1))
+    if (g.kchunk % X6_KB || g.tiles_m != (g.M + 127) / 128 || g.tiles_n != (g.N + 127) / 128 || (g.lda & 3) ||
+        (g.ldb & 3) || (g.fused && g.splitk != 1))
         return hipErrorInvalidValue;
     if (la == LAY_MN && lb == LAY_MN && g.fused == 2) return launch_bf16x6_t<LAY_MN, LAY_MN, 2>(g, s);
     if (la == LAY_MN && lb == LAY_MN && g.fused == 0) return launch_bf16x6_t<LAY_MN, LAY_MN, 0>(g, s);
