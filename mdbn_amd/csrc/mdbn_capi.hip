@@ -198,7 +198,7 @@ bool try_bf16x6(Plan& p, int64_t M, int64_t N, int64_t K, bool unsplit = false)
     } else if (p.splitk != 1) {
         return false;
     }
-    if (tiles * sk < 96) return false;                 // too few jobs: the exact kernel's 128x64 tiles spread wider
+    if (tiles * sk < 192) return false;                // too few jobs: the exact kernel's 128x64 tiles spread wider
     int64_t kchunk = ((K + sk - 1) / sk + 31) / 32 * 32;
     sk = (K + kchunk - 1) / kchunk;
     p.x6 = 1;
@@ -222,7 +222,7 @@ Plan plan_stats(int64_t V, int64_t H, int64_t K2, int64_t ldh)
 {
     if (prefer_skinny(V, H, K2) && V > 64) return plan_skinny(V, K2, ldh, false);
     Plan p = plan_gemm(V, H, K2);
-    if ((g_opt_gemm_bf16x6 & 1) && p.splitk == 1) try_bf16x6(p, V, H, K2, true);
+    if (g_opt_gemm_bf16x6 & 1) try_bf16x6(p, V, H, K2, p.splitk == 1);     // unsplit stays unsplit (fused epilogues)
     return p;
 }
 
@@ -287,6 +287,10 @@ WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
         s.slab = std::max(s.slab, std::max(ups.slab_floats(B, ldh), downs.slab_floats(B, ldv)));
     }
     if (st.splitk > 1) s.slab = std::max(s.slab, st.slab_floats(V, ldh));
+    {
+        const Plan st2 = plan_stats(V, H, 2 * B, ldh);        // under the current options (bf16x6 splits differently)
+        if (st2.splitk > 1) s.slab = std::max(s.slab, st2.slab_floats(V, ldh));
+    }
     s.slab = std::max<int64_t>(s.slab, 4 * std::max(ldv, ldh) * 8);
     s.cost = std::max<int64_t>(256, (((B + 3) / 4) * std::max(ldv, ldh) + 255) / 256) + 64;   // worst case: one column per thread
     // fused epilogues write one partial per block: 128 x 64 tiles, or 32-column strips (skinny)
