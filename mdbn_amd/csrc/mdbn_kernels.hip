@@ -650,10 +650,17 @@ typedef float f32x4n __attribute__((ext_vector_type(4)));
 constexpr int X6_KB = 32, X6_ROWB = 80, X6_PLANE = 128 * X6_ROWB, X6_BUF = 6 * X6_PLANE;
 
 // split two floats into three packed-bf16 pairs (lo half = first value)
+#ifndef X6_ABLATE
+#define X6_ABLATE 0     // diagnostic builds only: 1 = no split arithmetic, 2 = no producer LDS stores
+#endif
 __device__ __forceinline__ void x6_split2(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3)
 {
     f32x2 v = {a, b};
     const bf16x2 h1 = __builtin_convertvector(v, bf16x2);
+#if X6_ABLATE == 1
+    p1 = p2 = p3 = __builtin_bit_cast(unsigned, h1);
+    return;
+#endif
     v -= __builtin_convertvector(h1, f32x2);
     const bf16x2 h2 = __builtin_convertvector(v, bf16x2);
     v -= __builtin_convertvector(h2, f32x2);
@@ -711,11 +718,11 @@ __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t 
     if (nt > 2) { X6_LOAD(r1, 2); }                                                               \
     __syncthreads();                                                                              \
     for (int it = 0; it < nt; ++it) {                                                             \
-        if (it + 1 < nt) { X6_STORE(r0, (it + 1) & 1); }                                          \
+        if (it + 1 < nt && X6_ABLATE != 2) { X6_STORE(r0, (it + 1) & 1); }                        \
         if (it + 3 < nt) { X6_LOAD(r0, it + 3); }                                                 \
         __syncthreads();                                                                          \
         if (++it >= nt) break;                                                                    \
-        if (it + 1 < nt) { X6_STORE(r1, (it + 1) & 1); }                                          \
+        if (it + 1 < nt && X6_ABLATE != 2) { X6_STORE(r1, (it + 1) & 1); }                        \
         if (it + 3 < nt) { X6_LOAD(r1, it + 3); }                                                 \
         __syncthreads();                                                                          \
     }
