@@ -764,8 +764,10 @@ __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t 
     }
 }
 
-// AP = pieces of the A operand (3, or 1 when A holds 0/1 samples: three products instead of six)
-template <int LA, int LB, int FUSED, int AP = 3>
+// AP = pieces of the A operand (3, or 1 when A holds 0/1 samples: three products instead of six).
+// RAGGED = false: the host guarantees whole tiles and slices (no guarded code in the kernel at all: the
+// guarded variant costs the whole-tile case 2.6% through register allocation).
+template <int LA, int LB, int FUSED, int AP = 3, bool RAGGED = false>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
 {
     constexpr int BM = 128, BN = 128, KB = X6_KB;
@@ -787,14 +789,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nt = (kend - kbeg + KB - 1) / KB;                  // K tail: zero-filled by the guarded producer
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (kbeg + nt * KB <= g.K);
+    const bool interior = !RAGGED || ((m0 + BM <= g.M) && (n0 + BN <= g.N) && (kbeg + nt * KB <= g.K));
 
     if (wave >= 4) {
         __builtin_amdgcn_s_setprio(PRODUCER_PRIO);
-        if (interior) {
+        if (!RAGGED || interior) {
             if (wave < 6) x6_produce<LA, AP>(g.A, g.lda, m0, kbeg, nt, lds);
             else x6_produce<LB>(g.B, g.ldb, n0, kbeg, nt, lds + 3 * X6_PLANE);
-        } else {
+        } else if constexpr (RAGGED) {
             if (wave < 6) x6_produce<LA, AP, true>(g.A, g.lda, m0, kbeg, nt, lds, g.M, kend);
             else x6_produce<LB, 3, true>(g.B, g.ldb, n0, kbeg, nt, lds + 3 * X6_PLANE, g.N, kend);
         }
@@ -894,7 +896,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int row = m0 + wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * q;
-                        if (interior || (row < g.M && col < g.Nst)) C[(int64_t)row * g.ldc + col] = acc[a][b][e];
+                        if (!RAGGED || interior || (row < g.M && col < g.Nst)) C[(int64_t)row * g.ldc + col] = acc[a][b][e];
                     }
                 }
             return;
@@ -906,13 +908,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
     }
 }
 
-template <int LA, int LB, int FUSED, int AP = 3>
-static hipError_t launch_bf16x6_t(const GemmArgs& g, hipStream_t s)
+template <int LA, int LB, int FUSED, int AP, bool RAGGED>
+static hipError_t launch_bf16x6_r(const GemmArgs& g, hipStream_t s)
 {
     constexpr int park = (128 * (128 + 8) + 8) * (int)sizeof(float);
     constexpr int lds_bytes = 2 * X6_BUF > park ? 2 * X6_BUF : park;
     static bool attr_set = false;
-    auto kern = gemm_bf16x6_kernel<LA, LB, FUSED, AP>;
+    auto kern = gemm_bf16x6_kernel<LA, LB, FUSED, AP, RAGGED>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -921,6 +923,13 @@ static hipError_t launch_bf16x6_t(const GemmArgs& g, hipStream_t s)
     }
     hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n * g.splitk), dim3(GEMM_THREADS), lds_bytes, s, g);
     return hipGetLastError();
+}
+
+template <int LA, int LB, int FUSED, int AP = 3>
+static hipError_t launch_bf16x6_t(const GemmArgs& g, hipStream_t s)
+{
+    const bool whole = g.M % 128 == 0 && g.N % 128 == 0 && g.K % X6_KB == 0 && (g.splitk == 1 || g.kchunk * g.splitk == g.K);
+    return whole ? launch_bf16x6_r<LA, LB, FUSED, AP, false>(g, s) : launch_bf16x6_r<LA, LB, FUSED, AP, true>(g, s);
 }
 
 hipError_t launch_gemm_bf16x6(int la, int lb, const GemmArgs& g, hipStream_t s)
