@@ -765,3 +765,50 @@ def test_update_phase3_is_phase1_then_phase2(hip_engine, V, H, wc):
     for a, b in zip(out["split"], out["fused"]):
         assert np.array_equal(a, b)
     assert not np.array_equal(out["fused"][0], W_init)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,H,B", [(4096, 1024, 512), (2048, 400, 512), (1031, 4097, 777)])
+def test_bf16x6_gemm_is_f32_grade(hip_engine, V, H, B):
+    """The default GEMM path (gemm_bf16x6_kernel: exact three-way bf16 split of the f32 operands, six
+    products on the bf16 MFMA, f32 accumulation) against float64, next to the exact-f32 MFMA kernel
+    on the same inputs: pre-activations of both passes and the CD statistics.  The bar is the f32
+    tolerance of the other parity tests; the split path may not be more than 4x worse than the exact
+    kernel's own error (measured: about equal; rocBLAS sgemm sits at the same level)."""
+    import torch
+    eng = hip_engine
+    g = torch.Generator().manual_seed(V + 3 * H + B)
+    W = (0.03 * torch.randn((V, H), generator=g)).to(eng.device)
+    Wd = eng.alloc_matrix(V, H); Wd.copy_(W)
+    hb = (0.1 * torch.randn(H, generator=g)).to(eng.device)
+    vb = (0.1 * torch.randn(V, generator=g)).to(eng.device)
+    x = torch.randn((B, V), generator=g).to(eng.device)
+    h = torch.rand((B, H), generator=g).to(eng.device)                  # probabilities: three pieces
+    ref_up = x.double() @ W.double() + hb.double()
+    ref_dn = h.double() @ W.double().t() + vb.double()
+    V2 = torch.randn((2 * B, V), generator=g).to(eng.device)
+    P2 = torch.rand((2 * B, H), generator=g).to(eng.device)
+    ref_S = V2.double().t() @ P2.double()
+    err = {}
+    try:
+        for mode in (3, 0):
+            eng.set_option("gemm_bf16x6", mode)
+            up = eng.propup(x, Wd, hb, want_mean=False, want_sample=False)[0][:, :H].double()
+            dn = eng.propdown(h, Wd, vb, gauss=True)[0][:, :V].double()
+            ldv, ldh = (V + 3) // 4 * 4, (H + 3) // 4 * 4
+            V2d, P2d = eng.alloc_matrix(2 * B, V, ldv), eng.alloc_matrix(2 * B, H, ldh)
+            V2d.copy_(V2); P2d.copy_(P2)
+            stats = torch.zeros(V * ldh + ldh + ldv + 4, device=eng.device)
+            ws = eng.workspace(B, V, H)
+            from mdbn_amd import _lib
+            _lib.check(eng.lib.mdbn_cd_stats(eng.ctx, eng._stream(), eng._p(V2d), eng._p(P2d), B, V, H, ldv, ldh,
+                                             eng._p(stats), eng._p(ws), ws.numel() * 4), "mdbn_cd_stats")
+            S = stats[:V * ldh].reshape(V, ldh)[:, :H].double()
+            err[mode] = [float((up - ref_up).abs().max() / ref_up.abs().max()),
+                         float((dn - ref_dn).abs().max() / ref_dn.abs().max()),
+                         float((S - ref_S).abs().max() / ref_S.abs().max())]
+    finally:
+        eng.set_option("gemm_bf16x6", 3)
+    for e6, e0, K in zip(err[3], err[0], (V, H, 2 * B)):
+        assert e6 <= 4 * ptol(K)                       # the f32 bar
+        assert e6 <= 4 * e0 + 1e-7                     # and not materially worse than the exact-f32 MFMA kernel
