@@ -650,6 +650,9 @@ typedef float f32x4n __attribute__((ext_vector_type(4)));
 constexpr int X6_KB = 32, X6_ROWB = 80, X6_PLANE = 128 * X6_ROWB, X6_BUF = 6 * X6_PLANE;
 
 // split two floats into three packed-bf16 pairs (lo half = first value)
+#ifndef X6_DOT2_SPLIT
+#define X6_DOT2_SPLIT 1
+#endif
 #ifndef X6_ABLATE
 #define X6_ABLATE 0     // diagnostic builds only: 1 = no split arithmetic, 2 = no producer LDS stores
 #endif
@@ -661,10 +664,24 @@ __device__ __forceinline__ void x6_split2(float a, float b, unsigned& p1, unsign
     p1 = p2 = p3 = __builtin_bit_cast(unsigned, h1);
     return;
 #endif
+#if X6_DOT2_SPLIT
+    // remainder x - bf16(x) by v_dot2c_f32_bf16 (x + h.lo * c.lo + h.hi * c.hi); the constants are pinned in
+    // VGPRs (as inline constants / literals the packed halves were encoded the other way round)
+    unsigned c10 = 0x0000bf80u, c01 = 0xbf800000u;          // (-1, 0) and (0, -1) as (lo, hi) bf16 pairs
+    asm volatile("" : "+v"(c10), "+v"(c01));
+    const bf16x2 m10 = __builtin_bit_cast(bf16x2, c10), m01 = __builtin_bit_cast(bf16x2, c01);
+    v[0] = __builtin_amdgcn_fdot2_f32_bf16(h1, m10, v[0], false);
+    v[1] = __builtin_amdgcn_fdot2_f32_bf16(h1, m01, v[1], false);
+    const bf16x2 h2 = __builtin_convertvector(v, bf16x2);
+    v[0] = __builtin_amdgcn_fdot2_f32_bf16(h2, m10, v[0], false);
+    v[1] = __builtin_amdgcn_fdot2_f32_bf16(h2, m01, v[1], false);
+    const bf16x2 h3 = __builtin_convertvector(v, bf16x2);
+#else
     v -= __builtin_convertvector(h1, f32x2);
     const bf16x2 h2 = __builtin_convertvector(v, bf16x2);
     v -= __builtin_convertvector(h2, f32x2);
     const bf16x2 h3 = __builtin_convertvector(v, bf16x2);
+#endif
     p1 = __builtin_bit_cast(unsigned, h1);
     p2 = __builtin_bit_cast(unsigned, h2);
     p3 = __builtin_bit_cast(unsigned, h3);

@@ -812,3 +812,31 @@ def test_bf16x6_gemm_is_f32_grade(hip_engine, V, H, B):
     for e6, e0, K in zip(err[3], err[0], (V, H, 2 * B)):
         assert e6 <= 4 * ptol(K)                       # the f32 bar
         assert e6 <= 4 * e0 + 1e-7                     # and not materially worse than the exact-f32 MFMA kernel
+
+
+@pytest.mark.gpu
+def test_bf16x6_split_is_exact(hip_engine):
+    """Multiplying by an identity matrix through the bf16x6 GEMM must return the other operand BIT FOR BIT:
+    that holds only if the in-kernel three-way bf16 split reproduces every f32 value exactly (x = x1 + x2 +
+    x3) and the MFMA accumulation adds the pieces without loss -- for values across many magnitudes."""
+    import torch
+    eng = hip_engine
+    n, B = 1024, 512
+    g = torch.Generator().manual_seed(11)
+    eye = torch.eye(n)
+    Wd = eng.alloc_matrix(n, n); Wd.copy_(eye.to(eng.device))
+    zero = eng.alloc_vector(n)
+    # values over ~30 binades, both signs, plus exact zeros and powers of two
+    vals = torch.randn((B, n), generator=g) * torch.exp2(torch.randint(-20, 10, (B, n), generator=g).float())
+    vals[0, :8] = torch.tensor([0.0, 1.0, -1.0, 2.0 ** -20, 3.0, 1.0 + 2.0 ** -23, -(1.0 + 2.0 ** -12), 255.99998])
+    h = vals.to(eng.device)
+    try:
+        eng.set_option("gemm_bf16x6", 3)
+        pre_dn = eng.propdown(h, Wd, zero, gauss=True)[0]           # A operand (K-contiguous) split
+        assert torch.equal(pre_dn[:, :n], h)
+        W2 = eng.alloc_matrix(n, n); W2.copy_(vals[:n // 2].repeat(2, 1).to(eng.device))
+        x = eng.alloc_matrix(B, n); x.copy_(eye[:B].to(eng.device))
+        pre_up = eng.propup(x, W2, zero, want_mean=False, want_sample=False)[0]   # B operand (row-contiguous) split
+        assert torch.equal(pre_up[:, :n], W2[:B, :n])
+    finally:
+        eng.set_option("gemm_bf16x6", 3)
