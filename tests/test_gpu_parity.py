@@ -840,3 +840,37 @@ def test_bf16x6_split_is_exact(hip_engine):
         assert torch.equal(pre_up[:, :n], W2[:B, :n])
     finally:
         eng.set_option("gemm_bf16x6", 3)
+
+
+@pytest.mark.gpu
+def test_bf16x6_ragged_shapes_match_exact_kernel(hip_engine):
+    """Random ragged shapes (edge tiles in both dimensions, K tails, K not a multiple of 4, split and
+    unsplit K): the bf16x6 path against the exact-f32 kernel on both passes -- same results to the f32
+    accumulation tolerance, pad columns exactly zero."""
+    import torch
+    eng = hip_engine
+    rs = np.random.RandomState(20261004)
+    shapes = [(int(rs.randint(130, 1500)), int(rs.randint(130, 1500)), int(rs.randint(65, 900))) for _ in range(14)]
+    shapes += [(257, 1025, 129), (1281, 129, 640), (999, 1001, 1003)]
+    for V, H, B in shapes:
+        g = torch.Generator().manual_seed(V * 3 + H * 5 + B)
+        Wd = eng.alloc_matrix(V, H); Wd.copy_((0.05 * torch.randn((V, H), generator=g)).to(eng.device))
+        hb = (0.1 * torch.randn(H, generator=g)).to(eng.device)
+        vb = (0.1 * torch.randn(V, generator=g)).to(eng.device)
+        x = eng.alloc_matrix(B, V); x.copy_(torch.randn((B, V), generator=g).to(eng.device))
+        h = eng.alloc_matrix(B, H); h.copy_(torch.rand((B, H), generator=g).to(eng.device))
+        out = {}
+        try:
+            for mode in (3, 0):
+                eng.set_option("gemm_bf16x6", mode)
+                up = eng.propup(x, Wd, hb, want_mean=False, want_sample=False)[0]
+                dn = eng.propdown(h, Wd, vb, gauss=True)[0]
+                out[mode] = (up, dn)
+        finally:
+            eng.set_option("gemm_bf16x6", 3)
+        for a, b, K in zip(out[3], out[0], (V, H)):
+            scale = max(1.0, float(b.abs().max()))
+            assert float((a - b).abs().max()) <= 4 * ptol(K) * scale, (V, H, B)
+            base_a = a._base if a._base is not None else a
+            if base_a.shape[1] > a.shape[1]:
+                assert float(base_a[:, a.shape[1]:].abs().max()) == 0.0, "pad columns must stay zero"
