@@ -360,7 +360,7 @@ int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_
         Plan p = plan_forward(R, Ndim, Kdim, a.ldo);
         bool fuse = false;
         for (;;) {      // shrink the chunk until its slabs (unfused) and cost partials fit
-            fuse = g_opt_fused_epilogue && p.splitk == 1 && !p.x6;
+            fuse = g_opt_fused_epilogue && p.splitk == 1;
             const bool slabs_fit = fuse || p.slab_floats(R, a.ldo) <= ws.slab_floats;
             const int64_t need_cost = !a.want_cost ? 0 : fuse ? (int64_t)p.tiles_m * p.tiles_n : epilogue_blocks(R, a.ldo);
             if (slabs_fit && n_cost + need_cost <= ws.cost_floats) break;

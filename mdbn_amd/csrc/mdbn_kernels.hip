@@ -637,7 +637,8 @@ static hipError_t launch_gemm_l(const GemmArgs& g, hipStream_t s)
 // with (row >> 4) & 3 so that both the transposing writes (rows 4 apart per lane) and the fragment
 // reads (rows 1 apart) are bank-conflict free.  Nothing upstream changes: operands stay f32 in HBM.
 // 128x128 block tile, 32-deep slices, 4 producer + 4 consumer waves (2x2 grid of 64x64 wave tiles),
-// double-buffered LDS; epilogues as the tiled kernel (split-K slab / plain store, or FUSED = 2: finalize
+// double-buffered LDS; epilogues as the tiled kernel (split-K slab / plain store, FUSED = 1: activation
+// + sampling on the parked tile of an unsplit forward pass, FUSED = 2: finalize
 // units in the consumers' ramp-up and the parameter update on the parked tile).  Edge tiles and the K
 // tail take a guarded producer (rows / k beyond the operand load as zero).
 // ----------------------------------------------------------------------------------
@@ -921,7 +922,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
     }
     if constexpr (FUSED != 0) {
         __syncthreads();
-        fused_update_epilogue<BM, BN>(g.upd, smem, m0, n0);
+        if constexpr (FUSED == 1) fused_tile_epilogue<BM, BN>(g.epi, smem, m0, n0);   // activation + sampling
+        else fused_update_epilogue<BM, BN>(g.upd, smem, m0, n0);                       // parameter update
     }
 }
 
@@ -956,6 +958,10 @@ hipError_t launch_gemm_bf16x6(int la, int lb, const GemmArgs& g, hipStream_t s)
         return hipErrorInvalidValue;
     if (la == LAY_MN && lb == LAY_MN && g.fused == 2) return launch_bf16x6_t<LAY_MN, LAY_MN, 2>(g, s);
     if (la == LAY_MN && lb == LAY_MN && g.fused == 0) return launch_bf16x6_t<LAY_MN, LAY_MN, 0>(g, s);
+    if (la == LAY_K && lb == LAY_K && g.fused == 1 && g.x6 == 2) return launch_bf16x6_t<LAY_K, LAY_K, 1, 1>(g, s);
+    if (la == LAY_K && lb == LAY_MN && g.fused == 1 && g.x6 == 2) return launch_bf16x6_t<LAY_K, LAY_MN, 1, 1>(g, s);
+    if (la == LAY_K && lb == LAY_K && g.fused == 1) return launch_bf16x6_t<LAY_K, LAY_K, 1>(g, s);
+    if (la == LAY_K && lb == LAY_MN && g.fused == 1) return launch_bf16x6_t<LAY_K, LAY_MN, 1>(g, s);
     if (la == LAY_K && lb == LAY_K && g.fused == 0 && g.x6 == 2) return launch_bf16x6_t<LAY_K, LAY_K, 0, 1>(g, s);
     if (la == LAY_K && lb == LAY_MN && g.fused == 0 && g.x6 == 2) return launch_bf16x6_t<LAY_K, LAY_MN, 0, 1>(g, s);
     if (la == LAY_K && lb == LAY_K && g.fused == 0) return launch_bf16x6_t<LAY_K, LAY_K, 0>(g, s);
