@@ -651,41 +651,29 @@ typedef float f32x4n __attribute__((ext_vector_type(4)));
 constexpr int X6_KB = 32, X6_ROWB = 80, X6_PLANE = 128 * X6_ROWB, X6_BUF = 6 * X6_PLANE;
 
 // split two floats into three packed-bf16 pairs (lo half = first value)
-#ifndef X6_DOT2_SPLIT
-#define X6_DOT2_SPLIT 1
-#endif
 #ifndef X6_ABLATE
 #define X6_ABLATE 0     // diagnostic builds only: 1 = no split arithmetic, 2 = no producer LDS stores
 #endif
 __device__ __forceinline__ void x6_split2(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3)
 {
-    f32x2 v = {a, b};
-    const bf16x2 h1 = __builtin_convertvector(v, bf16x2);
+    // Truncating split on full-rate integer / f32 instructions: piece = value & 0xffff0000 (the upper half of
+    // an f32 IS a bf16), remainder = value - piece (exact).  Three pieces of 8 significant bits cover the
+    // 24-bit significand exactly; v_perm_b32 packs the upper halves of two values into one dword.  (The
+    // rounding conversion v_cvt_pk_bf16_f32 and v_dot2c_f32_bf16 are quarter-rate: with them the producer
+    // waves needed ~2300 cycles per slice for split + store and the MFMA waves waited at every barrier.)
+    const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
 #if X6_ABLATE == 1
-    p1 = p2 = p3 = __builtin_bit_cast(unsigned, h1);
+    p1 = p2 = p3 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
     return;
 #endif
-#if X6_DOT2_SPLIT
-    // remainder x - bf16(x) by v_dot2c_f32_bf16 (x + h.lo * c.lo + h.hi * c.hi); the constants are pinned in
-    // VGPRs (as inline constants / literals the packed halves were encoded the other way round)
-    unsigned c10 = 0x0000bf80u, c01 = 0xbf800000u;          // (-1, 0) and (0, -1) as (lo, hi) bf16 pairs
-    asm volatile("" : "+v"(c10), "+v"(c01));
-    const bf16x2 m10 = __builtin_bit_cast(bf16x2, c10), m01 = __builtin_bit_cast(bf16x2, c01);
-    v[0] = __builtin_amdgcn_fdot2_f32_bf16(h1, m10, v[0], false);
-    v[1] = __builtin_amdgcn_fdot2_f32_bf16(h1, m01, v[1], false);
-    const bf16x2 h2 = __builtin_convertvector(v, bf16x2);
-    v[0] = __builtin_amdgcn_fdot2_f32_bf16(h2, m10, v[0], false);
-    v[1] = __builtin_amdgcn_fdot2_f32_bf16(h2, m01, v[1], false);
-    const bf16x2 h3 = __builtin_convertvector(v, bf16x2);
-#else
-    v -= __builtin_convertvector(h1, f32x2);
-    const bf16x2 h2 = __builtin_convertvector(v, bf16x2);
-    v -= __builtin_convertvector(h2, f32x2);
-    const bf16x2 h3 = __builtin_convertvector(v, bf16x2);
-#endif
-    p1 = __builtin_bit_cast(unsigned, h1);
-    p2 = __builtin_bit_cast(unsigned, h2);
-    p3 = __builtin_bit_cast(unsigned, h3);
+    const float ra = a - __builtin_bit_cast(float, ua & 0xffff0000u);
+    const float rb = b - __builtin_bit_cast(float, ub & 0xffff0000u);
+    const unsigned va = __builtin_bit_cast(unsigned, ra), vb = __builtin_bit_cast(unsigned, rb);
+    const float sa = ra - __builtin_bit_cast(float, va & 0xffff0000u);
+    const float sb = rb - __builtin_bit_cast(float, vb & 0xffff0000u);
+    p1 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);            // (hi16(b) << 16) | hi16(a)
+    p2 = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+    p3 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), 0x07060302u);
 }
 
 // One operand's staging loop (two producer waves = 128 threads per operand).  LX = LAY_MN: P[k][ld],
@@ -698,9 +686,11 @@ __device__ __forceinline__ void x6_split2(float a, float b, unsigned& p1, unsign
 template <int LX, int NP = 3, bool GUARD = false>
 __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t ld, int row0, int kbeg, int nt,
                                            unsigned char* __restrict__ planes /* this operand's 3 planes, buffer 0 */,
-                                           int MN = 0, int kend = 0)
+                                           int MN = 0, int kend = 0, unsigned long long* stamp_buf = nullptr)
 {
     const f32x4n zero4 = {0.f, 0.f, 0.f, 0.f};
+    const struct { unsigned long long* stamps; } g = {stamp_buf};      // for STAMP() (diagnostic builds)
+    (void)g;
     constexpr int KB = X6_KB;
     const int t = threadIdx.x & 127;
     f32x4n r0[8], r1[8];                            // two register sets: two slices ahead
@@ -729,6 +719,11 @@ __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t 
             *reinterpret_cast<u32x4*>(d + 2 * X6_PLANE) = p3;                                     \
         }                                                                                         \
     }
+#ifdef MDBN_STAMP
+#define X6_DIAG_WAIT() do { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); STAMP(4); } while (0)
+#else
+#define X6_DIAG_WAIT() do { } while (0)
+#endif
 #define X6_PIPELINE()                                                                             \
     X6_LOAD(r0, 0);                                                                               \
     X6_STORE(r0, 0);                                                                              \
@@ -736,13 +731,23 @@ __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t 
     if (nt > 2) { X6_LOAD(r1, 2); }                                                               \
     __syncthreads();                                                                              \
     for (int it = 0; it < nt; ++it) {                                                             \
+        STAMP(0);                                                                                 \
+        X6_DIAG_WAIT();                                                                           \
         if (it + 1 < nt && X6_ABLATE != 2) { X6_STORE(r0, (it + 1) & 1); }                        \
+        STAMP(1);                                                                                 \
         if (it + 3 < nt) { X6_LOAD(r0, it + 3); }                                                 \
+        STAMP(2);                                                                                 \
         __syncthreads();                                                                          \
+        STAMP(3);                                                                                 \
         if (++it >= nt) break;                                                                    \
+        STAMP(0);                                                                                 \
+        X6_DIAG_WAIT();                                                                           \
         if (it + 1 < nt && X6_ABLATE != 2) { X6_STORE(r1, (it + 1) & 1); }                        \
+        STAMP(1);                                                                                 \
         if (it + 3 < nt) { X6_LOAD(r1, it + 3); }                                                 \
+        STAMP(2);                                                                                 \
         __syncthreads();                                                                          \
+        STAMP(3);                                                                                 \
     }
         X6_PIPELINE()
 #undef X6_LOAD
@@ -812,8 +817,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
     if (wave >= 4) {
         __builtin_amdgcn_s_setprio(PRODUCER_PRIO);
         if (!RAGGED || interior) {
-            if (wave < 6) x6_produce<LA, AP>(g.A, g.lda, m0, kbeg, nt, lds);
-            else x6_produce<LB>(g.B, g.ldb, n0, kbeg, nt, lds + 3 * X6_PLANE);
+            if (wave < 6) x6_produce<LA, AP>(g.A, g.lda, m0, kbeg, nt, lds, 0, 0, g.stamps);
+            else x6_produce<LB>(g.B, g.ldb, n0, kbeg, nt, lds + 3 * X6_PLANE, 0, 0, g.stamps);
         } else if constexpr (RAGGED) {
             if (wave < 6) x6_produce<LA, AP, true>(g.A, g.lda, m0, kbeg, nt, lds, g.M, kend);
             else x6_produce<LB, 3, true>(g.B, g.ldb, n0, kbeg, nt, lds + 3 * X6_PLANE, g.N, kend);
@@ -886,11 +891,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
         for (int it = 0; it < nt; ++it) {
             const unsigned char* base = lds + (it & 1) * X6_BUF;
             const unsigned char* next = lds + ((it + 1) & 1) * X6_BUF;
+            STAMP(0);
             X6_FRAGS(f1a, f1b, base, 1);
             X6_MMA(f0a, f0b);
+            STAMP(1);
             __syncthreads();                         // (waits for F1: every read of this slice's buffer is done)
+            STAMP(2);
             X6_FRAGS(f0a, f0b, next, 0);
             X6_MMA(f1a, f1b);
+            STAMP(3);
         }
 #undef X6_FRAGS
 #undef X6_MMA
