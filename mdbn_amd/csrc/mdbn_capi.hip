@@ -60,6 +60,7 @@ int fail(int code, const char* fmt, ...)
     } while (0)
 
 static int g_opt_gemm_bk = 0;          // mdbn_set_option("gemm_bk"): 0 = auto, 32, 64
+static int g_opt_x6_pw = 4;            // mdbn_set_option("x6_producer_waves"): bf16x6 producer waves per operand (2 | 4); 4: step 162.4 -> 158.3 us
 static int g_opt_gemm_cw = 0;          // mdbn_set_option("gemm_cw"): MFMA waves per SIMD of the tiled GEMM, 0 = auto, 1, 2
 // mdbn_set_option("update_overlap"): run finalize + the parameter half of the update on a side
 // stream under the statistics GEMM.  Measured (profile r01j): the fork/join events cost more than
@@ -98,7 +99,7 @@ struct Plan {
     {
         g.kchunk = kchunk; g.splitk = splitk; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.bn = bn; g.bk = bk;
         g.inner_m = tiles_m <= tiles_n;
-        g.skinny = skinny; g.mi = mi; g.fused = 0; g.cw = cw; g.fin_enabled = 0; g.x6 = x6;
+        g.skinny = skinny; g.mi = mi; g.fused = 0; g.cw = cw; g.fin_enabled = 0; g.x6 = x6; g.x6_pw = g_opt_x6_pw;
     }
 };
 
@@ -490,6 +491,11 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     }
     if (strcmp(name, "skinny_fused_max_k") == 0) {
         g_opt_skinny_fused_max_k = value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "x6_producer_waves") == 0) {
+        if (value != 2 && value != 4) return fail(MDBN_EINVAL, "x6_producer_waves must be 2 or 4");
+        g_opt_x6_pw = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "gemm_min_splitk") == 0) {

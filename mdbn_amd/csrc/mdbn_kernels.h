@@ -71,6 +71,7 @@ struct GemmArgs {
     int inner_m;           // work-list order inside one split: 1 = tile_m fastest
     int x6;                // 1: bf16 matrix pipe at f32 accuracy (gemm_bf16x6_kernel; full 128x128 tiles only);
                            // 2: the same with a one-piece A operand (A holds 0/1 samples: 3 products instead of 6)
+    int x6_pw;             // bf16x6: producer waves per operand (2 | 4)
     int cw;                // MFMA waves per SIMD (1 | 2; 2 only for unfused 128-column tiles)
     unsigned long long* stamps;   // diagnostic builds only (-DMDBN_STAMP); NULL otherwise
     int skinny;            // 1: skinny_gemm_kernel (tiles_n = 32-column strips, tiles_m = (32*mi)-row tiles,

@@ -307,9 +307,9 @@ __device__ __forceinline__ void finalize_unit(const FinArgs& f, int unit, int la
 // ----------------------------------------------------------------------------------
 constexpr int GEMM_THREADS = 512;
 
-template <int BM, int BN>
+template <int BM, int BN, int NT = 512>
 __device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, int m0, int n0);
-template <int BM, int BN>
+template <int BM, int BN, int NT = 512>
 __device__ __forceinline__ void fused_update_epilogue(const UpdEpi& u, const float* T, int m0, int n0);
 #ifndef ABLATE_STORE
 #define ABLATE_STORE 0    // diagnostic builds only: timing ablations of the producer
@@ -676,49 +676,33 @@ __device__ __forceinline__ void x6_split2(float a, float b, unsigned& p1, unsign
     p3 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), 0x07060302u);
 }
 
-// One operand's staging loop (two producer waves = 128 threads per operand).  LX = LAY_MN: P[k][ld],
-// rows contiguous -- a thread owns rows 4*mg..+3 and k-octet ko, loads 8 k-rows x float4 and transposes
-// in registers.  LX = LAY_K: P[row][ld], k contiguous -- a thread owns k-octet ko of rows rb + 32*jj and
-// loads two float4 per row.  Either way: 8 float4 per thread and slice, 12 ds_write_b128.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <int NDW>
+__device__ __forceinline__ void x6_store_piece(unsigned char* d, const unsigned (&p)[NDW])
+{
+    if constexpr (NDW == 4) { const u32x4 v = {p[0], p[1], p[2], p[3]}; *reinterpret_cast<u32x4*>(d) = v; }
+    else { const u32x2 v = {p[0], p[1]}; *reinterpret_cast<u32x2*>(d) = v; }
+}
+
+// One operand's staging loop, run by PW producer waves (64 * PW threads) per operand.  LX = LAY_MN:
+// P[k][ld], rows contiguous -- a thread owns rows 4*mg..+3 and 16/PW consecutive k-rows, loads them as
+// float4 and transposes in registers.  LX = LAY_K: P[row][ld], k contiguous -- a thread owns one k-octet of
+// 8/PW rows and loads two float4 per row.  16/PW float4 per thread and slice either way.
 // NP = pieces stored (3, or 1 for an operand whose values are exactly representable in bf16: the 0/1
 // samples of a Gibbs chain -- the other two pieces would be zero)
 // GUARD: rows >= MN and k >= kend load as zero (edge tiles / K tail); false = interior fast path
-template <int LX, int NP = 3, bool GUARD = false>
+template <int LX, int NP = 3, bool GUARD = false, int PW = 2>
 __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t ld, int row0, int kbeg, int nt,
                                            unsigned char* __restrict__ planes /* this operand's 3 planes, buffer 0 */,
+                                           int t /* thread within the operand's producers */,
                                            int MN = 0, int kend = 0, unsigned long long* stamp_buf = nullptr)
 {
+    static_assert(PW == 2 || PW == 4, "2 or 4 producer waves per operand");
     const f32x4n zero4 = {0.f, 0.f, 0.f, 0.f};
     const struct { unsigned long long* stamps; } g = {stamp_buf};      // for STAMP() (diagnostic builds)
     (void)g;
-    constexpr int KB = X6_KB;
-    const int t = threadIdx.x & 127;
-    f32x4n r0[8], r1[8];                            // two register sets: two slices ahead
-    if constexpr (LX == LAY_MN) {
-        const int mg = t & 31, ko = t >> 5;
-        const float* src = P + row0 + 4 * mg + (int64_t)(kbeg + ko * 8) * ld;
-        unsigned char* const dst0 = planes + (4 * mg) * X6_ROWB + ((ko ^ ((mg >> 2) & 3)) << 4);
-        const bool col_ok = !GUARD || row0 + 4 * mg < MN;      /* pad columns up to ld are zero in memory */
-#define X6_LOAD(R, SLICE)                                                                         \
-    _Pragma("unroll") for (int rr = 0; rr < 8; ++rr) {                                            \
-        const bool ok = !GUARD || (col_ok && kbeg + ko * 8 + (SLICE) * KB + rr < kend);           \
-        R[rr] = ok ? *reinterpret_cast<const f32x4n*>(src + (int64_t)((SLICE) * KB + rr) * ld) : zero4; \
-    }
-#define X6_STORE(R, BUF)                                                                          \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
-        u32x4 p1, p2, p3;                                                                         \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                        \
-            unsigned a1, a2, a3;                                                                  \
-            x6_split2(R[2 * kk][j], R[2 * kk + 1][j], a1, a2, a3);                                \
-            p1[kk] = a1; p2[kk] = a2; p3[kk] = a3;                                                \
-        }                                                                                         \
-        unsigned char* d = dst0 + (BUF) * X6_BUF + j * X6_ROWB;                                   \
-        *reinterpret_cast<u32x4*>(d) = p1;                                                        \
-        if (NP == 3) {                                                                            \
-            *reinterpret_cast<u32x4*>(d + X6_PLANE) = p2;                                         \
-            *reinterpret_cast<u32x4*>(d + 2 * X6_PLANE) = p3;                                     \
-        }                                                                                         \
-    }
+    constexpr int KB = X6_KB, NF = 16 / PW;         // float4 per thread and slice
+    f32x4n r0[NF], r1[NF];                          // two register sets: two slices ahead
 #ifdef MDBN_STAMP
 #define X6_DIAG_WAIT() do { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); STAMP(4); } while (0)
 #else
@@ -749,49 +733,75 @@ __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t 
         __syncthreads();                                                                          \
         STAMP(3);                                                                                 \
     }
+    if constexpr (LX == LAY_MN) {
+        // NKR k-rows per thread: a whole k-octet (one 16-byte LDS write per piece) or half of one (8 bytes)
+        constexpr int NKR = NF, NDW = NKR / 2;
+        const int mg = t & 31, kg = t >> 5;                     // column group, k-row group
+        const int chunk = (kg * NKR) >> 3, half = (kg * NKR) & 7;    // 16-byte chunk of the slice, k offset inside
+        const float* src = P + row0 + 4 * mg + (int64_t)(kbeg + kg * NKR) * ld;
+        unsigned char* const dst0 = planes + (4 * mg) * X6_ROWB + ((chunk ^ ((mg >> 2) & 3)) << 4) + 2 * half;
+        const bool col_ok = !GUARD || row0 + 4 * mg < MN;      /* pad columns up to ld are zero in memory */
+#define X6_LOAD(R, SLICE)                                                                         \
+    _Pragma("unroll") for (int rr = 0; rr < NKR; ++rr) {                                          \
+        const bool ok = !GUARD || (col_ok && kbeg + kg * NKR + (SLICE) * KB + rr < kend);         \
+        R[rr] = ok ? *reinterpret_cast<const f32x4n*>(src + (int64_t)((SLICE) * KB + rr) * ld) : zero4; \
+    }
+#define X6_STORE(R, BUF)                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+        unsigned p1[NDW], p2[NDW], p3[NDW];                                                       \
+        _Pragma("unroll") for (int kk = 0; kk < NDW; ++kk)                                        \
+            x6_split2(R[2 * kk][j], R[2 * kk + 1][j], p1[kk], p2[kk], p3[kk]);                    \
+        unsigned char* d = dst0 + (BUF) * X6_BUF + j * X6_ROWB;                                   \
+        x6_store_piece<NDW>(d, p1);                                                               \
+        if (NP == 3) {                                                                            \
+            x6_store_piece<NDW>(d + X6_PLANE, p2);                                                \
+            x6_store_piece<NDW>(d + 2 * X6_PLANE, p3);                                            \
+        }                                                                                         \
+    }
         X6_PIPELINE()
 #undef X6_LOAD
 #undef X6_STORE
     } else {
+        constexpr int NRW = NF / 2, RSTRIDE = 16 * PW;          // rows per thread, distance between them
         const int ko = t & 3, rb = t >> 2;
         const float* src = P + (int64_t)(row0 + rb) * ld + kbeg + ko * 8;
         unsigned char* const dst0 = planes + rb * X6_ROWB;
 #define X6_LOAD(R, SLICE)                                                                         \
-    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                            \
-        const float* sp = src + (int64_t)(32 * jj) * ld + (SLICE) * KB;                           \
+    _Pragma("unroll") for (int jj = 0; jj < NRW; ++jj) {                                          \
+        const float* sp = src + (int64_t)(RSTRIDE * jj) * ld + (SLICE) * KB;                      \
         const int k0 = kbeg + ko * 8 + (SLICE) * KB;                                              \
-        const bool row_ok = !GUARD || row0 + rb + 32 * jj < MN;                                   \
+        const bool row_ok = !GUARD || row0 + rb + RSTRIDE * jj < MN;                              \
         R[2 * jj] = (row_ok && (!GUARD || k0 < kend)) ? *reinterpret_cast<const f32x4n*>(sp) : zero4;        \
         R[2 * jj + 1] = (row_ok && (!GUARD || k0 + 4 < kend)) ? *reinterpret_cast<const f32x4n*>(sp + 4) : zero4; \
     }
 #define X6_STORE(R, BUF)                                                                          \
-    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                            \
-        u32x4 p1, p2, p3;                                                                         \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                        \
-            unsigned a1, a2, a3;                                                                  \
-            x6_split2(R[2 * jj + (kk >> 1)][2 * (kk & 1)], R[2 * jj + (kk >> 1)][2 * (kk & 1) + 1], a1, a2, a3); \
-            p1[kk] = a1; p2[kk] = a2; p3[kk] = a3;                                                \
-        }                                                                                         \
-        const int row = rb + 32 * jj;                                                             \
-        unsigned char* d = dst0 + (BUF) * X6_BUF + (32 * jj) * X6_ROWB + ((ko ^ ((row >> 4) & 3)) << 4); \
-        *reinterpret_cast<u32x4*>(d) = p1;                                                        \
+    _Pragma("unroll") for (int jj = 0; jj < NRW; ++jj) {                                          \
+        unsigned p1[4], p2[4], p3[4];                                                             \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                          \
+            x6_split2(R[2 * jj + (kk >> 1)][2 * (kk & 1)], R[2 * jj + (kk >> 1)][2 * (kk & 1) + 1], p1[kk], p2[kk], p3[kk]); \
+        const int row = rb + RSTRIDE * jj;                                                        \
+        unsigned char* d = dst0 + (BUF) * X6_BUF + (RSTRIDE * jj) * X6_ROWB + ((ko ^ ((row >> 4) & 3)) << 4); \
+        x6_store_piece<4>(d, p1);                                                                 \
         if (NP == 3) {                                                                            \
-            *reinterpret_cast<u32x4*>(d + X6_PLANE) = p2;                                         \
-            *reinterpret_cast<u32x4*>(d + 2 * X6_PLANE) = p3;                                     \
+            x6_store_piece<4>(d + X6_PLANE, p2);                                                  \
+            x6_store_piece<4>(d + 2 * X6_PLANE, p3);                                              \
         }                                                                                         \
     }
         X6_PIPELINE()
 #undef X6_LOAD
 #undef X6_STORE
-#undef X6_PIPELINE
     }
+#undef X6_PIPELINE
+#undef X6_DIAG_WAIT
 }
 
 // AP = pieces of the A operand (3, or 1 when A holds 0/1 samples: three products instead of six).
 // RAGGED = false: the host guarantees whole tiles and slices (no guarded code in the kernel at all: the
 // guarded variant costs the whole-tile case 2.6% through register allocation).
-template <int LA, int LB, int FUSED, int AP = 3, bool RAGGED = false>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
+// PW = producer waves per operand (2: 8-wave block, 4: 12-wave block -- the producers' per-slice latency,
+// which the MFMA waves wait for at the barrier, halves).
+template <int LA, int LB, int FUSED, int AP = 3, bool RAGGED = false, int PW = 2>
+__global__ __launch_bounds__(64 * (4 + 2 * PW)) void gemm_bf16x6_kernel(GemmArgs g)
 {
     constexpr int BM = 128, BN = 128, KB = X6_KB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -816,12 +826,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
 
     if (wave >= 4) {
         __builtin_amdgcn_s_setprio(PRODUCER_PRIO);
+        const bool opA = wave < 4 + PW;
+        const int t = (int)threadIdx.x - 256 - (opA ? 0 : 64 * PW);
         if (!RAGGED || interior) {
-            if (wave < 6) x6_produce<LA, AP>(g.A, g.lda, m0, kbeg, nt, lds, 0, 0, g.stamps);
-            else x6_produce<LB>(g.B, g.ldb, n0, kbeg, nt, lds + 3 * X6_PLANE, 0, 0, g.stamps);
+            if (opA) x6_produce<LA, AP, false, PW>(g.A, g.lda, m0, kbeg, nt, lds, t, 0, 0, g.stamps);
+            else x6_produce<LB, 3, false, PW>(g.B, g.ldb, n0, kbeg, nt, lds + 3 * X6_PLANE, t, 0, 0, g.stamps);
         } else if constexpr (RAGGED) {
-            if (wave < 6) x6_produce<LA, AP, true>(g.A, g.lda, m0, kbeg, nt, lds, g.M, kend);
-            else x6_produce<LB, 3, true>(g.B, g.ldb, n0, kbeg, nt, lds + 3 * X6_PLANE, g.N, kend);
+            if (opA) x6_produce<LA, AP, true, PW>(g.A, g.lda, m0, kbeg, nt, lds, t, g.M, kend);
+            else x6_produce<LB, 3, true, PW>(g.B, g.ldb, n0, kbeg, nt, lds + 3 * X6_PLANE, t, g.N, kend);
         }
         if constexpr (FUSED == 0) return;
         __builtin_amdgcn_s_setprio(0);
@@ -931,26 +943,32 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x6_kernel(GemmArgs g)
     }
     if constexpr (FUSED != 0) {
         __syncthreads();
-        if constexpr (FUSED == 1) fused_tile_epilogue<BM, BN>(g.epi, smem, m0, n0);   // activation + sampling
-        else fused_update_epilogue<BM, BN>(g.upd, smem, m0, n0);                       // parameter update
+        if constexpr (FUSED == 1) fused_tile_epilogue<BM, BN, 64 * (4 + 2 * PW)>(g.epi, smem, m0, n0);   // activation + sampling
+        else fused_update_epilogue<BM, BN, 64 * (4 + 2 * PW)>(g.upd, smem, m0, n0);                       // parameter update
     }
 }
 
-template <int LA, int LB, int FUSED, int AP, bool RAGGED>
-static hipError_t launch_bf16x6_r(const GemmArgs& g, hipStream_t s)
+template <int LA, int LB, int FUSED, int AP, bool RAGGED, int PW>
+static hipError_t launch_bf16x6_p(const GemmArgs& g, hipStream_t s)
 {
     constexpr int park = (128 * (128 + 8) + 8) * (int)sizeof(float);
     constexpr int lds_bytes = 2 * X6_BUF > park ? 2 * X6_BUF : park;
     static bool attr_set = false;
-    auto kern = gemm_bf16x6_kernel<LA, LB, FUSED, AP, RAGGED>;
+    auto kern = gemm_bf16x6_kernel<LA, LB, FUSED, AP, RAGGED, PW>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n * g.splitk), dim3(GEMM_THREADS), lds_bytes, s, g);
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n * g.splitk), dim3(64 * (4 + 2 * PW)), lds_bytes, s, g);
     return hipGetLastError();
+}
+
+template <int LA, int LB, int FUSED, int AP, bool RAGGED>
+static hipError_t launch_bf16x6_r(const GemmArgs& g, hipStream_t s)
+{
+    return g.x6_pw == 4 ? launch_bf16x6_p<LA, LB, FUSED, AP, RAGGED, 4>(g, s) : launch_bf16x6_p<LA, LB, FUSED, AP, RAGGED, 2>(g, s);
 }
 
 template <int LA, int LB, int FUSED, int AP = 3>
@@ -1110,7 +1128,7 @@ __device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, f
     if (e.colsum) e.colsum[(int64_t)(r0 >> 2) * e.ld + col] = csum;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NT>
 __device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, int m0, int n0)
 {
     constexpr int LDT = BN + 8;
@@ -1120,7 +1138,7 @@ __device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, 
     const float bias = live ? e.bias[col] : 0.f;
     float cost = 0.f;
 #pragma unroll 1
-    for (int rg = rg0; rg < BM / 4; rg += GEMM_THREADS / BN) {
+    for (int rg = rg0; rg < BM / 4; rg += NT / BN) {
         const int r0 = m0 + 4 * rg;
         if (r0 >= e.rows || !incol) continue;
         float x[4];
@@ -1699,10 +1717,10 @@ hipError_t launch_colsum_groups(const float* X, const float* Y, int rows, int64_
 // stride BN + 8): W and W_speed are read and written once, S never touches HBM.  The GEMM reads
 // only V2 / P2, so updating W in place under it is safe.  A thread owns one float4 column group and
 // walks rows; 4 rows of loads are in flight per round.
-template <int BM, int BN>
+template <int BM, int BN, int NT>
 __device__ __forceinline__ void fused_update_epilogue(const UpdEpi& u, const float* T, int m0, int n0)
 {
-    constexpr int LDT = BN + 8, C4 = BN / 4, RSTEP = GEMM_THREADS / C4, RB = 4;
+    constexpr int LDT = BN + 8, C4 = BN / 4, RSTEP = NT / C4, RB = 4;
     const int c4 = threadIdx.x % C4, rr = threadIdx.x / C4;
     const int col = n0 + 4 * c4;
     if (col >= (int)u.ld) return;

@@ -12,14 +12,14 @@ W = eng.alloc_matrix(V, H); W.normal_(0, 0.05)
 hb = eng.alloc_vector(H)
 for B in (512, 16384):
     x = eng.alloc_matrix(B, V); x.normal_()
-    stamps = torch.zeros(8 * 64 * 8, dtype=torch.int64, device=eng.device)
+    stamps = torch.zeros(12 * 64 * 8, dtype=torch.int64, device=eng.device)
     for _ in range(3):
         eng.propup(x, W, hb, want_pre=False, want_sample=False)
     lib.mdbn_debug_set_stamps(C.c_void_p(stamps.data_ptr()))
     eng.propup(x, W, hb, want_pre=False, want_sample=False)
     eng.synchronize()
     lib.mdbn_debug_set_stamps(C.c_void_p(0))
-    st = stamps.cpu().numpy().reshape(8, 64, 8)
+    st = stamps.cpu().numpy().reshape(12, 64, 8)
     nt = int((st[0, :, 0] > 0).sum())
     t0 = st[:, 0, 0].min()
     print("B=%d: %d slices stamped" % (B, nt))

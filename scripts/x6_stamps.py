@@ -19,17 +19,19 @@ W = eng.alloc_matrix(V, H); W.normal_(0, 0.05)
 hb = eng.alloc_vector(H)
 for B in (512, 4096):
     x = eng.alloc_matrix(B, V); x.normal_()
-    stamps = torch.zeros(8 * 64 * 8, dtype=torch.int64, device=eng.device)
+    stamps = torch.zeros(12 * 64 * 8, dtype=torch.int64, device=eng.device)      # up to 12 waves per block
     for _ in range(3): eng.propup(x, W, hb, want_pre=False, want_sample=False)
     lib.mdbn_debug_set_stamps(C.c_void_p(stamps.data_ptr()))
     eng.propup(x, W, hb, want_pre=False, want_sample=False)
     eng.synchronize()
     lib.mdbn_debug_set_stamps(C.c_void_p(0))
-    st = stamps.cpu().numpy().reshape(8, 64, 8).astype(np.int64)
+    st = stamps.cpu().numpy().reshape(12, 64, 8).astype(np.int64)
     nt = int((st[0, :, 0] > 0).sum())
     print("B=%d: %d slices stamped" % (B, nt))
-    for w in range(8):
+    for w in range(12):
         s_ = st[w, :nt]
+        if not (s_[:, 0] > 0).any():
+            continue
         tot = s_[1:, 0] - s_[:-1, 0]
         if w < 4:
             d = np.stack([s_[:, 1] - s_[:, 0], s_[:, 2] - s_[:, 1], s_[:, 3] - s_[:, 2]], 1)
