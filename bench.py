@@ -35,7 +35,7 @@ def gemm_traffic_bytes():
     """HBM bytes per GEMM launch from the committed PMC profile (FETCH_SIZE / WRITE_SIZE collected
     in separate rocprofv3 passes and corrected as MI355X_MICROARCH.md prescribes); counters cannot
     be read from inside this process, so the figure is the profiled one, or null if absent."""
-    path = os.path.join(ROOT, "profiles", "r01v_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01w_pmc_traffic.json")
     try:
         with open(path) as f:
             return json.load(f)["gemm_avg_bytes_per_launch"]
