@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Build the library with different -D flags on the GPU box and time the headline step with each.
+    python scripts/build_variants.py "-DX6_SCHED=0" "-DX6_SCHED=1" ..."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = [os.path.join(ROOT, "mdbn_amd", "csrc", f) for f in ("mdbn_kernels.hip", "mdbn_capi.hip")]
+out = os.path.join(ROOT, "gpurun_out"); os.makedirs(out, exist_ok=True)
+for i, flags in enumerate(sys.argv[1:]):
+    so = os.path.join(out, "libmdbn_var%d.so" % i)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"] + flags.split() + src + ["-o", so])
+    prog = r'''
+import sys, time; sys.path.insert(0, %r)
+import numpy as np, torch, mdbn_amd
+from mdbn_amd import _lib
+_lib.LIB_PATH = %r
+eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
+V, H, B, N = 4096, 1024, 512, 32768
+g = torch.Generator(device="cpu").manual_seed(0)
+data = mdbn_amd.shared(torch.randn((N, V), generator=g).to(eng.device))
+rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123))
+_, up = rbm.get_cost_updates(lr=0.001, k=1, lambda_2=0.1, batch_size=B)
+fn = mdbn_amd.function(up, data)
+perm = torch.from_numpy(np.random.RandomState(1).permutation(N)).to(eng.device)
+def run(n):
+    c = None
+    for it in range(n):
+        mb = it %% (N // B)
+        c = fn(indexes=perm[mb * B:(mb + 1) * B], momentum=0.0)
+    return c
+run(30); eng.synchronize()
+ts = []
+for r in range(5):
+    t0 = time.perf_counter(); c = run(100); eng.synchronize(); ts.append((time.perf_counter() - t0) * 1e4)
+print("%%-30s median %%.1f us/step   cost %%.6f" %% (%r, np.median(ts), float(c)), flush=True)
+''' % (ROOT, so, flags)
+    subprocess.check_call([sys.executable, "-c", prog])
