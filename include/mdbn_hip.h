@@ -111,6 +111,7 @@ int  mdbn_ctx_destroy(mdbn_ctx *ctx);
  * "gemm_bf16x6" (default 3): bit 0 = statistics GEMM, bit 1 = forward GEMMs run on the bf16 matrix pipe
  *   with exactly split f32 operands and f32 accumulation (f32-grade results) when the problem is made of
  *   whole 128x128 tiles; 0 = always the exact-f32 MFMA kernel.
+ * "x6_min_jobs" (default 48): problems with fewer 128x128-tile jobs keep the exact-f32 kernel.
  * "x6_producer_waves" (default 4): producer waves per operand of the bf16x6 kernel (2 | 4).
  * "gemm_bk": GEMM slice depth, 0 = auto, 32 or 64.  "gemm_cw": MFMA waves per SIMD of the tiled
  *   GEMM, 0 = auto (2 for <= 512 rows), 1 or 2.

@@ -60,6 +60,7 @@ int fail(int code, const char* fmt, ...)
     } while (0)
 
 static int g_opt_gemm_bk = 0;          // mdbn_set_option("gemm_bk"): 0 = auto, 32, 64
+static int g_opt_x6_min_jobs = 48;     // mdbn_set_option("x6_min_jobs"): fewer 128x128-tile jobs than this keep the exact kernel (192 -> 48: 1024->256 and 512^3 at B = 512 -6%)
 static int g_opt_x6_pw = 4;            // mdbn_set_option("x6_producer_waves"): bf16x6 producer waves per operand (2 | 4); 4: step 162.4 -> 158.3 us
 static int g_opt_gemm_cw = 0;          // mdbn_set_option("gemm_cw"): MFMA waves per SIMD of the tiled GEMM, 0 = auto, 1, 2
 // mdbn_set_option("update_overlap"): run finalize + the parameter half of the update on a side
@@ -199,7 +200,7 @@ bool try_bf16x6(Plan& p, int64_t M, int64_t N, int64_t K, bool unsplit = false)
     } else if (p.splitk != 1) {
         return false;
     }
-    if (tiles * sk < 192) return false;                // too few jobs: the exact kernel's 128x64 tiles spread wider
+    if (tiles * sk < g_opt_x6_min_jobs) return false;  // too few jobs: the exact kernel's 128x64 tiles spread wider
     int64_t kchunk = ((K + sk - 1) / sk + 31) / 32 * 32;
     sk = (K + kchunk - 1) / kchunk;
     p.x6 = 1;
@@ -491,6 +492,10 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     }
     if (strcmp(name, "skinny_fused_max_k") == 0) {
         g_opt_skinny_fused_max_k = value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "x6_min_jobs") == 0) {
+        g_opt_x6_min_jobs = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "x6_producer_waves") == 0) {
