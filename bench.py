@@ -1,21 +1,30 @@
 #!/usr/bin/env python
 """Headline benchmark: CD-1 training steps of the Gaussian-Bernoulli RBM 4096 -> 1024 at
-batch 512 per GPU (BASELINE.json configs[1]; configs[2] when launched with N > 1 ranks).
+batch 512 per GPU (BASELINE.json configs[1]; configs[2] with N > 1 ranks).
 
     python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With --gpus N > 1 and no torchrun environment this process starts the N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` as a CHILD process, before
+anything here has touched the GPU) and relays rank 0's JSON line; under torchrun it is a rank.
 
 One "step" = one call of the compiled step function of reference src/rbm.py:258-376 as
 src/dbn.py:302-312 builds it: minibatch gather, positive phase, one gibbs_hvh, the
 statistics GEMM, (all-reduce over ranks,) parameter update and monitoring cost -- nothing
-skipped.  Inputs are synthetic N(0,1) rows already resident in HBM.  Rank 0 prints ONE JSON
-line (see the driver contract) with `roofline` (dominant kernel = the f32 MFMA GEMM, timed
-by HIP events on its stream) and `cpu_baseline` (the numpy float32 oracle, timed on the
-host cores: Theano is not installable offline, so this is kind "port").
+skipped.  Inputs are synthetic N(0,1) rows already resident in HBM.  Timing: W warm-up steps,
+then windows of exactly K steps, each bracketed by barrier + synchronize on both sides (max
+over ranks); `ms_per_step` is the MEDIAN window (>= 5 windows, more for short ones, so that the
+driver's small K gives the same number as a long run); all windows are listed in `windows_ms`.
+Rank 0 prints ONE JSON line with `roofline` (per-kernel HIP-event times against the matrix pipe
+each kernel issues on) and `cpu_baseline` (the numpy float32 oracle on the host cores: Theano is
+not installable offline, so kind "port").
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,61 +38,147 @@ V, H, B_PER_GPU, N_DATA, K_GIBBS = 4096, 1024, 512, 32768, 1
 LR, LAMBDA_1, LAMBDA_2 = 0.001, 0.0, 0.1          # lr 0.005 (MDBN.py:49) diverges on this synthetic shape; see DESIGN.md
 MFMA_F32_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md: f32-input MFMA, dense
 MFMA_BF16_PEAK_TFLOPS = 2500.0                    # MI355X_MICROARCH.md: bf16 MFMA, dense
+KIND_NAMES = {1: "propup", 0: "propdown", 3: "statistics"}   # 2 * la + lb of mdbn_kernel_timing_detail
 
 
-def gemm_traffic_bytes():
-    """HBM bytes per GEMM launch from the committed PMC profile (FETCH_SIZE / WRITE_SIZE collected
-    in separate rocprofv3 passes and corrected as MI355X_MICROARCH.md prescribes); counters cannot
-    be read from inside this process, so the figure is the profiled one, or null if absent."""
-    path = os.path.join(ROOT, "profiles", "r01w_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["gemm_avg_bytes_per_launch"]
-    except Exception:
-        return None
-
-
-def cpu_baseline(budget_s=20.0):
-    """NumPy float32 restatement of the same step (oracle/rbm_np.py), all host cores via BLAS."""
-    from oracle import rbm_np
-    from oracle.philox_np import PhiloxDraws
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    rs = np.random.RandomState(123)
-    rs.randint(2 ** 30)
-    st = rbm_np.RBMState(V, H, W=rbm_np.init_W(rs, V, H, np.float32), dtype=np.float32, gauss=True)
-    n_rows = 4 * B_PER_GPU
-    data = np.random.default_rng(0).standard_normal((n_rows, V), dtype=np.float32)
-    draws = [PhiloxDraws(1, 0, t) for t in range(4)]
-    pre = [{0: d.u(0, B_PER_GPU, H), 2: d.u(2, B_PER_GPU, H)} for d in draws]   # RNG not timed
-    done, t0 = 0, None
-    for it in range(10000):
-        if it == 3:
-            t0 = time.perf_counter()
-        idx = np.arange(B_PER_GPU) + (it % 4) * B_PER_GPU
-        rbm_np.cd_step(st, data[idx], rbm_np.ArrayDraws(pre[it % 4]), lr=LR, k=K_GIBBS, lambda_1=LAMBDA_1,
-                       lambda_2=LAMBDA_2, batch_size=B_PER_GPU, momentum=0.0)
-        if t0 is not None:
-            done += 1
-            if time.perf_counter() - t0 > budget_s and done >= 5:
-                break
-    dt = time.perf_counter() - t0
-    return {"value": done * B_PER_GPU / dt, "unit": "samples/s", "cores": int(threads), "kind": "port",
-            "steps_per_s": done / dt,
-            "sample": "%d CD-1 steps of the same GRBM 4096->1024, B=512, numpy float32 oracle "
-                      "(BLAS threads=%d, host cpus=%d), injected uniforms" % (done, threads, os.cpu_count() or 0)}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--windows", type=int, default=0, help="timed windows of --steps steps (0 = auto, >= 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """Start the N ranks as a child torchrun job and relay its output.  Nothing in this process
+    has initialised the GPU (torch is not even imported yet), and the parent only waits."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--windows", str(args.windows)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def pmc_traffic():
+    """HBM bytes per GEMM launch from the newest committed PMC profile (FETCH_SIZE / WRITE_SIZE
+    collected in separate rocprofv3 passes and corrected as MI355X_MICROARCH.md prescribes);
+    counters cannot be read from inside this process, so the figure is the profiled one, or null."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+        try:
+            with open(path) as f:
+                best = (os.path.basename(path), json.load(f)["gemm_avg_bytes_per_launch"])
+        except Exception:
+            pass
+    return best if best else (None, None)
+
+
+def _blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def _time_oracle_steps(cfg, budget_s, min_steps):
+    """Timed CD-k steps of the numpy float32 oracle on one of the named shapes."""
+    from oracle import rbm_np
+    from oracle.philox_np import PhiloxDraws
+    v, h, b, gauss = cfg["V"], cfg["H"], cfg["B"], cfg["gauss"]
+    rs = np.random.RandomState(123)
+    rs.randint(2 ** 30)
+    st = rbm_np.RBMState(v, h, W=rbm_np.init_W(rs, v, h, np.float32), dtype=np.float32, gauss=gauss)
+    if cfg.get("weightcost"):
+        st.freeze_W0()
+    g = np.random.default_rng(0)
+    data = g.standard_normal((4 * b, v), dtype=np.float32) if gauss else \
+        (np.round(255 * g.beta(0.1, 0.7, size=(4 * b, v))) / 255).astype(np.float32)
+    draws = [PhiloxDraws(1, 0, t) for t in range(4)]
+    need = [0, 2] if gauss else [0, 1, 2]
+    pre = [{d: (dr.u(d, b, v) if d == 1 else dr.u(d, b, h)) for d in need} for dr in draws]   # RNG not timed
+    hp = dict(lr=cfg["lr"], k=1, lambda_1=0.0, lambda_2=cfg.get("lambda_2", 0.0), weightcost=cfg.get("weightcost", 0.0),
+              batch_size=b, momentum=cfg.get("momentum", 0.0))
+    done, t0 = 0, None
+    for it in range(1000000):
+        if it == 2:
+            t0 = time.perf_counter()
+        idx = np.arange(b) + (it % 4) * b
+        rbm_np.cd_step(st, data[idx], rbm_np.ArrayDraws(pre[it % 4]), **hp)
+        if t0 is not None:
+            done += 1
+            if time.perf_counter() - t0 > budget_s and done >= min_steps:
+                break
+    dt = time.perf_counter() - t0
+    return done, dt
+
+
+def cpu_baseline():
+    """NumPy float32 restatement of the same step (oracle/rbm_np.py) on the host cores: the headline
+    shape (c2) on all BLAS threads = `value`; beside it single-core c2 and the reference's own
+    CPU-runnable shape c1 (RBM 784->500, batch 20) on all cores and on one."""
+    threads = _blas_threads()
+    c2 = dict(V=V, H=H, B=B_PER_GPU, gauss=True, lr=LR, lambda_2=LAMBDA_2)
+    c1 = dict(V=784, H=500, B=20, gauss=False, lr=0.1, weightcost=2e-4, momentum=0.6)
+    done, dt = _time_oracle_steps(c2, 10.0, 5)
+    out = {"value": done * B_PER_GPU / dt, "unit": "samples/s", "cores": int(threads), "kind": "port",
+           "steps_per_s": done / dt,
+           "sample": "%d CD-1 steps of the same GRBM 4096->1024, B=512, numpy float32 oracle "
+                     "(BLAS threads=%d, host cpus=%d), injected uniforms" % (done, threads, os.cpu_count() or 0)}
+    d1, t1 = _time_oracle_steps(c1, 3.0, 20)
+    out["c1_rbm_784_500_b20"] = {"steps_per_s": d1 / t1, "samples_per_s": 20 * d1 / t1, "cores": int(threads), "steps": d1}
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            ds, ts = _time_oracle_steps(c2, 6.0, 2)
+            d1s, t1s = _time_oracle_steps(c1, 3.0, 20)
+        out["single_core"] = {"value": ds * B_PER_GPU / ts, "unit": "samples/s", "steps_per_s": ds / ts, "cores": 1,
+                              "steps": ds}
+        out["c1_rbm_784_500_b20_single_core"] = {"steps_per_s": d1s / t1s, "samples_per_s": 20 * d1s / t1s,
+                                                 "cores": 1, "steps": d1s}
+    except Exception as exc:                       # threadpoolctl missing: say so instead of guessing
+        out["single_core"] = {"error": repr(exc)}
+    return out
+
+
+def kernel_breakdown(detail):
+    """Aggregate mdbn_kernel_timing_detail rows by GEMM: launches, average time, issued and
+    algorithmic FLOPs, and the fraction of the matrix pipe the kernel executes on."""
+    groups = {}
+    for ms, alg, pipe, kind in detail:
+        groups.setdefault(kind, []).append((ms, alg, pipe))
+    rows = {}
+    for kind, v in sorted(groups.items()):
+        p = (kind // 100) % 10
+        name = KIND_NAMES.get(kind % 10, "gemm%d" % (kind % 10)) + ("" if kind < 1000 else "_streaming")
+        t = sum(x[0] for x in v) * 1e-3
+        alg, pipe = sum(x[1] for x in v), sum(x[2] for x in v)
+        peak = MFMA_BF16_PEAK_TFLOPS if p else MFMA_F32_PEAK_TFLOPS
+        key = name if name not in rows else "%s_%d" % (name, kind)
+        rows[key] = {"launches": len(v), "avg_us": 1e6 * t / len(v),
+                     "pipe": ("bf16 MFMA, %d products per algorithmic product" % (6 if p == 1 else 3)) if p else "f32 MFMA",
+                     "issued_tflops": pipe / t / 1e12, "pipe_peak_tflops": peak, "frac_of_pipe": pipe / t / 1e12 / peak,
+                     "algorithmic_f32_tflops": alg / t / 1e12, "fused_epilogue": (kind // 10) % 10}
+    return rows
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     import torch
     import mdbn_amd
@@ -91,10 +186,11 @@ def main():
 
     rank, local_rank, world = dist.init_from_env()
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
     dev = eng.device
     B_global = B_PER_GPU * world
+    td = torch.distributed
 
     # synthetic z-scored features, identical on every rank
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -116,47 +212,86 @@ def main():
 
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            td.barrier()
         torch.cuda.synchronize(dev)
 
+    def timed_window(first):
+        barrier()
+        t0 = time.perf_counter()
+        cost = run(args.steps, first)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, cost
+
+    def measure(first):
+        """Median of >= 5 windows of exactly --steps steps (short windows: up to 40, ~0.25 s in all)."""
+        n_win = args.windows
+        wins, cost = [], None
+        while True:
+            dt, cost = timed_window(first)
+            first += args.steps
+            wins.append(dt)
+            if n_win:
+                if len(wins) >= n_win:
+                    break
+            elif len(wins) >= 5 and (sum(wins) >= 0.25 or len(wins) >= 40):
+                break
+        return wins, cost, first
+
     run(args.warmup, 0)
-    barrier()
-    t0 = time.perf_counter()
-    cost = run(args.steps, args.warmup)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    wins, cost, nxt = measure(args.warmup)
+    elapsed = float(np.median(wins))
     final_cost = float(cost)
+    rank_ms = [1e3 * float(np.median(wins)) / args.steps]
+    allreduce_us = None
+    backend = None
+    if world > 1:
+        backend = td.get_backend()
+        mine = torch.tensor([rank_ms[0]], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        td.all_gather(allr, mine)
+        rank_ms = [float(x.item()) for x in allr]
+        # the collective on its own: the packed statistics buffer, summed over ranks, HIP events on the
+        # stream that waits for it (the step overlaps it with the next step's compute)
+        buf = torch.zeros(V * H + H + V + 4, dtype=torch.float32, device=dev)
+        for _ in range(5):
+            td.all_reduce(buf)
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            td.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        allreduce_us = 1e3 * e0.elapsed_time(e1) / 20
 
-    # dominant kernel: the MFMA GEMM (4 launches per CD-1 step); average duration from HIP events on
-    # the launch stream over the same K steps
+    # per-kernel durations: HIP events around every GEMM launch on its stream, over K more steps
     eng.kernel_timing(True)
-    run(args.steps, args.warmup + args.steps)
+    run(args.steps, nxt)
     torch.cuda.synchronize(dev)
-    n_launch, gemm_ms = eng.kernel_timing_read()
+    detail = eng.kernel_timing_detail()
     eng.kernel_timing(False)
+    nxt += args.steps
 
-    # the same K steps with the GEMMs forced onto the exact-f32 MFMA (v_mfma_f32_32x32x2_f32): by default
+    # the same steps with the GEMMs forced onto the exact-f32 MFMA (v_mfma_f32_32x32x2_f32): by default
     # they run on the bf16 matrix pipe with three-way split operands and f32 accumulation (f32 accuracy,
     # DESIGN.md section 3); both numbers are reported
-    exact_ms = exact_gemm_us = None
+    exact_ms = None
+    exact_rows = None
     if world == 1:
         eng.set_option("gemm_bf16x6", 0)
         run(args.warmup, 0)
-        barrier()
-        t0 = time.perf_counter()
-        run(args.steps, args.warmup)
-        barrier()
-        exact_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+        ewins, _, _ = measure(args.warmup)
+        exact_ms = 1e3 * float(np.median(ewins)) / args.steps
         eng.kernel_timing(True)
-        run(args.steps, args.warmup + args.steps)
+        run(args.steps, args.warmup)
         torch.cuda.synchronize(dev)
-        n2, ms2 = eng.kernel_timing_read()
+        exact_rows = kernel_breakdown(eng.kernel_timing_detail())
         eng.kernel_timing(False)
-        exact_gemm_us = 1e3 * ms2 / max(n2, 1)
         eng.set_option("gemm_bf16x6", 3)
 
     # free-energy parity of the trained model vs the float64 oracle (north star: <= 1e-4 rel)
@@ -176,14 +311,18 @@ def main():
     if rank != 0:
         return
     steps_per_s = args.steps / elapsed
-    # algorithmic FLOPs: 2*B*V*H per product, 2k+3 products per CD-k step.  The
-    # engine issues them as 2k+2 launches (the two statistic products run as ONE GEMM over
-    # the stacked batch), so the per-launch figure is the step's FLOPs / launches per step.
+    # algorithmic FLOPs: 2*B*V*H per product, 2k+3 products per CD-k step
     flop_per_step = 2.0 * B_PER_GPU * V * H * (2 * K_GIBBS + 3)
-    launches_per_step = n_launch / float(args.steps) if n_launch else float(2 * K_GIBBS + 2)
-    flop_per_gemm = flop_per_step / launches_per_step
-    avg_gemm_s = gemm_ms / 1e3 / max(n_launch, 1)
-    achieved = flop_per_gemm / avg_gemm_s / 1e12 if n_launch else None
+    rows = kernel_breakdown(detail)
+    n_launch = len(detail)
+    t_all = sum(d[0] for d in detail) * 1e-3
+    issued = sum(d[2] for d in detail)
+    alg = sum(d[1] for d in detail)
+    on_bf16 = all(((d[3] // 100) % 10) != 0 for d in detail) and n_launch > 0
+    peak = MFMA_BF16_PEAK_TFLOPS if on_bf16 else MFMA_F32_PEAK_TFLOPS
+    achieved = issued / t_all / 1e12 if n_launch else None
+    traffic_file, traffic = pmc_traffic()
+    worst = min(rows.items(), key=lambda kv: kv[1]["frac_of_pipe"])[0] if rows else None
     out = {
         "metric": "CD-k Gibbs steps/sec (samples/sec), GRBM 4096->1024 CD-1",
         "value": steps_per_s * B_global * K_GIBBS,
@@ -192,34 +331,45 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "arithmetic": "f32 operands split exactly into 3 bf16 pieces, 6 products on v_mfma_f32_32x32x16_bf16, f32 accumulate "
-                      "(error vs float64 = rocBLAS sgemm's); exact_f32_mfma_* = the same step on v_mfma_f32_32x32x2_f32",
+        "timing": "median of %d windows of %d steps, each bracketed by barrier + synchronize (max over ranks)"
+                  % (len(wins), args.steps),
+        "windows_ms_per_step": [1e3 * w / args.steps for w in wins],
+        "arithmetic": "f32 operands split exactly into 3 bf16 pieces; 6 piece products (3 when one operand holds 0/1 "
+                      "samples) on v_mfma_f32_32x32x16_bf16 with f32 accumulation (error vs float64 = rocBLAS sgemm's); "
+                      "exact_f32_mfma_* = the same step on v_mfma_f32_32x32x2_f32",
         "exact_f32_mfma_ms_per_step": exact_ms,
         "exact_f32_mfma_value": (B_global * K_GIBBS * 1e3 / exact_ms) if exact_ms else None,
+        "exact_f32_mfma_kernels": exact_rows,
         "config": {"workload": "GRBM 4096->1024 CD-1, batch %d per GPU, fp32, N(0,1) rows resident in HBM "
                                "(BASELINE configs[%d])" % (B_PER_GPU, 1 if world == 1 else 2),
                    "global_batch": B_global, "k": K_GIBBS, "n_data": N_DATA,
                    "parallelism": "dp%d" % world},
         "cd_steps_per_s": steps_per_s,
-        "step_tflops": flop_per_step * world * steps_per_s / 1e12,          # whole job
-        "step_frac_of_mfma_f32_peak": flop_per_step * steps_per_s / 1e12 / MFMA_F32_PEAK_TFLOPS,   # per GPU
+        "step_algorithmic_f32_tflops": flop_per_step * world * steps_per_s / 1e12,          # whole job
+        "step_algorithmic_f32_tflops_over_f32_mfma_peak": flop_per_step * steps_per_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
         "final_cost": final_cost,
         "free_energy_max_rel_err_vs_f64_oracle": fe_rel,
         "free_energy_max_elementwise_rel_err": fe_rel_elem,
-        # achieved = ALGORITHMIC f32 FLOPs per launch / average launch duration; peak = the dense f32 MFMA
-        # peak (the dtype's).  The default kernel issues 6 bf16 products per algorithmic product on the
-        # bf16 pipe (2.5 PFLOP/s dense): pipe_frac prices that work against that pipe.
-        "roofline": {"bound": "mfma", "kernel": "gemm_bf16x6_kernel (v_mfma_f32_32x32x16_bf16, 3-way split operands)",
-                     "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": (achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None,
-                     "traffic": gemm_traffic_bytes(),
-                     "launches_timed": n_launch, "launches_per_step": launches_per_step, "avg_launch_us": 1e6 * avg_gemm_s,
-                     "algorithmic_flop_per_launch": flop_per_gemm,
-                     "pipe": "bf16 MFMA", "pipe_flop_per_launch": 6 * flop_per_gemm, "pipe_peak": MFMA_BF16_PEAK_TFLOPS,
-                     "pipe_frac": (6 * achieved / MFMA_BF16_PEAK_TFLOPS) if achieved else None,
-                     "exact_f32_mfma_avg_launch_us": exact_gemm_us,
-                     "exact_f32_mfma_frac": (flop_per_gemm / (exact_gemm_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS)
-                                            if exact_gemm_us else None},
+        "distributed": {"ranks": world, "backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
+                        "per_rank_ms_per_step": rank_ms, "allreduce_alone_us": allreduce_us,
+                        "allreduce_bytes": 4 * (V * H + H + V + 4) if world > 1 else 0,
+                        "overlap": bool(getattr(step_fn, "overlap", False))},
+        # achieved = FLOPs ISSUED on the matrix pipe the GEMM kernels execute on (six / three bf16 products per
+        # algorithmic f32 product), summed over the step's GEMM launches, / their summed HIP-event durations;
+        # peak = that pipe's dense peak.  `kernels` has the same per GEMM; the f32-equivalent (algorithmic)
+        # rate is a separate, informational field.
+        "roofline": {"bound": "mfma",
+                     "kernel": "GEMM launches of the step (%s)" % ("bf16 matrix pipe, split f32 operands" if on_bf16
+                                                                   else "mixed / f32 matrix pipe"),
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": (achieved / peak) if achieved else None,
+                     "traffic": traffic, "traffic_source": traffic_file,
+                     "launches_timed": n_launch, "launches_per_step": n_launch / float(args.steps),
+                     "avg_launch_us": 1e6 * t_all / max(n_launch, 1),
+                     "issued_flop_per_step": issued / float(args.steps), "algorithmic_flop_per_step": alg / float(args.steps),
+                     "algorithmic_f32_tflops": alg / t_all / 1e12 if n_launch else None,
+                     "furthest_below_roof": worst,
+                     "kernels": rows},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

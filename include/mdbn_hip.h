@@ -103,6 +103,9 @@ typedef struct mdbn_update_args {
 
 int  mdbn_version(void);
 int  mdbn_last_error(char *buf, size_t n);
+/* SHA-256 (hex) of the sources this library was built from (mdbn_amd/build.py compares it with the
+ * sources on disk: a stale prebuilt library is rebuilt or refused, never silently used). */
+int  mdbn_source_hash(char *buf, size_t n);
 
 int  mdbn_ctx_create(mdbn_ctx **out, int device);
 int  mdbn_ctx_destroy(mdbn_ctx *ctx);
@@ -136,6 +139,13 @@ int  mdbn_set_option(mdbn_ctx *ctx, const char *name, int64_t value);
  * of launches recorded since enabling and the sum of their durations. */
 int  mdbn_kernel_timing(mdbn_ctx *ctx, int enable);
 int  mdbn_kernel_timing_read(mdbn_ctx *ctx, int64_t *n_launches, double *total_ms);
+/* Per recorded launch (up to `cap`): duration, algorithmic FLOPs 2*M*N*K, FLOPs issued on the matrix
+ * pipe the kernel runs on (x6 / x3 for the split-operand bf16 kernels), and
+ * kind = 1000*skinny + 100*pipe (0 exact-f32 MFMA, 1 bf16 six products, 2 bf16 three products)
+ *        + 10*fused + 2*la + lb  ((la, lb): 1 = propup, 0 = propdown, 3 = statistics).
+ * *n_launches receives the number recorded (may exceed cap). */
+int  mdbn_kernel_timing_detail(mdbn_ctx *ctx, int64_t cap, double *ms, double *alg_flop,
+                               double *pipe_flop, int32_t *kind, int64_t *n_launches);
 
 /* bytes of split-K / reduction scratch the calls below need for shapes up to (B, V, H) */
 int  mdbn_workspace_bytes(int64_t B, int64_t V, int64_t H, int64_t *bytes);

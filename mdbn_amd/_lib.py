@@ -49,11 +49,14 @@ _rngp = C.POINTER(Rng)
 SIGNATURES = {
     "mdbn_version": [],
     "mdbn_last_error": [C.c_char_p, C.c_size_t],
+    "mdbn_source_hash": [C.c_char_p, C.c_size_t],
     "mdbn_ctx_create": [C.POINTER(_vp), _i32],
     "mdbn_ctx_destroy": [_vp],
     "mdbn_set_option": [_vp, C.c_char_p, _i64],
     "mdbn_kernel_timing": [_vp, _i32],
     "mdbn_kernel_timing_read": [_vp, C.POINTER(_i64), C.POINTER(C.c_double)],
+    "mdbn_kernel_timing_detail": [_vp, _i64, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(_i64)],
     "mdbn_workspace_bytes": [_i64, _i64, _i64, C.POINTER(_i64)],
     "mdbn_padded_ld": [_i64, C.POINTER(_i64)],
     "mdbn_stats_floats": [_i64, _i64, _i64, C.POINTER(_i64)],
@@ -81,11 +84,16 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise MdbnError(
-            "%s is missing: the HIP extension has not been built. Run "
-            "`python -c 'import __graft_entry__ as g; g.build()'` (or python -m mdbn_amd.build). "
-            "There is no CPU fallback." % LIB_PATH)
+    from . import build as _build
+    if _build.is_stale():
+        # missing, or built from other sources than the ones on disk (content hash, not mtime)
+        try:
+            _build.build_lib(force=True)
+        except Exception as exc:
+            raise MdbnError(
+                "%s is missing or was built from different sources, and rebuilding it failed (%r). Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or python -m mdbn_amd.build). "
+                "There is no CPU fallback." % (LIB_PATH, exc))
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -27,6 +27,9 @@ struct mdbn_ctx {
 struct GemmTiming {
     bool enabled = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    // per recorded launch: which GEMM it was and the work it issued (mdbn_kernel_timing_detail)
+    struct Meta { int kind; double alg_flop, pipe_flop; };
+    std::vector<Meta> meta;
     size_t used = 0;
 };
 static GemmTiming g_timing;
@@ -243,6 +246,16 @@ hipError_t timed_gemm(int la, int lb, const GemmArgs& g_in, hipStream_t s)
         if (e != hipSuccess) return e;
         g_timing.pool.emplace_back(a, b);
     }
+    {
+        // kind = 100 * pipe (0 exact-f32 MFMA, 1 bf16 pipe with 6 products, 2 bf16 pipe with 3) + 10 * fused
+        //        + 2 * la + lb; (la, lb) = (K, MN) propup, (K, K) propdown, (MN, MN) statistics
+        const double alg = 2.0 * (double)g.M * (double)g.N * (double)g.K;
+        const int pipe = g.skinny ? 0 : g.x6;
+        GemmTiming::Meta m{100 * pipe + 10 * g.fused + 2 * la + lb + (g.skinny ? 1000 : 0), alg,
+                           alg * (pipe == 1 ? 6.0 : pipe == 2 ? 3.0 : 1.0)};
+        if (g_timing.meta.size() <= g_timing.used) g_timing.meta.resize(g_timing.used + 1);
+        g_timing.meta[g_timing.used] = m;
+    }
     auto& ev = g_timing.pool[g_timing.used++];
     hipError_t e = hipEventRecord(ev.first, s);
     if (e != hipSuccess) return e;
@@ -434,6 +447,16 @@ extern "C" {
 
 int mdbn_version(void) { return MDBN_VERSION; }
 
+#ifndef MDBN_SRC_HASH
+#define MDBN_SRC_HASH "unknown"
+#endif
+int mdbn_source_hash(char* buf, size_t n)
+{
+    if (!buf || n == 0) return MDBN_EINVAL;
+    snprintf(buf, n, "%s", MDBN_SRC_HASH);
+    return MDBN_OK;
+}
+
 int mdbn_last_error(char* buf, size_t n)
 {
     if (!buf || n == 0) return MDBN_EINVAL;
@@ -560,6 +583,24 @@ int mdbn_kernel_timing_read(mdbn_ctx* ctx, int64_t* n_launches, double* total_ms
     }
     *n_launches = (int64_t)g_timing.used;
     *total_ms = tot;
+    return MDBN_OK;
+}
+
+int mdbn_kernel_timing_detail(mdbn_ctx* ctx, int64_t cap, double* ms, double* alg_flop, double* pipe_flop,
+                              int32_t* kind, int64_t* n_launches)
+{
+    REQUIRE(ctx && n_launches && (cap == 0 || (ms && alg_flop && pipe_flop && kind)), "NULL argument");
+    const int64_t n = std::min<int64_t>(cap, (int64_t)g_timing.used);
+    for (int64_t i = 0; i < n; ++i) {
+        HIP_OK(hipEventSynchronize(g_timing.pool[i].second));
+        float t = 0.f;
+        HIP_OK(hipEventElapsedTime(&t, g_timing.pool[i].first, g_timing.pool[i].second));
+        ms[i] = t;
+        alg_flop[i] = g_timing.meta[i].alg_flop;
+        pipe_flop[i] = g_timing.meta[i].pipe_flop;
+        kind[i] = g_timing.meta[i].kind;
+    }
+    *n_launches = (int64_t)g_timing.used;
     return MDBN_OK;
 }
 

@@ -24,6 +24,35 @@ from .shared import SharedArray, shared
 from .utils import get_minibatches_idx
 
 
+class _Patience(object):
+    """Early stopping of dbn.py:408-441,476-508.  ``limit`` starts at the layer's EPOCH budget but is
+    compared with the ITERATION count (the reference does exactly that); every ``every`` iterations the
+    cost is looked at: a new best that beats the old one by more than 0.5 % stretches the limit to
+    twice the current iteration."""
+
+    growth, threshold = 2, 0.995                     # dbn.py:410,412
+
+    def __init__(self, budget, n_batches):
+        self.limit = budget
+        self.every = max(1, min(20 * n_batches, budget // 2))       # dbn.py:441
+        self.best = numpy.inf
+
+    def due(self, it):
+        return (it + 1) % self.every == 0
+
+    def observe(self, it, cost):
+        """Record a validation-point cost; True if it is a new best."""
+        if not cost < self.best:
+            return False
+        if cost < self.best * self.threshold:
+            self.limit = max(self.limit, it * self.growth)
+        self.best = cost
+        return True
+
+    def exhausted(self, it):
+        return self.limit <= it                      # dbn.py:506
+
+
 class DBN(object):
     """Deep Belief Network: stacked RBMs sharing weights with an MLP (dbn.py:51-62)."""
 
@@ -142,90 +171,70 @@ class DBN(object):
                  graph_output=False):
         '''Greedy layer-wise pre-training (dbn.py:334-517).  Returns, per layer, the list of
         (iteration, cost, free_energy_gap) records taken at the validation points.'''
-        train_set_x = shared(train_set_x, engine=self.engine)
-        if validation_set_x is not None:
-            validation_set_x = shared(validation_set_x, engine=self.engine)
+        data = shared(train_set_x, engine=self.engine)
+        held_out = None if validation_set_x is None else shared(validation_set_x, engine=self.engine)
         self._print('... getting the pretraining functions')
-        self._print('Training set sample size %i' % train_set_x.shape[0])
-        if validation_set_x is not None:
-            self._print('Validation set sample size %i' % validation_set_x.shape[0])
-
-        training_fns, free_energy_gap_fns = self.training_functions(
-            train_set_x=train_set_x, batch_size=batch_size, k=k,
-            lambda_1=lambda_1, lambda_2=lambda_2, monitor=monitor)
-
+        self._print('Training set sample size %i' % data.shape[0])
+        if held_out is not None:
+            self._print('Validation set sample size %i' % held_out.shape[0])
+        step_fns, energy_fns = self.training_functions(train_set_x=data, batch_size=batch_size, k=k,
+                                                       lambda_1=lambda_1, lambda_2=lambda_2, monitor=monitor)
         self._print('... pre-training the model')
-        start_time = timeit.default_timer()
-        n_data = train_set_x.shape[0]
-
-        patience_increase = 2            # dbn.py:410
-        improvement_threshold = 0.995    # dbn.py:412
-
-        idx_minibatches, minibatches = get_minibatches_idx(n_data, batch_size, shuffle=True,
-                                                           rng=self.shuffle_rng)
-        n_train_batches = idx_minibatches[-1] + 1
-        history = []
-
-        for i in range(self.n_layers):
-            momentum = 0.0 if isinstance(self.rbm_layers[i], GRBM) else 0.6    # dbn.py:430-433
-            best_cost = numpy.inf
-            epoch = 0
-            done_looping = False
-            records = []
-
-            patience = pretraining_epochs[i]      # compared against the ITERATION count (dbn.py:440,506)
-            validation_frequency = max(1, min(20 * n_train_batches, patience // 2))
-            self._print('Validation frequency: %d' % validation_frequency)
-
-            while (epoch < pretraining_epochs[i]) and (not done_looping):
-                epoch = epoch + 1
-                idx_minibatches, minibatches = get_minibatches_idx(n_data, batch_size, shuffle=True,
-                                                                   rng=self.shuffle_rng)
-                dev_idx = self.engine.index_tensor(numpy.concatenate(minibatches))
-                if not isinstance(self.rbm_layers[i], GRBM) and epoch == 6:      # dbn.py:452-453
-                    momentum = 0.9
-
-                start = 0
-                for mb, minibatch in enumerate(minibatches):
-                    n_mb = len(minibatch)
-                    current_cost = training_fns[i](indexes=dev_idx[start:start + n_mb],
-                                                   momentum=momentum, lr=pretrain_lr[i])
-                    start += n_mb
-                    iter = (epoch - 1) * n_train_batches + mb
-
-                    if (iter + 1) % validation_frequency == 0:
-                        current_cost = float(current_cost)
-                        self._print('Pre-training cost (layer %i, epoch %d): ' % (i, epoch), end=' ')
-                        self._print(current_cost)
-                        free_energy_gap = None
-                        if current_cost < best_cost:
-                            if current_cost < best_cost * improvement_threshold:
-                                patience = max(patience, iter * patience_increase)
-                            best_cost = current_cost
-                            if validation_set_x is not None:
-                                n_val = validation_set_x.shape[0]
-                                if i == 0:
-                                    input_t_set, input_v_set = train_set_x, validation_set_x
-                                else:                                   # dbn.py:494-496
-                                    input_t_set = self._forward(train_set_x.tensor[:n_val], i - 1)
-                                    input_v_set = self._forward(validation_set_x, i - 1)
-                                free_energy_train, free_energy_test = free_energy_gap_fns[i](
-                                    input_t_set, input_v_set)
-                                free_energy_gap = float(free_energy_test.mean() - free_energy_train.mean())
-                                self._print('Free energy gap (layer %i, epoch %i): ' % (i, epoch), end=' ')
-                                self._print(free_energy_gap)
-                        records.append((iter, current_cost, free_energy_gap))
-
-                    if patience <= iter:                                # dbn.py:506-508
-                        done_looping = True
-                        break
-            training_fns[i].flush()
-            history.append(records)
-
-        end_time = timeit.default_timer()
+        t_start = timeit.default_timer()
+        # the batch count is fixed once, from a first split that is otherwise unused (dbn.py:404-406)
+        n_batches = len(get_minibatches_idx(data.shape[0], batch_size, shuffle=True, rng=self.shuffle_rng)[1])
+        history = [self._pretrain_layer(i, step_fns[i], energy_fns[i], data, held_out, batch_size, n_batches,
+                                        pretraining_epochs[i], pretrain_lr[i])
+                   for i in range(self.n_layers)]
         if self.verbose:
-            print('The pretraining ran for %.2fm' % ((end_time - start_time) / 60.), file=sys.stderr)
+            print('The pretraining ran for %.2fm' % ((timeit.default_timer() - t_start) / 60.), file=sys.stderr)
         return history
+
+    def _pretrain_layer(self, i, step_fn, energy_fn, data, held_out, batch_size, n_batches, epoch_budget, lr):
+        """One layer of dbn.py:426-508: epochs of reshuffled minibatches under the layer's momentum
+        schedule until the epoch budget or the early-stopping state (``_Patience``) ends it."""
+        bernoulli = not isinstance(self.rbm_layers[i], GRBM)
+        stop = _Patience(epoch_budget, n_batches)
+        self._print('Validation frequency: %d' % stop.every)
+        records = []
+        for epoch in range(1, epoch_budget + 1):
+            # Gaussian layer: no momentum at all; Bernoulli layers 0.6, 0.9 from the sixth epoch (dbn.py:430-433,452-453)
+            momentum = 0.0 if not bernoulli else (0.6 if epoch < 6 else 0.9)
+            batches = get_minibatches_idx(data.shape[0], batch_size, shuffle=True, rng=self.shuffle_rng)[1]
+            order = self.engine.index_tensor(numpy.concatenate(batches))
+            bounds = numpy.cumsum([0] + [len(b) for b in batches])
+            for mb in range(len(batches)):
+                cost = step_fn(indexes=order[bounds[mb]:bounds[mb + 1]], momentum=momentum, lr=lr)
+                it = (epoch - 1) * n_batches + mb
+                if stop.due(it):
+                    cost = float(cost)
+                    self._print('Pre-training cost (layer %i, epoch %d): ' % (i, epoch), end=' ')
+                    self._print(cost)
+                    gap = None
+                    if stop.observe(it, cost) and held_out is not None:
+                        gap = self._free_energy_gap(i, energy_fn, data, held_out)
+                        self._print('Free energy gap (layer %i, epoch %i): ' % (i, epoch), end=' ')
+                        self._print(gap)
+                    records.append((it, cost, gap))
+                if stop.exhausted(it):
+                    break
+            else:
+                continue
+            break
+        step_fn.flush()
+        return records
+
+    def _free_energy_gap(self, i, energy_fn, data, held_out):
+        """mean F(validation) - mean F(first n_val training rows), both seen through the layers below
+        layer i (dbn.py:476-501)."""
+        n_val = held_out.shape[0]
+        if i == 0:
+            below_train, below_val = data, held_out
+        else:
+            below_train = self._forward(data.tensor[:n_val], i - 1)
+            below_val = self._forward(held_out, i - 1)
+        f_train, f_val = energy_fn(below_train, below_val)
+        return float(f_val.mean() - f_train.mean())
 
     def MLP_output_from_datafile(self, datafile, holdout=0.0, repeats=1, clip=None,
                                  transform_fn=None, exponent=1.0, datadir='data'):

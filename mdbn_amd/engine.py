@@ -377,5 +377,14 @@ class HipEngine(object):
                    "mdbn_kernel_timing_read")
         return n.value, ms.value
 
+    def kernel_timing_detail(self, cap=8192):
+        """Per recorded GEMM launch: (ms, algorithmic FLOPs, FLOPs issued on its matrix pipe, kind)."""
+        ms, alg, pipe = (C.c_double * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
+        kind, n = (C.c_int32 * cap)(), C.c_int64()
+        _lib.check(self.lib.mdbn_kernel_timing_detail(self.ctx, cap, ms, alg, pipe, kind, C.byref(n)),
+                   "mdbn_kernel_timing_detail")
+        m = min(cap, n.value)
+        return [(ms[i], alg[i], pipe[i], kind[i]) for i in range(m)]
+
     def synchronize(self):
         torch.cuda.synchronize(self.device)

@@ -11,25 +11,16 @@ import numpy
 
 
 def get_minibatches_idx(n, batch_size, shuffle=False, rng=None):
-    """Minibatch index lists, as reference utils.py:54-75: int32 arange, optional shuffle,
-    ``n // batch_size`` full batches plus a ragged tail.  The reference shuffles with the
-    unseeded global ``numpy.random`` (utils.py:62); pass ``rng`` (a RandomState) for
-    reproducible runs."""
-    idx_list = numpy.arange(n, dtype="int32")
-
+    """Minibatch index lists with the contract of reference utils.py:54-75: the int32 row numbers
+    0..n-1, optionally shuffled, cut into ``n // batch_size`` full batches plus a ragged tail; returns
+    ``(range(number of batches), list of index arrays)``.  The reference shuffles with the unseeded
+    global ``numpy.random`` (utils.py:62); pass ``rng`` (a RandomState) for reproducible runs."""
+    order = numpy.arange(n, dtype="int32")
     if shuffle:
-        (rng if rng is not None else numpy.random).shuffle(idx_list)
-
-    minibatches = []
-    minibatch_start = 0
-    for i in range(n // batch_size):
-        minibatches.append(idx_list[minibatch_start:minibatch_start + batch_size])
-        minibatch_start += batch_size
-
-    if minibatch_start != n:
-        minibatches.append(idx_list[minibatch_start:])
-
-    return range(len(minibatches)), minibatches
+        (numpy.random if rng is None else rng).shuffle(order)
+    pieces = numpy.split(order, numpy.arange(batch_size, n, batch_size))
+    batches = [p for p in pieces if len(p)]
+    return range(len(batches)), batches
 
 
 def import_TCGA_data(file, datadir, dtype):
@@ -86,46 +77,45 @@ def load_n_preprocess_data(datafile, dtype='float32', holdout=0.1, clip=None, tr
 # Class post-processing of the joint layer's output (reference utils.py:121-176)
 
 def remap_class(classified_samples, distance_matrix, n_classes):
-    """Keep the ``n_classes`` most frequent classes and reassign every other class to a kept
-    class near it in Hamming distance (reference utils.py:124-159, including its tie and
-    overwrite order: the LAST admissible neighbour in ascending-distance order wins)."""
-    def class_by_frequency(a):
-        classes = range(int(numpy.max(a)) + 1)
-        frequency = [numpy.sum(a == idx) for idx in classes]
-        order = list(reversed(numpy.argsort(frequency).tolist()))
-        return [{classes[i]: (r, frequency[i]) for r, i in enumerate(order)},
-                {r: (classes[i], frequency[i]) for r, i in enumerate(order)}]
+    """Keep the ``n_classes`` most frequent classes (relabelled 0, 1, ... by falling frequency) and fold
+    every other class into a kept one (specification: reference utils.py:124-159).
 
-    def merge_classes(cmap, D, n_classes):
-        new_map = {}
-        n_initial_classes = D.shape[0]
-        for i in range(n_classes):
-            new_map[cmap[1][i][0]] = i
-        for c in [cmap[1][i][0] for i in range(n_classes, n_initial_classes)]:
-            for i in numpy.argsort(D[c]):
-                r = cmap[0][i][0]
-                if r < n_classes and r != c:
-                    new_map[c] = r
-        return new_map
-
-    cmap = class_by_frequency(classified_samples)
-    new_classification = merge_classes(cmap, distance_matrix, n_classes)
-    return numpy.array([new_classification[i] for i in classified_samples])
+    The reference walks a dropped class's neighbours by rising Hamming distance and overwrites its
+    choice at every admissible one, so the LAST admissible neighbour wins (the farthest, not the
+    nearest); "admissible" means the neighbour's frequency rank is below ``n_classes`` and differs
+    from the dropped class's own ID (a rank compared with an ID -- kept as is).  Ties in frequency
+    rank the higher class ID first (a reversed ascending argsort)."""
+    labels = numpy.asarray(classified_samples)
+    counts = numpy.array([numpy.sum(labels == c) for c in range(int(numpy.max(labels)) + 1)])
+    by_rank = numpy.argsort(counts)[::-1]                    # class IDs, most frequent first
+    rank_of = numpy.empty(len(by_rank), dtype=int)
+    rank_of[by_rank] = numpy.arange(len(by_rank))
+    n_initial = distance_matrix.shape[0]
+    table = numpy.full(max(n_initial, len(by_rank)), -1, dtype=int)
+    table[by_rank[:n_classes]] = numpy.arange(min(n_classes, len(by_rank)))
+    for c in by_rank[n_classes:n_initial]:
+        ranks = rank_of[numpy.argsort(distance_matrix[c])]
+        admissible = ranks[(ranks < n_classes) & (ranks != c)]
+        if len(admissible):
+            table[c] = admissible[-1]
+    merged = table[labels.astype(int)]
+    if (merged < 0).any():
+        raise KeyError("class %d has no admissible neighbour" % int(labels[merged < 0][0]))
+    return merged
 
 
 def find_unique_classes(dbn_output):
-    """Unique output-node patterns -> (class index per sample, Hamming distance matrix between
-    the class patterns) (reference utils.py:162-176)."""
-    from scipy.spatial import distance
-    dbn_output = numpy.ascontiguousarray(dbn_output)
-    class_representation = numpy.unique(dbn_output, axis=0)
-    # the reference orders patterns by their raw bytes (numpy.void view); reproduce that order
-    raw = class_representation.view(numpy.dtype((numpy.void, dbn_output.dtype.itemsize * dbn_output.shape[1])))
-    class_representation = class_representation[numpy.argsort(raw.ravel())]
-    distance_matrix = distance.cdist(class_representation, class_representation, metric='hamming')
-    classified_samples = numpy.zeros((dbn_output.shape[0]))
-    output_nodes = dbn_output.shape[1]
-    for idx, pattern in enumerate(class_representation):
-        classified_samples = classified_samples + \
-            (numpy.sum(dbn_output == pattern, axis=1) == output_nodes) * idx
-    return classified_samples, distance_matrix
+    """Distinct output-node patterns -> (class index of every sample, Hamming distance matrix between
+    the class patterns) (reference utils.py:162-176).  Classes are numbered in the order of the
+    patterns' raw bytes, which is what the reference's ``numpy.unique`` over a void view yields."""
+    from scipy.spatial.distance import cdist
+    rows = numpy.ascontiguousarray(dbn_output)
+    as_bytes = rows.view(numpy.dtype((numpy.void, rows.dtype.itemsize * rows.shape[1]))).ravel()
+    order = numpy.argsort(as_bytes, kind='stable')
+    ranked = rows[order]
+    opens_class = numpy.ones(len(rows), dtype=bool)
+    opens_class[1:] = (ranked[1:] != ranked[:-1]).any(axis=1)
+    labels = numpy.empty(len(rows), dtype=numpy.float64)
+    labels[order] = numpy.cumsum(opens_class) - 1
+    patterns = ranked[opens_class]
+    return labels, cdist(patterns, patterns, metric='hamming')

@@ -113,3 +113,21 @@ def test_class_postprocessing():
     assert merged[0] == merged[2] == merged[4] == 0          # most frequent class -> 0
     assert merged[1] == merged[5] == 1
     assert merged[3] in (0, 1) and merged[6] in (0, 1)
+
+
+def test_remap_class_hand_case():
+    """reference utils.py:124-159 on a hand-worked case: ranks by falling frequency with the higher ID
+    first among ties; a dropped class takes the LAST admissible neighbour in rising-distance order;
+    a neighbour is skipped when its RANK equals the dropped class's ID (the reference's comparison)."""
+    labels = np.array([1, 1, 1, 2, 2, 3, 3, 0])
+    # counts 1, 3, 2, 2 -> ranks: class 1 -> 0, class 3 -> 1 (tie with 2: higher ID first), class 2 -> 2, class 0 -> 3
+    D = np.array([[0.0, 0.75, 0.5, 0.25],
+                  [0.75, 0.0, 0.25, 1.0],
+                  [0.5, 0.25, 0.0, 0.75],
+                  [0.25, 1.0, 0.75, 0.0]])
+    # class 2: neighbours by distance 2, 1, 0, 3 = ranks 2, 0, 3, 1 -> admissible 0 then 1 -> last wins: 1
+    # class 0: neighbours 0, 3, 2, 1 = ranks 3, 1, 2, 0 -> rank 0 is skipped (equals the class ID 0) -> 1
+    assert utils.remap_class(labels, D, 2).tolist() == [0, 0, 0, 1, 1, 1, 1, 1]
+    assert utils.remap_class(labels.astype(np.float64), D, 2).tolist() == [0, 0, 0, 1, 1, 1, 1, 1]
+    # keeping everything only relabels by rank
+    assert utils.remap_class(labels, D, 4).tolist() == [0, 0, 0, 2, 2, 1, 1, 3]
