@@ -6,8 +6,14 @@ notebooks and vice versa.
 
 The reference saves only W and b at the end of a run (vbias, momentum speeds, RNG position and
 epoch are lost, so it cannot resume).  ``save_network(..., resume=True)`` adds
-``<name>_resume``: visible biases, the three speeds, RNG seed / stream / step and the update
-count of every RBM layer; ``load_network`` restores them when present."""
+``<name>_resume``: visible biases, the three speeds, RNG seed / stream / step, the update count and
+-- where a step function with a weight cost was built -- the frozen weight-cost constant W0
+(rbm.py:415) of every RBM layer; ``load_network`` restores them when present, and the next
+``get_cost_updates`` of a restored layer reuses that W0 instead of snapshotting the resumed W.
+
+NOT saved (a resumed ``DBN.training`` starts these afresh): the index of the layer in training, the
+epoch and iteration counters, the early-stopping state (patience limit, best cost) and the state of
+the shuffle RNG.  Resume therefore continues a layer's step function exactly, not the trainer's loop."""
 import numpy
 
 from .dbn import DBN
@@ -17,7 +23,9 @@ from .rbm import GRBM
 def _resume_state(dbn):
     out = []
     for r in dbn.rbm_layers:
-        out.append({'vbias': r.vbias.get_value(), 'W_speed': r.W_speed.get_value(),
+        w0 = r._W0_snapshot if r._W0_snapshot is not None else None
+        out.append({'W0': None if w0 is None else w0.get_value(),
+                    'vbias': r.vbias.get_value(), 'W_speed': r.W_speed.get_value(),
                     'hbias_speed': r.hbias_speed.get_value(), 'vbias_speed': r.vbias_speed.get_value(),
                     'rng_seed': r.theano_rng.seed, 'rng_stream': r.stream_id, 'rng_step': r._rng_step,
                     'n_updates': r._n_updates, 'bit_i_idx': r.bit_i_idx})
@@ -70,6 +78,8 @@ def load_network(input_file, names=None, engine=None):
                 r.vbias_speed.set_value(st['vbias_speed'])
                 r.theano_rng.seed, r.stream_id = int(st['rng_seed']), int(st['rng_stream'])
                 r._rng_step, r._n_updates, r.bit_i_idx = int(st['rng_step']), int(st['n_updates']), int(st['bit_i_idx'])
+                if st.get('W0') is not None:
+                    r._resume_W0 = st['W0']
         out[name] = dbn
     for key in ('classes', 'holdout', 'repeats'):
         if key in npz.files:

@@ -136,7 +136,11 @@ class DBN(object):
             return None
 
         def provider():
-            version = tuple(r._n_updates for r in self.rbm_layers[:i])
+            # what the cached activations depend on: the lower layers' training steps, direct writes to
+            # their parameters (SharedArray.set_value, e.g. weights loaded into an existing DBN) and
+            # in-place writes to the data tensor
+            version = tuple((r._n_updates, r.W.version, r.hbias.version) for r in self.rbm_layers[:i]) + \
+                (train_set_x.version, getattr(train_set_x.tensor, "_version", 0))
             hit = self._lower_cache.get(i)
             if self.cache_lower and hit is not None and hit[0] == version and hit[1] is train_set_x:
                 return hit[2]

@@ -133,15 +133,25 @@ class HipEngine(object):
     def to_numpy(self, t):
         return t.detach().cpu().numpy()
 
-    def index_tensor(self, indexes):
-        """Minibatch indices -> device int32/int64 tensor (no copy if already there)."""
+    check_indexes = False       # True: also range-check index lists that already live on the device (one sync)
+
+    def index_tensor(self, indexes, n_rows=None):
+        """Minibatch indices -> device int32/int64 tensor (no copy if already there).  With ``n_rows``
+        host index lists are range-checked like numpy fancy indexing (IndexError; negative indices
+        count from the end) -- the gather kernel itself clamps instead of faulting."""
         if isinstance(indexes, torch.Tensor):
             if indexes.dtype not in (torch.int32, torch.int64):
                 indexes = indexes.to(torch.int64)
+            if n_rows is not None and indexes.numel() and (self.check_indexes or indexes.device.type == "cpu"):
+                lo, hi = int(indexes.min()), int(indexes.max())
+                if lo < -n_rows or hi >= n_rows:
+                    raise IndexError("minibatch index out of range for %d rows: [%d, %d]" % (n_rows, lo, hi))
             return indexes.to(self.device).contiguous()
         a = numpy.asarray(indexes)
         if a.dtype not in (numpy.int32, numpy.int64):
             a = a.astype(numpy.int64)
+        if n_rows is not None and a.size and (a.min() < -n_rows or a.max() >= n_rows):
+            raise IndexError("minibatch index out of range for %d rows: [%d, %d]" % (n_rows, a.min(), a.max()))
         return torch.from_numpy(numpy.ascontiguousarray(a)).to(self.device)
 
     # ------------------------------------------------------------------ scratch
@@ -160,14 +170,22 @@ class HipEngine(object):
             self._ws_key = (B, V, H)
         return self._workspace
 
+    def new_stats_buffer(self, V, H, ldv=None, ldh=None):
+        """A packed [S | s_h | s_v | cost] buffer owned by the caller (a step function whose statistics
+        must survive until a deferred update reads them keeps its own, never the engine's shared one)."""
+        ldv = padded_ld(V) if ldv is None else ldv
+        ldh = padded_ld(H) if ldh is None else ldh
+        n = C.c_int64()
+        _lib.check(self.lib.mdbn_stats_floats(V, ldv, ldh, C.byref(n)), "mdbn_stats_floats")
+        return torch.zeros(n.value, dtype=torch.float32, device=self.device)
+
     def stats_buffer(self, V, H, slot=0, ldv=None, ldh=None):
+        """Engine-wide scratch statistics buffer (consumed before the call that filled it returns)."""
         ldv = padded_ld(V) if ldv is None else ldv
         ldh = padded_ld(H) if ldh is None else ldh
         key = (V, H, slot, ldv, ldh)
         if key not in self._stats:
-            n = C.c_int64()
-            _lib.check(self.lib.mdbn_stats_floats(V, ldv, ldh, C.byref(n)), "mdbn_stats_floats")
-            self._stats[key] = torch.zeros(n.value, dtype=torch.float32, device=self.device)
+            self._stats[key] = self.new_stats_buffer(V, H, ldv, ldh)
         return self._stats[key]
 
     def cd_scratch(self, B, V, H, need_vs, ldv=None, ldh=None):
@@ -257,7 +275,7 @@ class HipEngine(object):
 
     def gather_rows(self, src, indexes):
         src = self.as_matrix(src)
-        idx = self.index_tensor(indexes)
+        idx = self.index_tensor(indexes, src.shape[0])
         out = self.alloc_matrix(idx.numel(), src.shape[1])
         if idx.numel() == 0:
             return out
@@ -269,15 +287,16 @@ class HipEngine(object):
 
     # ------------------------------------------------------------------ CD-k
     def _cd_args(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent, add_noise, stats_slot,
-                 sample_stats=False):
+                 sample_stats=False, stats=None):
         data = self.as_matrix(data)
         V, H = W.shape
         assert data.shape[1] == V, "data has %d columns, RBM has %d visibles" % (data.shape[1], V)
-        idx = self.index_tensor(indexes) if indexes is not None else None
+        idx = self.index_tensor(indexes, data.shape[0]) if indexes is not None else None
         B = idx.numel() if idx is not None else data.shape[0]
         ldv, ldh = data.stride(0), W.stride(0)
         sc = self.cd_scratch(B, V, H, not gauss, ldv, ldh)
-        stats = self.stats_buffer(V, H, stats_slot, ldv, ldh)
+        if stats is None:
+            stats = self.stats_buffer(V, H, stats_slot, ldv, ldh)
         if persistent is not None and persistent.stride(0) != ldh:
             raise _lib.MdbnError("persistent chain must share W's leading dimension")
         ws = self.workspace(B, V, H)
@@ -299,12 +318,12 @@ class HipEngine(object):
         return a, stats, sc, (data, idx, ws)        # keep the tensors alive until enqueued
 
     def cd_step(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent=None, add_noise=False,
-                stats_slot=0, sample_stats=False):
+                stats_slot=0, sample_stats=False, stats=None):
         """gather + positive phase + k Gibbs steps + statistics (rbm.py:303-345,374).
         Returns (stats, scratch): the packed [S | s_h | s_v | cost_sum] buffer and the
         CDScratch holding ph_mean / nv_mean / nh_mean for inspection."""
         a, stats, sc, _keep = self._cd_args(data, indexes, W, hbias, vbias, gauss, k, rng, persistent,
-                                            add_noise, stats_slot, sample_stats)
+                                            add_noise, stats_slot, sample_stats, stats)
         _lib.check(self.lib.mdbn_cd_step(self.ctx, self._stream(), C.byref(a)), "mdbn_cd_step")
         return stats, sc
 

@@ -106,6 +106,10 @@ class StepFunction(object):
                             and (p.weightcost == 0.0 or p.W0 is not None))
         self._pending = None                # (work, stats, hyper-parameters, LazyCost) of the last step
         self._n_calls = 0
+        # statistics buffers of the data-parallel path are OWNED by this step function: a deferred
+        # update reads them a whole call later, so another step function of the same shape (two
+        # equal-sized modalities, alternating layers) must not share them
+        self._stats_slots = [None, None]
         if self.group is not None and self.group.world_size > 1 and hasattr(self.engine, "set_option"):
             # RCCL's all-reduce kernels run beside the next step's GEMMs.  A GEMM block with two MFMA
             # waves per SIMD fills the CU's register file (3 x 168 VGPRs per SIMD), so a collective
@@ -166,7 +170,7 @@ class StepFunction(object):
             idx = None if (lo == 0 and hi == data.shape[0]) else \
                 torch.arange(lo, hi, dtype=torch.int64, device=data.device)
         else:
-            idx = eng.index_tensor(indexes)[lo:hi]
+            idx = eng.index_tensor(indexes, data.shape[0])[lo:hi]
         step = rbm._take_step()
         persistent = None
         if p.persistent is not None:
@@ -191,13 +195,15 @@ class StepFunction(object):
             return out
         slot = self._n_calls & 1 if self.overlap else 0     # the other buffer may still be reducing
         self._n_calls += 1
+        if self._stats_slots[slot] is None:
+            self._stats_slots[slot] = eng.new_stats_buffer(rbm.n_visible, rbm.n_hidden, data.stride(0),
+                                                           rbm.W.tensor.stride(0))
+        stats = self._stats_slots[slot]
         if hi > lo:
-            stats, _ = eng.cd_step(data, idx, rbm.W.tensor, rbm.hbias.tensor, rbm.vbias.tensor,
-                                   rbm.gauss, p.k,
-                                   RngAddr(rbm.theano_rng.seed, rbm.stream_id, step, 0, lo),
-                                   persistent=persistent, stats_slot=slot, sample_stats=p.symbolic_grad)
+            eng.cd_step(data, idx, rbm.W.tensor, rbm.hbias.tensor, rbm.vbias.tensor, rbm.gauss, p.k,
+                        RngAddr(rbm.theano_rng.seed, rbm.stream_id, step, 0, lo),
+                        persistent=persistent, sample_stats=p.symbolic_grad, stats=stats)
         else:                                  # this rank holds no row of a short minibatch
-            stats = eng.stats_buffer(rbm.n_visible, rbm.n_hidden, slot, data.stride(0), rbm.W.tensor.stride(0))
             stats.zero_()
 
         if p.persistent is not None:
@@ -299,6 +305,8 @@ class RBM(object):
         # rbm.py:415 captures W.get_value() when the update graph is built: a frozen
         # snapshot.  strict_reference=False uses the live W instead.
         self.strict_reference = True
+        self._W0_snapshot = None               # the frozen weight-cost constant of the last get_cost_updates
+        self._resume_W0 = None                 # ... restored from a checkpoint, consumed by the next one
         self.bit_i_idx = 0                     # rbm.py:425
         self._rng_step = 0
         self._n_updates = 0
@@ -390,8 +398,14 @@ class RBM(object):
         if weightcost != 0.0 and self.strict_reference:
             # rbm.py:415; same padded layout as W (a plain clone() would drop the leading dimension)
             snap = self.engine.alloc_matrix(self.n_visible, self.n_hidden, self.W.tensor.stride(0))
-            snap.copy_(self.W.tensor)
+            if self._resume_W0 is not None:
+                # resumed run: the constant is the W of the ORIGINAL graph construction (checkpoint.py)
+                snap.copy_(as_tensor(self._resume_W0, self.engine))
+                self._resume_W0 = None
+            else:
+                snap.copy_(self.W.tensor)
             W0 = SharedArray(None, engine=self.engine, _tensor=snap)
+            self._W0_snapshot = W0
         if persistent is not None:
             persistent = shared(persistent, engine=self.engine)
             if persistent.tensor.stride(0) != self.W.tensor.stride(0):

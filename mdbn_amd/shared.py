@@ -15,6 +15,7 @@ class SharedArray(object):
         self.engine = engine if engine is not None else get_engine()
         self.name = name
         self._sync_hook = None      # called before host reads (completes deferred device work)
+        self.version = 0            # bumped by every set_value (caches of derived data key on it)
         if _tensor is not None:
             self.tensor = _tensor
         else:
@@ -31,6 +32,7 @@ class SharedArray(object):
         return self.engine.to_numpy(self.tensor)
 
     def set_value(self, value, borrow=False):
+        self.version += 1
         new = getattr(value, "tensor", value)
         if not isinstance(new, torch.Tensor):
             new = torch.from_numpy(numpy.ascontiguousarray(new, dtype=numpy.float32))

@@ -49,15 +49,18 @@ class OracleEngine(object):
     def to_numpy(self, t):
         return t.detach().cpu().numpy().astype(np.float32)
 
-    def index_tensor(self, indexes):
+    def index_tensor(self, indexes, n_rows=None):
         if isinstance(indexes, torch.Tensor):
             return indexes.to(torch.int64)
         return torch.from_numpy(np.asarray(indexes).astype(np.int64))
 
+    def new_stats_buffer(self, V, H, ldv=None, ldh=None):
+        return torch.zeros(V * H + H + V + 4, dtype=self.t_dtype)
+
     def stats_buffer(self, V, H, slot=0, ldv=None, ldh=None):
         key = (V, H, slot)
         if key not in self._stats:
-            self._stats[key] = torch.zeros(V * H + H + V + 4, dtype=self.t_dtype)
+            self._stats[key] = self.new_stats_buffer(V, H)
         return self._stats[key]
 
     # --- helpers
@@ -113,7 +116,7 @@ class OracleEngine(object):
 
     # --- CD-k
     def cd_step(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent=None, add_noise=False,
-                stats_slot=0, sample_stats=False):
+                stats_slot=0, sample_stats=False, stats=None):
         data = self.as_matrix(data)
         v0 = (data if indexes is None else data[self.index_tensor(indexes)]).numpy()
         s = self._state(W, hbias, vbias, gauss)
@@ -130,7 +133,8 @@ class OracleEngine(object):
             cost = (v0 * rbm_np.softplus(-pre_nv) + (1 - v0) * rbm_np.softplus(pre_nv)).sum()
         if persistent is not None:
             persistent.copy_(self._t(nh_sample))
-        stats = self.stats_buffer(W.shape[0], W.shape[1], stats_slot)
+        if stats is None:
+            stats = self.stats_buffer(W.shape[0], W.shape[1], stats_slot)
         stats.copy_(self._t(np.concatenate([S.ravel(), s_h, s_v, [cost, 0, 0, 0]])))
         sc = _Scratch()
         sc.ph_mean, sc.nv_mean, sc.nh_mean, sc.ph_sample = ph_mean, nv_mean, nh_mean, ph_sample

@@ -59,6 +59,33 @@ def run_steps(gauss, overlap, group_mode):
                 mid=mid_speed, costs=np.array(costs))
 
 
+def run_interleaved(overlap, group_mode):
+    """Two step functions of the SAME shape (two equal-sized modalities) called alternately: with the
+    all-reduce of each deferred by one call, neither may see the other's pending statistics."""
+    import mdbn_amd
+    from _oracle_engine import OracleEngine
+    eng = mdbn_amd.set_engine(OracleEngine())
+    V, H, data, batches = make_problem(1)
+    out = {}
+    fns = []
+    for name, seed in (("a", 5), ("b", 6)):
+        rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(seed),
+                            theano_rng=mdbn_amd.RandomStreams(11 + seed), engine=eng)
+        _, up = rbm.get_cost_updates(lr=0.05, k=1, batch_size=10, lambda_2=0.1)
+        fns.append((name, rbm, mdbn_amd.function(up, mdbn_amd.shared(data + seed, engine=eng),
+                                                 data_parallel="auto" if group_mode else None, overlap=overlap)))
+    costs = {"a": [], "b": []}
+    for b in batches:
+        for name, rbm, fn in fns:
+            costs[name].append(fn(indexes=b, momentum=0.5))
+    for name, rbm, fn in fns:
+        fn.flush()
+        out["W_" + name] = rbm.W.tensor.numpy().copy()
+        out["Ws_" + name] = rbm.W_speed.tensor.numpy().copy()
+        out["costs_" + name] = np.array([float(c) for c in costs[name]])
+    return out
+
+
 def worker(rank, world, port, outdir, gauss, overlap):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
@@ -67,7 +94,7 @@ def worker(rank, world, port, outdir, gauss, overlap):
     torch.set_num_threads(1)
     from mdbn_amd import dist
     dist.init_from_env(backend="gloo")
-    out = run_steps(gauss, overlap, True)
+    out = run_interleaved(overlap, True) if gauss == 2 else run_steps(gauss, overlap, True)
     np.savez(os.path.join(outdir, "rank%d_%d_%d.npz" % (rank, gauss, overlap)), **out)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -77,7 +104,7 @@ def worker(rank, world, port, outdir, gauss, overlap):
 def dp_results():
     res = {}
     with tempfile.TemporaryDirectory() as d:
-        for gauss in (1, 0):
+        for gauss in (1, 0, 2):             # 2 = the two-step-function interleaving case
             for overlap in (0, 1):
                 mp.spawn(worker, args=(2, free_port(), d, gauss, overlap), nprocs=2, join=True)
                 res[(gauss, overlap)] = [dict(np.load(os.path.join(d, "rank%d_%d_%d.npz" % (r, gauss, overlap))))
@@ -101,6 +128,16 @@ def test_overlap_is_bit_identical_to_sync(dp_results, gauss):
     sync, ovl = dp_results[(gauss, 0)][0], dp_results[(gauss, 1)][0]
     for k in sync:
         assert np.array_equal(sync[k], ovl[k]), k
+
+
+def test_two_step_functions_of_equal_shape_do_not_share_pending_statistics(dp_results):
+    sys.path.insert(0, HERE)
+    single = run_interleaved(False, False)
+    sync, ovl = dp_results[(2, 0)], dp_results[(2, 1)]
+    for k in single:
+        assert np.array_equal(sync[0][k], ovl[0][k]), k                 # overlapped == synchronous, bit for bit
+        assert np.array_equal(ovl[0][k], ovl[1][k]), k                  # replicas agree
+        np.testing.assert_allclose(ovl[0][k], single[k], rtol=1e-11, atol=1e-13, err_msg=k)
 
 
 def test_shard_bounds():

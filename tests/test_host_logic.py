@@ -155,7 +155,7 @@ def test_dbn_training_loop_and_cache(oracle_engine):
     assert out.shape == (60, 4) and np.all((out > 0) & (out < 1))
     # the cached lower activations were refreshed after layer 0 finished training
     ver, _, cached = dbn._lower_cache[1]
-    assert ver == (dbn.rbm_layers[0]._n_updates,)
+    assert ver[0][0] == dbn.rbm_layers[0]._n_updates
     np.testing.assert_allclose(cached.numpy(), dbn.get_output(train, 0), rtol=1e-6)
 
 

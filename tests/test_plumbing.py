@@ -131,3 +131,61 @@ def test_remap_class_hand_case():
     assert utils.remap_class(labels.astype(np.float64), D, 2).tolist() == [0, 0, 0, 1, 1, 1, 1, 1]
     # keeping everything only relabels by rank
     assert utils.remap_class(labels, D, 4).tolist() == [0, 0, 0, 2, 2, 1, 1, 3]
+
+
+def test_resume_keeps_frozen_weight_cost_constant(tmp_path, oracle_engine):
+    """A Bernoulli layer's weight-cost term uses the W captured when its step function was BUILT
+    (rbm.py:415).  A resumed run must keep that constant, not snapshot the resumed W."""
+    DBN.verbose = False
+    rs = np.random.RandomState(0)
+    x = (rs.uniform(size=(40, 8)) < 0.4).astype(np.float64)
+    net = DBN(numpy_rng=np.random.RandomState(4), n_ins=8, gauss=False, hidden_layers_sizes=[], n_outs=5)
+    rbm = net.rbm_layers[0]
+    _, up = rbm.get_cost_updates(0.1, k=1, weightcost=0.05, batch_size=10)      # large cost: the term matters
+    fn = mdbn_amd.function(up, mdbn_amd.shared(x))
+    for t in range(2):
+        fn(indexes=np.arange(10) + 10 * t, momentum=0.5)
+    path = str(tmp_path / "resume.npz")
+    checkpoint.save_network(path, {'top': net}, resume=True)
+    want = [float(fn(indexes=np.arange(10) + 10 * t, momentum=0.5)) for t in (2, 3)]
+    net2 = checkpoint.load_network(path)['top']
+    r2 = net2.rbm_layers[0]
+    _, up2 = r2.get_cost_updates(0.1, k=1, weightcost=0.05, batch_size=10)
+    np.testing.assert_allclose(up2.W0.get_value(), up.W0.get_value(), rtol=0, atol=1e-7)   # float32 round trip
+    fn2 = mdbn_amd.function(up2, mdbn_amd.shared(x))
+    got = [float(fn2(indexes=np.arange(10) + 10 * t, momentum=0.5)) for t in (2, 3)]
+    np.testing.assert_allclose(got, want, rtol=1e-6)
+    np.testing.assert_allclose(r2.W.get_value(), rbm.W.get_value(), rtol=1e-5, atol=1e-7)
+    # without the stored constant the trajectories differ visibly
+    net3 = checkpoint.load_network(path)['top']
+    net3.rbm_layers[0]._resume_W0 = None
+    _, up3 = net3.rbm_layers[0].get_cost_updates(0.1, k=1, weightcost=0.05, batch_size=10)
+    fn3 = mdbn_amd.function(up3, mdbn_amd.shared(x))
+    for t in (2, 3):
+        fn3(indexes=np.arange(10) + 10 * t, momentum=0.5)
+    assert np.abs(net3.rbm_layers[0].W.get_value() - rbm.W.get_value()).max() > 2e-5      # (the positive check above holds 1e-7)
+
+
+def test_lower_layer_cache_sees_direct_parameter_writes(oracle_engine):
+    """The cached lower-layer activations are dropped when a lower layer's W is replaced through
+    set_value (weights loaded into an existing DBN), not only after training steps."""
+    DBN.verbose = False
+    rs = np.random.RandomState(0)
+    net = DBN(numpy_rng=np.random.RandomState(1), n_ins=6, hidden_layers_sizes=[5], n_outs=3)
+    x = mdbn_amd.shared(rs.normal(size=(12, 6)))
+    provider = net._layer_input_fn(1, x)
+    a = provider().clone()
+    assert provider() is provider()                                   # cached
+    net.rbm_layers[0].W.set_value(net.rbm_layers[0].W.get_value() * 0.5)
+    b = provider()
+    assert not np.allclose(a.numpy(), b.numpy())
+    np.testing.assert_allclose(b.numpy(), net._forward(x, 0).numpy())
+
+
+def test_bad_minibatch_index_raises(oracle_engine):
+    from mdbn_amd.engine import HipEngine
+    with pytest.raises(IndexError):
+        HipEngine.index_tensor(oracle_engine, np.array([0, 5, 12]), 12)
+    with pytest.raises(IndexError):
+        HipEngine.index_tensor(oracle_engine, [-13], 12)
+    assert HipEngine.index_tensor(oracle_engine, np.array([-12, 11]), 12).tolist() == [-12, 11]
