@@ -76,6 +76,12 @@ typedef struct mdbn_cd_args {
     void        *workspace;   /* >= mdbn_workspace_bytes(B, V, H)                                */
     int64_t      workspace_bytes;
     mdbn_rng     rng;         /* .draw is ignored (the step numbers its own draws)               */
+    /* optional monitoring taps on the Gibbs chain (NULL = off; the role MonitorMode plays at
+     * dbn.py:297-300,538-548): every sample the chain feeds onward is also copied here, so a checker can
+     * follow the device's chain half-step by half-step */
+    float       *trace_h;     /* [k+1][B][ldh]: slot 0 = positive-phase sample, slot t = hidden sample of
+                               * Gibbs step t (slot k only when that sample is materialised: PCD)      */
+    float       *trace_v;     /* [k][B][ldv]: slot t-1 = Bernoulli visible sample of step t (RBM only)   */
 } mdbn_cd_args;
 
 /* Parameter update of src/rbm.py:347-365 from (all-reduced) statistics. */

@@ -25,7 +25,7 @@ class CdArgs(C.Structure):
                 ("persistent", C.c_void_p),
                 ("V2", C.c_void_p), ("P2", C.c_void_p), ("hs", C.c_void_p), ("vs", C.c_void_p),
                 ("stats", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("rng", Rng)]
+                ("rng", Rng), ("trace_h", C.c_void_p), ("trace_v", C.c_void_p)]
 
 
 class UpdateArgs(C.Structure):

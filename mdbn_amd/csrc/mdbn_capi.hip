@@ -797,6 +797,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
                   nullptr, 0, false, &a->rng, 0u};
         up.colsum = ws.colPpos;                                         // sum_rows ph_mean
         CHECK(run_affine(up, ws, s, nullptr));
+        if (a->trace_h) HIP_OK(hipMemcpyAsync(a->trace_h, a->hs, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
     }
     int n_cost = 0;
     for (int t = 1; t <= a->k; ++t) {                                  // gibbs_hvh x k (rbm.py:318-336)
@@ -813,6 +814,9 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         down.x_binary = chain == a->hs;         // our own 0/1 hidden samples (a caller's persistent chain may hold anything)
         if (last) { down.colsum = ws.colV; down.colsum_kind = samp_stats ? 2 : 1; }   // sum_rows (v0 - nv)
         CHECK(run_affine(down, ws, s, last ? &n_cost : nullptr));
+        if (a->trace_v && !a->gauss)
+            HIP_OK(hipMemcpyAsync(a->trace_v + (int64_t)(t - 1) * B * ldv, samp_stats ? nv : a->vs, sizeof(float) * B * ldv,
+                                  hipMemcpyDeviceToDevice, s));
         // h_t | v_t: from the mean for GRBM (rbm.py:669), from the sample for RBM (rbm.py:246)
         const bool need_sample = !last || a->persistent != nullptr;
         float* hdst = (last && a->persistent) ? a->persistent : a->hs;            // rbm.py:369
@@ -821,6 +825,8 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         up.x_binary = !a->gauss;                // Bernoulli visibles: the chain feeds the 0/1 sample upward
         if (last) up.colsum = ws.colPneg;                               // sum_rows (-nh_mean)
         CHECK(run_affine(up, ws, s, nullptr));
+        if (a->trace_h && need_sample)
+            HIP_OK(hipMemcpyAsync(a->trace_h + (int64_t)t * B * ldh, hdst, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
     }
 
     float* S = a->stats;

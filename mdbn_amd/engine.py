@@ -67,6 +67,7 @@ class CDScratch(object):
         self.P2 = engine.alloc_matrix(2 * B, H, ldh)       # same ld as W
         self.hs = engine.alloc_matrix(B, H, ldh)
         self.vs = engine.alloc_matrix(B, V, ldv) if need_vs else None
+        self.trace_h = self.trace_v = None      # chain taps (HipEngine.trace_chain), [k+1, B, ldh] / [k, B, ldv]
 
 
 class HipEngine(object):
@@ -88,6 +89,7 @@ class HipEngine(object):
         self._scratch = {}
         self._cost_ring = torch.zeros(1024, dtype=torch.float32, device=self.device)
         self._cost_slot = 0
+        self.last_scratch = None        # CDScratch of the most recent CD step (inspection / chain taps)
 
     def __del__(self):
         try:
@@ -133,6 +135,7 @@ class HipEngine(object):
     def to_numpy(self, t):
         return t.detach().cpu().numpy()
 
+    trace_chain = False         # True: every CD step also records the samples its Gibbs chain feeds onward
     check_indexes = False       # True: also range-check index lists that already live on the device (one sync)
 
     def index_tensor(self, indexes, n_rows=None):
@@ -295,6 +298,7 @@ class HipEngine(object):
         B = idx.numel() if idx is not None else data.shape[0]
         ldv, ldh = data.stride(0), W.stride(0)
         sc = self.cd_scratch(B, V, H, not gauss, ldv, ldh)
+        self.last_scratch = sc
         if stats is None:
             stats = self.stats_buffer(V, H, stats_slot, ldv, ldh)
         if persistent is not None and persistent.stride(0) != ldh:
@@ -315,6 +319,12 @@ class HipEngine(object):
         a.stats = stats.data_ptr()
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         a.rng = rng.c()
+        if self.trace_chain:
+            if sc.trace_h is None or sc.trace_h.shape[0] != k + 1:
+                sc.trace_h = torch.zeros((k + 1, B, ldh), dtype=torch.float32, device=self.device)
+                sc.trace_v = None if gauss else torch.zeros((k, B, ldv), dtype=torch.float32, device=self.device)
+            a.trace_h = sc.trace_h.data_ptr()
+            a.trace_v = sc.trace_v.data_ptr() if sc.trace_v is not None else None
         return a, stats, sc, (data, idx, ws)        # keep the tensors alive until enqueued
 
     def cd_step(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent=None, add_noise=False,

@@ -185,6 +185,52 @@ def cd_chain(s, v0, draws, k, persistent=None):
     return ph_mean, ph_sample, out
 
 
+def _follow(own, recorded, u, mean, tie, what):
+    """Teacher forcing: the recorded sample must equal the oracle's own except where the uniform lies
+    within ``tie`` of the probability (a draw that fp32 rounding can push either way)."""
+    recorded = np.asarray(recorded, dtype=own.dtype)
+    differ = own != recorded
+    if differ.any():
+        gap = np.abs(np.asarray(u, dtype=np.float64) - mean)[differ]
+        assert gap.max() < tie, "%s: recorded sample differs from the oracle's away from a tie (|u - p| = %g)" % (what, gap.max())
+    return recorded, int(differ.sum())
+
+
+def cd_chain_forced(s, v0, draws, k, trace_h, trace_v=None, persistent=None, tie=1e-6):
+    """``cd_chain`` (rbm.py:303-336) that FOLLOWS a recorded chain (tests only): every sample the chain
+    feeds onward is taken from ``trace_h[t]`` / ``trace_v[t-1]`` (the device's, mdbn_cd_args.trace_*)
+    after checking it against the oracle's own draw outside near-ties, so probabilities are always
+    compared on identical chain states -- for any k.  Returns (ph_mean, ph_sample, out, n_tie_flips)."""
+    B = v0.shape[0]
+    flips = 0
+    U0 = draws.u(0, B, s.n_hidden)
+    pre_ph, ph_mean, own = sample_h_given_v(s, v0, U0)
+    ph_sample, n = _follow(own, trace_h[0], U0, ph_mean, tie, "h0")
+    flips += n
+    chain = ph_sample if persistent is None else persistent
+    Bc = chain.shape[0]
+    out = None
+    for t in range(1, k + 1):
+        if s.gauss:
+            dv = None if s.error_free else draws.z(2 * t - 1, Bc, s.n_visible)
+            pre_v, v_mean, v_sample = sample_v_given_h(s, chain, dv)
+            v_in = v_mean                                                   # rbm.py:669
+        else:
+            Uv = draws.u(2 * t - 1, Bc, s.n_visible)
+            pre_v, v_mean, own_v = sample_v_given_h(s, chain, Uv)
+            v_sample, n = _follow(own_v, trace_v[t - 1], Uv, v_mean, tie, "v%d" % t)
+            flips += n
+            v_in = v_sample                                                 # rbm.py:246
+        Uh = draws.u(2 * t, Bc, s.n_hidden)
+        pre_h, h_mean, h_sample = sample_h_given_v(s, v_in, Uh)
+        if t < k or persistent is not None:
+            h_sample, n = _follow(h_sample, trace_h[t], Uh, h_mean, tie, "h%d" % t)
+            flips += n
+        out = [pre_v, v_mean, v_sample, pre_h, h_mean, h_sample]
+        chain = h_sample
+    return ph_mean, ph_sample, out, flips
+
+
 def cd_statistics(v0, ph_mean, nv_mean, nh_mean):
     """Un-normalised sufficient statistics of rbm.py:411-417 (what a DP rank sums
     before the all-reduce): S = v0'ph - nv'nh, s_h, s_v."""
@@ -223,7 +269,7 @@ def apply_update(s, g_W, g_hb, g_vb, lr, lambda_1, lambda_2, momentum):
 
 def cd_step(s, v0, draws, lr=0.1, k=1, lambda_1=0.0, lambda_2=0.0, weightcost=0.0,
             batch_size=None, momentum=0.0, persistent=False, strict_reference=True,
-            return_extras=False, symbolic_grad=False, chain_start=None):
+            return_extras=False, symbolic_grad=False, chain_start=None, forced=None, tie=1e-6):
     """One call of the compiled step function of rbm.py:258-376 (get_cost_updates +
     theano.function with updates): mutates ``s`` and returns the monitoring cost.
 
@@ -231,12 +277,17 @@ def cd_step(s, v0, draws, lr=0.1, k=1, lambda_1=0.0, lambda_2=0.0, weightcost=0.
     ``chain_start`` (tests only): start the CD chain from these hidden samples instead of the
     oracle's own positive-phase sample -- teacher forcing, so that a Bernoulli draw within fp32
     rounding of its probability on the device cannot fork the two chains.
+    ``forced`` (tests only): ``(trace_h, trace_v)`` recorded by the device; the whole chain follows
+    them (``cd_chain_forced``).
     """
     v0 = np.asarray(v0, dtype=s.dtype)
     if batch_size is None:
         batch_size = v0.shape[0]
     chain0 = s.persistent if persistent else chain_start
-    ph_mean, ph_sample, out = cd_chain(s, v0, draws, k, chain0)
+    if forced is not None:
+        ph_mean, ph_sample, out, _ = cd_chain_forced(s, v0, draws, k, forced[0], forced[1], chain0, tie=tie)
+    else:
+        ph_mean, ph_sample, out = cd_chain(s, v0, draws, k, chain0)
     pre_nv, nv_mean, nv_sample, pre_nh, nh_mean, nh_sample = out
     if symbolic_grad:
         # rbm.py:341-342,378-390: gradient of mean F(chain_end) - mean F(input) with

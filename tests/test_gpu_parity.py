@@ -435,10 +435,10 @@ def test_shape_sweep_chain_and_update(hip_engine, V, H, B):
     import mdbn_amd
     rs = np.random.RandomState(V * 7 + H * 3 + B)
     N = B + 3
-    # Chains are compared without teacher forcing here, so a Bernoulli draw within fp32 rounding
-    # of its probability would fork device and oracle (test_cd_step_statistics handles that case
-    # explicitly).  The Philox seed below was checked to have no such near-tie for these shapes.
-    seed = 78 if (V, H, B) in ((1021, 509, 131), (256, 200, 512)) else 77
+    # The oracle follows the device's recorded chain (mdbn_cd_args.trace_*, rbm_np.cd_chain_forced), so a
+    # Bernoulli draw within fp32 rounding of its probability cannot fork the two -- whatever the seed.
+    seed = 77
+    hip_engine.trace_chain = True
     for cls, gauss, hp, k in ((mdbn_amd.RBM, False, dict(lr=0.1, weightcost=2e-4), 2),
                               (mdbn_amd.GRBM, True, dict(lr=0.002, lambda_1=0.01, lambda_2=0.1), 1)):
         data = rs.normal(size=(N, V)).astype(np.float32) if gauss else (rs.uniform(size=(N, V)) < 0.4).astype(np.float32)
@@ -452,7 +452,10 @@ def test_shape_sweep_chain_and_update(hip_engine, V, H, B):
         idx = rs.permutation(N)[:B]
         for t in range(2):
             c = float(fn(indexes=idx, momentum=0.5))
-            c_o = rbm_np.cd_step(st, data[idx], PhiloxDraws(seed, rbm.stream_id, t), k=k, batch_size=B, momentum=0.5, **hp)
+            sc = hip_engine.last_scratch
+            forced = (sc.trace_h.cpu().numpy()[:, :, :H], None if gauss else sc.trace_v.cpu().numpy()[:, :, :V])
+            c_o = rbm_np.cd_step(st, data[idx], PhiloxDraws(seed, rbm.stream_id, t), k=k, batch_size=B, momentum=0.5,
+                                 forced=forced, **hp)
             assert abs(c - c_o) <= 2e-4 * abs(c_o) + 1e-6, (cls.__name__, t, c, c_o)
         for name in ("W", "hbias", "vbias", "W_speed", "hbias_speed", "vbias_speed"):
             got, want = getattr(rbm, name).get_value(), getattr(st, name)
@@ -461,6 +464,7 @@ def test_shape_sweep_chain_and_update(hip_engine, V, H, B):
         F = rbm.free_energy(data).get_value()
         F_o = rbm_np.free_energy(st, data.astype(np.float64))
         assert np.abs(F - F_o).max() <= 1e-4 * max(1.0, np.abs(F_o).max())
+    hip_engine.trace_chain = False
 
 
 def test_pcd_on_device(hip_engine):

@@ -1,0 +1,235 @@
+"""The reference's class surface ON THE HIP ENGINE, checked step by step against the float64 oracle with
+teacher forcing (tests/_shadow.py): eager gibbs_hvh / gibbs_vhv and their RNG accounting, the stand-alone
+trainers RBM.training (CD and PCD) / GRBM.training / learn_model, DBN.training, MDBN.train_bottom_layer /
+train_top, CD-5 at the c5 miRNA shape, and 100-step weight drift at the shapes SURVEY 8d names."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox_np, rbm_np
+from oracle.philox_np import PhiloxDraws
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def shadow(built_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import mdbn_amd
+    import mdbn_amd.engine as E
+    from _shadow import ShadowEngine
+    prev = E._default_engine
+    eng = mdbn_amd.set_engine(ShadowEngine())
+    yield eng
+    E._default_engine = prev
+
+
+def _u(rbm, step, rows, cols):
+    return philox_np.uniform(rows, cols, rbm.theano_rng.seed, rbm.stream_id, step, 0, 0)
+
+
+@pytest.mark.parametrize("gauss", [False, True])
+@pytest.mark.parametrize("V,H,B", [(12, 7, 5), (784, 500, 20), (1024, 256, 512)])
+def test_eager_gibbs_steps_and_rng_accounting(hip_engine, gauss, V, H, B):
+    """gibbs_hvh / gibbs_vhv (rbm.py:242-256; GRBM :662-682) as eager device calls: the six outputs in
+    the documented order against the oracle, and the Philox bookkeeping: every sample_* call takes one
+    ``step`` (draw 0), so one Gibbs step advances the layer's counter by exactly two."""
+    import mdbn_amd
+    cls = mdbn_amd.GRBM if gauss else mdbn_amd.RBM
+    rbm = cls(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(V + H), theano_rng=mdbn_amd.RandomStreams(31),
+              engine=hip_engine)
+    rs = np.random.RandomState(1)
+    rbm.hbias.set_value(rs.normal(0, 0.2, H).astype(np.float32))
+    rbm.vbias.set_value(rs.normal(0, 0.2, V).astype(np.float32))
+    st = rbm_np.RBMState(V, H, W=rbm.W.get_value(), hbias=rbm.hbias.get_value(), vbias=rbm.vbias.get_value(), gauss=gauss)
+    tol_h = 2e-6 * max(1.0, (V / 1024.0) ** 0.5)
+    tol_v = 4e-6 * max(1.0, (H / 1024.0) ** 0.5)
+
+    def same_sample(got, mean, u):
+        want = (u < mean).astype(np.float64)
+        bad = got != want
+        assert np.all(np.abs(u - mean)[bad] < 1e-6)
+
+    # --- gibbs_hvh from a binary hidden state
+    h0 = (rs.uniform(size=(B, H)) < 0.5).astype(np.float32)
+    s0 = rbm._rng_step
+    pre_v, v_mean, v_sample, pre_h, h_mean, h_sample = [a.get_value() for a in rbm.gibbs_hvh(h0)]
+    assert rbm._rng_step == s0 + 2
+    o_pre_v, o_v_mean, _ = rbm_np.sample_v_given_h(st, h0.astype(np.float64), _u(rbm, s0, B, V))
+    scale = max(1.0, np.abs(o_v_mean).max())
+    assert np.abs(v_mean - o_v_mean).max() <= tol_v * scale and np.abs(pre_v - o_pre_v).max() <= 2 * tol_v * max(1.0, np.abs(o_pre_v).max())
+    if gauss:
+        assert np.array_equal(v_sample, v_mean)                 # error_free: the sample IS the mean (rbm.py:652-653)
+        v_in = v_mean
+    else:
+        same_sample(v_sample, o_v_mean, _u(rbm, s0, B, V))
+        v_in = v_sample
+    o_pre_h, o_h_mean = rbm_np.propup(st, v_in.astype(np.float64))   # teacher-forced on the device's visible state
+    assert np.abs(h_mean - o_h_mean).max() <= tol_h and np.abs(pre_h - o_pre_h).max() <= 1e-5 * max(1.0, np.abs(o_pre_h).max())
+    same_sample(h_sample, o_h_mean, _u(rbm, s0 + 1, B, H))
+
+    # --- gibbs_vhv from data
+    v0 = rs.normal(size=(B, V)).astype(np.float32) if gauss else (rs.uniform(size=(B, V)) < 0.3).astype(np.float32)
+    s1 = rbm._rng_step
+    pre_h, h_mean, h_sample, pre_v, v_mean, v_sample = [a.get_value() for a in rbm.gibbs_vhv(v0)]
+    assert rbm._rng_step == s1 + 2
+    _, o_h_mean = rbm_np.propup(st, v0.astype(np.float64))
+    assert np.abs(h_mean - o_h_mean).max() <= tol_h
+    same_sample(h_sample, o_h_mean, _u(rbm, s1, B, H))
+    h_in = h_mean if gauss else h_sample                       # GRBM: v1 from the hidden MEAN (rbm.py:680)
+    _, o_v_mean, _ = rbm_np.sample_v_given_h(st, h_in.astype(np.float64), _u(rbm, s1 + 1, B, V))
+    assert np.abs(v_mean - o_v_mean).max() <= tol_v * max(1.0, np.abs(o_v_mean).max())
+    if not gauss:
+        same_sample(v_sample, o_v_mean, _u(rbm, s1 + 1, B, V))
+
+
+def test_noisy_grbm_sample(hip_engine):
+    """GRBM(error_free=False): v1_sample = v1_mean + N(0,1) (rbm.py:655-658), Box-Muller twin."""
+    import mdbn_amd
+    V, H, B = 96, 40, 33
+    rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(3), theano_rng=mdbn_amd.RandomStreams(8),
+                        error_free=False, engine=hip_engine)
+    h0 = (np.random.RandomState(0).uniform(size=(B, H)) < 0.5).astype(np.float32)
+    s0 = rbm._rng_step
+    _, mean, sample = [a.get_value() for a in rbm.sample_v_given_h(h0)]
+    z = philox_np.normal(B, V, 8, rbm.stream_id, s0, 0, 0)
+    np.testing.assert_allclose(sample - mean, z, atol=3e-5)
+
+
+@pytest.mark.parametrize("persistent", [False, True])
+def test_rbm_training_on_device(shadow, persistent):
+    """RBM.training -> learn_model (rbm.py:484-629) on the HIP engine: CD-2 and PCD-2, momentum switch at
+    epoch 6, every step replayed by the oracle along the device's chain."""
+    import mdbn_amd
+    V, H, N, B = 100, 60, 120, 20
+    rs = np.random.RandomState(0)
+    data = (rs.uniform(size=(N, V)) < 0.3).astype(np.float32)
+    rbm = mdbn_amd.RBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123), theano_rng=mdbn_amd.RandomStreams(5),
+                       engine=shadow)
+    np.random.seed(4)                                        # the reference shuffles with the global state (utils.py:62)
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        history = rbm.training(data, data[:30], training_epochs=8, batch_size=B, learning_rate=0.1, k=2,
+                               initial_momentum=0.6, final_momentum=0.9, weightcost=2e-4, persistent=persistent)
+    assert len(history) == 8 and shadow.steps == 8 * (N // B)
+    assert all(np.isfinite(c) and g is not None and np.isfinite(g) for c, g in history)
+    if persistent:
+        # pseudo-likelihood monitor (rbm.py:421-447): epoch means of the per-step costs, bit index rotating
+        per_epoch = np.array(shadow.pl_costs).reshape(8, N // B).mean(axis=1)
+        np.testing.assert_allclose([c for c, _ in history], per_epoch, rtol=2e-4)
+        assert rbm.bit_i_idx == (8 * (N // B)) % V
+        assert shadow.stat_err <= 1e-5
+    else:
+        assert shadow.cost_err <= 1e-4
+    assert shadow.param_err(rbm) <= 2e-5
+
+
+def test_grbm_training_on_device(shadow):
+    """GRBM.training (rbm.py:701-728: always CD, lambda_2 forwarded) on the HIP engine."""
+    import io, contextlib
+    import mdbn_amd
+    V, H, N, B = 130, 70, 96, 32
+    rs = np.random.RandomState(1)
+    data = rs.normal(size=(N, V)).astype(np.float32)
+    rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123), theano_rng=mdbn_amd.RandomStreams(6),
+                        engine=shadow)
+    np.random.seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        history = rbm.training(data, data[:16], training_epochs=7, batch_size=B, learning_rate=0.005, k=1,
+                               lambda_1=0.01, lambda_2=0.1, persistent=True)      # persistent is ignored (rbm.py:701-728)
+    assert len(history) == 7 and shadow.steps == 7 * 3
+    assert shadow.cost_err <= 1e-4 and shadow.param_err(rbm) <= 2e-5
+
+
+def test_mdbn_glue_on_device(shadow):
+    """MDBN.train_bottom_layer / train_top (MDBN.py:31-76) on the HIP engine: two modalities with a
+    Gaussian first layer, concatenated, joint Bernoulli DBN 24 -> 3; every CD step oracle-checked."""
+    import mdbn_amd
+    from mdbn_amd import MDBN
+    mdbn_amd.DBN.verbose = False
+    rs = np.random.RandomState(0)
+    N = 64
+    rng = np.random.RandomState(123)
+    np.random.seed(11)
+    shadow.tie = 5e-5            # thousands of steps: fp32 parameters drift from the float64 shadow by up to ~5e-5
+    outs, nets = [], []
+    for width, sizes in ((96, [24, 8]), (40, [6])):
+        x = rs.normal(size=(N, width)).astype(np.float32)
+        net, out_t, out_v = MDBN.train_bottom_layer(x, x[:8], batch_size=16, k=1, layers_sizes=sizes,
+                                                    pretraining_epochs=[6] * len(sizes),
+                                                    pretrain_lr=[0.005] + [0.1] * (len(sizes) - 1), rng=rng)
+        assert out_t.shape == (N, sizes[-1]) and out_v.shape == (8, sizes[-1])
+        outs.append(out_t)
+        nets.append(net)
+    joint = np.concatenate(outs, axis=1)
+    top = MDBN.train_top(16, False, joint, None, rng)
+    # train_top's fixed schedule: 800 "epochs" budget compared with the iteration count -> stops after ~800 iterations
+    assert top.number_of_nodes() == [14, 24, 3]
+    assert shadow.steps > 100
+    assert shadow.cost_err <= 2e-4, shadow.cost_err
+    for net in nets + [top]:
+        for r in net.rbm_layers:
+            assert shadow.param_err(r) <= 5e-5
+    assert top.get_output(joint).shape == (N, 3)
+
+
+@pytest.mark.parametrize("V,H,B,k,gauss", [(512, 40, 512, 5, True), (512, 40, 512, 5, False), (130, 70, 37, 3, False),
+                                           (2048, 400, 512, 2, True), (100, 128, 512, 5, False)])
+def test_cd_k_chain_teacher_forced(hip_engine, V, H, B, k, gauss):
+    """CD-k with k > 1 (c5's miRNA layer: 512 -> 40, CD-5 at B = 512): statistics and cost of one step with the
+    oracle following the device's chain at every half-step."""
+    from mdbn_amd import RngAddr
+    rs = np.random.RandomState(V + k)
+    W = rbm_np.init_W(rs, V, H, np.float32)
+    hb, vb = rs.normal(0, 0.2, H).astype(np.float32), rs.normal(0, 0.2, V).astype(np.float32)
+    x = rs.normal(size=(B, V)).astype(np.float32) if gauss else (rs.uniform(size=(B, V)) < 0.3).astype(np.float32)
+    dW, dhb, dvb, dx = [hip_engine.to_device(a) for a in (W, hb, vb, x)]
+    hip_engine.trace_chain = True
+    try:
+        stats, sc = hip_engine.cd_step(dx, None, dW, dhb, dvb, gauss, k, RngAddr(99, 2, 7, 0, 0))
+        th = sc.trace_h.cpu().numpy()[:, :, :H]
+        tv = None if gauss else sc.trace_v.cpu().numpy()[:, :, :V]
+    finally:
+        hip_engine.trace_chain = False
+    st = rbm_np.RBMState(V, H, W=W, hbias=hb, vbias=vb, gauss=gauss)
+    v0 = x.astype(np.float64)
+    ph, _, out, flips = rbm_np.cd_chain_forced(st, v0, PhiloxDraws(99, 2, 7, 0), k, th, tv)
+    S_o, s_h_o, s_v_o = rbm_np.cd_statistics(v0, ph, out[1], out[4])
+    ldh, ldv = sc.P2.stride(0), sc.V2.stride(0)
+    d = stats.cpu().numpy()
+    S, s_h, s_v = d[:V * ldh].reshape(V, ldh)[:, :H], d[V * ldh:V * ldh + H], d[V * ldh + ldh:V * ldh + ldh + V]
+    assert np.abs(S - S_o).max() <= 1e-5 * max(1.0, np.abs(S_o).max())
+    assert np.abs(s_h - s_h_o).max() <= 1e-5 * max(1.0, np.abs(s_h_o).max())
+    assert np.abs(s_v - s_v_o).max() <= 1e-5 * max(1.0, np.abs(s_v_o).max())
+    assert np.abs(sc.V2[B:].cpu().numpy() - out[1]).max() <= 4e-6 * max(1.0, np.abs(out[1]).max())
+    assert flips <= 3
+
+
+@pytest.mark.parametrize("V,H,B,gauss,hp", [
+    (784, 500, 20, False, dict(lr=0.1, weightcost=2e-4)),                     # c1, the reference's own shape
+    (4096, 1024, 512, True, dict(lr=0.001, lambda_2=0.1)),                    # c2 (lr as bench.py: 0.005 diverges)
+])
+def test_hundred_step_drift_teacher_forced(shadow, V, H, B, gauss, hp):
+    """W after 100 teacher-forced steps within 1e-4 relative of the float64 oracle, at the named
+    parity shapes."""
+    import mdbn_amd
+    N = 8 * B
+    rs = np.random.RandomState(7)
+    data = rs.normal(size=(N, V)).astype(np.float32) if gauss else (rs.uniform(size=(N, V)) < 0.13).astype(np.float32)
+    cls = mdbn_amd.GRBM if gauss else mdbn_amd.RBM
+    rbm = cls(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123), theano_rng=mdbn_amd.RandomStreams(21),
+              engine=shadow)
+    _, up = rbm.get_cost_updates(k=1, batch_size=B, **hp)
+    fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=shadow), data_parallel=None)
+    shadow.tie = 2e-5            # the allowed 1e-4 relative weight drift moves probabilities by up to ~1e-5
+    for t in range(100):
+        fn(indexes=rs.permutation(N)[:B], momentum=0.6 if t < 50 else 0.9)
+    assert shadow.steps == 100
+    st = shadow.shadow[rbm.W.tensor.data_ptr()]
+    W, W_o = rbm.W.get_value(), st.W
+    assert np.abs(W - W_o).max() <= 1e-4 * np.abs(W_o).max()
+    assert shadow.cost_err <= 1e-4
+    F = rbm.free_energy(data[:B]).get_value()
+    F_o = rbm_np.free_energy(st, data[:B].astype(np.float64))
+    assert np.abs(F - F_o).max() <= 1e-4 * np.abs(F_o).max()            # the north star's parity quantity

@@ -204,3 +204,35 @@ def test_float32_close_to_float64():
     c64 = rbm_np.cd_step(s64, v0, ArrayDraws(U), lr=0.005, lambda_2=0.1, batch_size=8)
     c32 = rbm_np.cd_step(s32, v0, ArrayDraws(U), lr=0.005, lambda_2=0.1, batch_size=8)
     assert abs(c64 - c32) < 1e-5 and np.abs(s64.W_speed - s32.W_speed).max() < 1e-5
+
+
+def test_forced_chain_follows_a_recording():
+    """cd_chain_forced (teacher forcing for the device tests): following its own recording reproduces
+    cd_chain; a recorded sample that differs away from a tie is refused, one within a tie is followed."""
+    from oracle.philox_np import PhiloxDraws
+    for gauss in (False, True):
+        V, H, B, k = 9, 6, 5, 3
+        rs = np.random.RandomState(2)
+        s = rbm_np.RBMState(V, H, numpy_rng=rs, gauss=gauss)
+        v0 = rs.normal(size=(B, V)) if gauss else (rs.uniform(size=(B, V)) < 0.4).astype(np.float64)
+        draws = PhiloxDraws(3, 1, 4)
+        ph, ph_s, out = rbm_np.cd_chain(s, v0, draws, k)
+        # record: hidden samples h0..h_{k-1}, visible samples v1..vk (Bernoulli)
+        th, tv, chain = [ph_s], [], ph_s
+        for t in range(1, k + 1):
+            dv = None if gauss else draws.u(2 * t - 1, B, V)
+            o = rbm_np.gibbs_hvh(s, chain, dv, draws.u(2 * t, B, H))
+            tv.append(o[2]); th.append(o[5]); chain = o[5]
+        ph2, ph_s2, out2, flips = rbm_np.cd_chain_forced(s, v0, draws, k, th, None if gauss else tv)
+        assert flips == 0 and np.array_equal(ph, ph2) and all(np.array_equal(a, b) for a, b in zip(out, out2))
+        bad = [t.copy() for t in th]
+        u0 = draws.u(0, B, H)
+        far = np.unravel_index(np.argmax(np.abs(u0 - ph)), ph.shape)
+        bad[0][far] = 1 - bad[0][far]
+        with pytest.raises(AssertionError):
+            rbm_np.cd_chain_forced(s, v0, draws, k, bad, None if gauss else tv)
+        # a flip within the tie width is followed, and the rest of the chain is computed from it
+        # (k = 1: the step after the flipped h0 is the one returned)
+        _, _, out1, _ = rbm_np.cd_chain_forced(s, v0, draws, 1, th, None if gauss else tv)
+        _, _, out3, flips = rbm_np.cd_chain_forced(s, v0, draws, 1, bad, None if gauss else tv, tie=1.0)
+        assert flips >= 1 and not np.array_equal(out3[1], out1[1])
