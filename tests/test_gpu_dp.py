@@ -14,7 +14,8 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-V, H, N, BG = 320, 192, 1024, 256
+SHAPES = {"small": (320, 192, 1024, 256),
+          "c2": (4096, 1024, 4096, 1024)}      # BASELINE configs[2] at two ranks: 512 rows per rank
 
 
 def free_port():
@@ -25,8 +26,9 @@ def free_port():
     return p
 
 
-def run_steps(group_mode, overlap):
+def run_steps(group_mode, overlap, shape="small"):
     import mdbn_amd
+    V, H, N, BG = SHAPES[shape]
     eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
     rs = np.random.RandomState(0)
     data = rs.normal(size=(N, V)).astype(np.float32)
@@ -45,26 +47,27 @@ def run_steps(group_mode, overlap):
                 hbs=rbm.hbias_speed.get_value(), costs=np.array(costs))
 
 
-def worker(rank, world, port, outdir, overlap):
+def worker(rank, world, port, outdir, overlap, shape):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     from mdbn_amd import dist
     dist.init_from_env(backend="gloo")
-    out = run_steps(True, overlap)
+    out = run_steps(True, overlap, shape)
     np.savez(os.path.join(outdir, "rank%d_%d.npz" % (rank, overlap)), **out)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process_on_device(built_lib):
+@pytest.mark.parametrize("shape", ["small", "c2"])
+def test_two_ranks_equal_one_process_on_device(built_lib, shape):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    single = run_steps(False, False)
+    single = run_steps(False, False, shape)
     with tempfile.TemporaryDirectory() as d:
         res = {}
         for overlap in (0, 1):
-            mp.spawn(worker, args=(2, free_port(), d, overlap), nprocs=2, join=True)
+            mp.spawn(worker, args=(2, free_port(), d, overlap, shape), nprocs=2, join=True)
             res[overlap] = [dict(np.load(os.path.join(d, "rank%d_%d.npz" % (r, overlap)))) for r in range(2)]
     for overlap in (0, 1):
         r0, r1 = res[overlap]
