@@ -133,24 +133,35 @@ def cpu_baseline():
     threads = _blas_threads()
     c2 = dict(V=V, H=H, B=B_PER_GPU, gauss=True, lr=LR, lambda_2=LAMBDA_2)
     c1 = dict(V=784, H=500, B=20, gauss=False, lr=0.1, weightcost=2e-4, momentum=0.6)
-    done, dt = _time_oracle_steps(c2, 10.0, 5)
-    out = {"value": done * B_PER_GPU / dt, "unit": "samples/s", "cores": int(threads), "kind": "port",
-           "steps_per_s": done / dt,
-           "sample": "%d CD-1 steps of the same GRBM 4096->1024, B=512, numpy float32 oracle "
-                     "(BLAS threads=%d, host cpus=%d), injected uniforms" % (done, threads, os.cpu_count() or 0)}
-    d1, t1 = _time_oracle_steps(c1, 3.0, 20)
-    out["c1_rbm_784_500_b20"] = {"steps_per_s": d1 / t1, "samples_per_s": 20 * d1 / t1, "cores": int(threads), "steps": d1}
+    runs = {}
+    done, dt = _time_oracle_steps(c2, 6.0, 5)
+    runs[int(threads)] = (done, dt)
+    d1, t1 = _time_oracle_steps(c1, 2.0, 20)
+    c1_runs = {int(threads): (d1, t1)}
     try:
+        # more BLAS threads are not always faster on a many-core host: also time 16 threads and one
+        # core, and quote the FASTEST as the baseline (cores = the threads it used)
         from threadpoolctl import threadpool_limits
-        with threadpool_limits(limits=1):
-            ds, ts = _time_oracle_steps(c2, 6.0, 2)
-            d1s, t1s = _time_oracle_steps(c1, 3.0, 20)
-        out["single_core"] = {"value": ds * B_PER_GPU / ts, "unit": "samples/s", "steps_per_s": ds / ts, "cores": 1,
-                              "steps": ds}
-        out["c1_rbm_784_500_b20_single_core"] = {"steps_per_s": d1s / t1s, "samples_per_s": 20 * d1s / t1s,
-                                                 "cores": 1, "steps": d1s}
-    except Exception as exc:                       # threadpoolctl missing: say so instead of guessing
-        out["single_core"] = {"error": repr(exc)}
+        for n in (16, 1):
+            if n < threads:
+                with threadpool_limits(limits=n):
+                    runs[n] = _time_oracle_steps(c2, 6.0, 3)
+                    c1_runs[n] = _time_oracle_steps(c1, 2.0, 20)
+    except Exception:                               # threadpoolctl missing: all-thread figures only
+        pass
+    best = max(runs, key=lambda n: runs[n][0] / runs[n][1])
+    done, dt = runs[best]
+    out = {"value": done * B_PER_GPU / dt, "unit": "samples/s", "cores": int(best), "kind": "port",
+           "steps_per_s": done / dt,
+           "sample": "%d CD-1 steps of the same GRBM 4096->1024, B=512, numpy float32 oracle, injected uniforms; fastest of "
+                     "BLAS thread counts %s on a host with %d cpus" % (done, sorted(runs), os.cpu_count() or 0),
+           "by_threads": {str(n): {"steps_per_s": d / t, "samples_per_s": d * B_PER_GPU / t, "steps": d}
+                          for n, (d, t) in sorted(runs.items())},
+           "single_core": ({"value": runs[1][0] * B_PER_GPU / runs[1][1], "unit": "samples/s", "cores": 1,
+                            "steps_per_s": runs[1][0] / runs[1][1]} if 1 in runs else None),
+           # BASELINE configs[0], the reference's own CPU-runnable shape: RBM 784->500, CD-1, batch 20
+           "c1_rbm_784_500_b20": {str(n): {"steps_per_s": d / t, "samples_per_s": 20 * d / t, "steps": d}
+                                  for n, (d, t) in sorted(c1_runs.items())}}
     return out
 
 

@@ -1,0 +1,279 @@
+// Experiment (not product): GEMM on pre-split bf16 planes.  Operands live in HBM as three bf16 planes
+// per f32 matrix (x = p1 + p2 + p3 exactly); the kernel only COPIES them into LDS (LDS-DMA,
+// global_load_lds_dwordx4) and issues the six piece products on v_mfma_f32_32x32x16_bf16.
+//   ROW operand: planes [rows][ld], k contiguous  -> LDS image [128 rows][32 k], read by ds_read_b128
+//   COL operand: planes [k][ld], rows contiguous  -> LDS image [32 k][128 rows], read by ds_read_b64_tr_b16
+// 128x128 tile, 32-deep stages, 3-stage LDS ring (144 KB), 4 MFMA waves + LW loader waves.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+enum { ROW = 0, COL = 1 };
+constexpr int PLANE = 8192, STAGE = 6 * PLANE, NSTAGE = 3;
+
+struct PArgs {
+    const unsigned short* A; int64_t lda, pa;       // plane stride in elements
+    const unsigned short* B; int64_t ldb, pb;
+    float* C; int64_t ldc, slab_stride;
+    int M, N, K, kchunk, splitk, tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void glds16(const void* g, unsigned lds_off, char* smem)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
+}
+
+// One loader wave's share of the staging: instructions q = w, w + LW, ... of the NQ = 8 * (AP + 3) per stage.
+template <int LA, int LB, int AP, int LW>
+__device__ __forceinline__ void loader(const PArgs& g, char* smem, int w, int lane, int m0, int n0, int kbeg, int nt)
+{
+    constexpr int NQ = 8 * (AP + 3), PER = NQ / LW;
+    const char* src[PER];
+    unsigned dst[PER];
+    int64_t step[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int q = w + j * LW;
+        const bool isA = q < 8 * AP;
+        const int plane = isA ? q / 8 : (q - 8 * AP) / 8, sub = q & 7;
+        const int lay = isA ? LA : LB;
+        const unsigned short* base = isA ? g.A + plane * g.pa : g.B + plane * g.pb;
+        const int64_t ld = isA ? g.lda : g.ldb;
+        const int mn0 = isA ? m0 : n0;
+        dst[j] = (isA ? plane : 3 + plane) * PLANE + sub * 1024;
+        if (lay == ROW) {       // 16 rows x 64 B per instruction; phys chunk = c ^ ((row >> 2) & 3)
+            const int row = 16 * sub + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            src[j] = reinterpret_cast<const char*>(base + (int64_t)(mn0 + row) * ld + kbeg + 8 * c);
+            step[j] = 64;
+        } else {                // 4 k-rows x 256 B per instruction; phys chunk = ch ^ ((k & 3) << 2)
+            const int k = 4 * sub + (lane >> 4);
+            const int ch = (lane & 15) ^ ((k & 3) << 2);
+            src[j] = reinterpret_cast<const char*>(base + (int64_t)(kbeg + k) * ld + mn0 + 8 * ch);
+            step[j] = 64 * ld;
+        }
+    }
+#define ISSUE(T)                                                                              \
+    do {                                                                                      \
+        const unsigned so = ((T) % NSTAGE) * STAGE;                                           \
+        _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                     \
+            glds16(src[j], so + dst[j], smem);                                                \
+            src[j] += step[j];                                                                \
+        }                                                                                     \
+    } while (0)
+    ISSUE(0);
+    if (nt > 1) { ISSUE(1); }
+    if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < nt; ++it) {
+        if (it + 2 < nt) {
+            ISSUE(it + 2);
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");     // stage it + 1 has landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+#undef ISSUE
+}
+
+template <int LAY>
+__device__ __forceinline__ bf16x8 frag(const char* plane, int off0, int off1)
+{
+    if constexpr (LAY == ROW) {
+        return *reinterpret_cast<const bf16x8*>(plane + off0);
+    } else {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off1));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <int LA, int LB, int AP, int LW>
+__global__ __launch_bounds__(64 * (4 + LW)) void planes_gemm_kernel(PArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int qq = nwg >> 3, rem = nwg & 7;
+    const int w = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + slot;
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int ks = w / tiles, t = w - ks * tiles;
+    int tm, tn;
+    if (g.tiles_m <= g.tiles_n) { tn = t / g.tiles_m; tm = t - tn * g.tiles_m; }
+    else { tm = t / g.tiles_n; tn = t - tm * g.tiles_n; }
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int kbeg = ks * g.kchunk;
+    const int nt = g.kchunk / 32;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+
+    if (wave >= 4) {
+        loader<LA, LB, AP, LW>(g, smem, wave - 4, lane, m0, n0, kbeg, nt);
+        return;
+    }
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    // fragment byte offsets inside a plane image, [32-row block][k16 step][first / second half (COL only)]
+    int offA[2][2][2], offB[2][2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            {
+                const int row = wm + 32 * b + r;
+                if (LA == ROW) {
+                    offA[b][s][0] = row * 64 + ((((2 * s + h) ^ ((row >> 2) & 3))) << 4);
+                    offA[b][s][1] = 0;
+                } else {
+                    const int gq = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
+                    const int ch = (wm + 32 * b) / 8 + 2 * gq + (p >> 1);
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int k = 16 * s + 8 * h + 4 * tt + q;
+                        offA[b][s][tt] = k * 256 + ((ch ^ (q << 2)) << 4) + 8 * (p & 1);
+                    }
+                }
+            }
+            {
+                const int row = wn + 32 * b + r;
+                if (LB == ROW) {
+                    offB[b][s][0] = row * 64 + ((((2 * s + h) ^ ((row >> 2) & 3))) << 4);
+                    offB[b][s][1] = 0;
+                } else {
+                    const int gq = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
+                    const int ch = (wn + 32 * b) / 8 + 2 * gq + (p >> 1);
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int k = 16 * s + 8 * h + 4 * tt + q;
+                        offB[b][s][tt] = k * 256 + ((ch ^ (q << 2)) << 4) + 8 * (p & 1);
+                    }
+                }
+            }
+        }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    bf16x8 f0a[3][2], f0b[3][2], f1a[3][2], f1b[3][2];
+#define FRAGS(FA, FB, BASE, S)                                                                \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                          \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                       \
+            if (pl < AP) FA[pl][a] = frag<LA>((BASE) + pl * PLANE, offA[a][S][0], offA[a][S][1]); \
+            FB[pl][a] = frag<LB>((BASE) + (3 + pl) * PLANE, offB[a][S][0], offB[a][S][1]);     \
+        }
+#define MMA(FA, FB)                                                                           \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                             \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                       \
+            if constexpr (AP == 3) {                                                          \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[2][a], FB[0][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[2][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][a], FB[1][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][a], FB[0][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[1][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[0][b], acc[a][b], 0, 0, 0); \
+            } else {                                                                          \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[2][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[1][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[0][b], acc[a][b], 0, 0, 0); \
+            }                                                                                 \
+        }
+    __syncthreads();                                 // stage 0 landed
+    FRAGS(f0a, f0b, smem, 0);
+    for (int it = 0; it < nt; ++it) {
+        const char* base = smem + (it % NSTAGE) * STAGE;
+        const char* next = smem + ((it + 1) % NSTAGE) * STAGE;
+        FRAGS(f1a, f1b, base, 1);
+        MMA(f0a, f0b);
+        __syncthreads();                             // all reads of stage `it` done; stage it + 1 landed
+        FRAGS(f0a, f0b, next, 0);
+        MMA(f1a, f1b);
+    }
+#undef FRAGS
+#undef MMA
+    float* C = g.C + (int64_t)ks * g.slab_stride;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + wn + 32 * b + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h;
+                C[(int64_t)row * g.ldc + col] = acc[a][b][e];
+            }
+        }
+}
+
+// exact 3-way truncation split of an f32 matrix into bf16 planes (same layout, same ld)
+__global__ void split_kernel(const float* __restrict__ X, int64_t n, unsigned short* __restrict__ P, int64_t plane)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const f32x4n v = *reinterpret_cast<const f32x4n*>(X + i);
+    unsigned short o[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = v[j];
+        const unsigned ua = __builtin_bit_cast(unsigned, a);
+        const float ra = a - __builtin_bit_cast(float, ua & 0xffff0000u);
+        const unsigned va = __builtin_bit_cast(unsigned, ra);
+        const float sa = ra - __builtin_bit_cast(float, va & 0xffff0000u);
+        o[0][j] = ua >> 16; o[1][j] = va >> 16; o[2][j] = __builtin_bit_cast(unsigned, sa) >> 16;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        uint2 w;
+        w.x = o[p][0] | ((unsigned)o[p][1] << 16);
+        w.y = o[p][2] | ((unsigned)o[p][3] << 16);
+        *reinterpret_cast<uint2*>(P + p * plane + i) = w;
+    }
+}
+
+template <int LA, int LB, int AP, int LW>
+static int launch(const PArgs& g, hipStream_t s)
+{
+    auto kern = planes_gemm_kernel<LA, LB, AP, LW>;
+    static bool attr = false;
+    constexpr int lds = NSTAGE * STAGE;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return -2;
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n * g.splitk), dim3(64 * (4 + LW)), lds, s, g);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+extern "C" int exp_split(const float* X, int64_t rows, int64_t ld, unsigned short* P, void* stream)
+{
+    const int64_t n = rows * ld;
+    hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, n, P, n);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int exp_gemm(int la, int lb, int ap, int lw, const unsigned short* A, int64_t lda, int64_t pa,
+                        const unsigned short* B, int64_t ldb, int64_t pb, float* C, int64_t ldc, int64_t slab_stride,
+                        int M, int N, int K, int splitk, void* stream)
+{
+    if (M % 128 || N % 128 || K % (32 * splitk)) return -1;
+    PArgs g{A, lda, pa, B, ldb, pb, C, ldc, slab_stride, M, N, K, K / splitk, splitk, M / 128, N / 128};
+    hipStream_t s = (hipStream_t)stream;
+#define CASE(LAV, LBV, APV, LWV) if (la == LAV && lb == LBV && ap == APV && lw == LWV) return launch<LAV, LBV, APV, LWV>(g, s)
+    CASE(ROW, COL, 3, 4); CASE(ROW, COL, 3, 8); CASE(ROW, COL, 1, 4); CASE(ROW, COL, 1, 8);
+    CASE(ROW, ROW, 3, 4); CASE(ROW, ROW, 3, 8); CASE(ROW, ROW, 1, 4); CASE(ROW, ROW, 1, 8);
+    CASE(COL, COL, 3, 4); CASE(COL, COL, 3, 8);
+#undef CASE
+    return -4;
+}

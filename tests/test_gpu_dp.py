@@ -73,7 +73,9 @@ def test_two_ranks_equal_one_process_on_device(built_lib, shape):
         r0, r1 = res[overlap]
         for k in single:
             assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
-            tol = 2e-6 * max(1.0, np.abs(single[k]).max())
+            # two K-halves summed by the all-reduce instead of one K-long fp32 chain: rounding of order
+            # eps * sqrt(K) on values of the statistics' magnitude
+            tol = (2e-6 if shape == "small" else 5e-6) * max(1.0, np.abs(single[k]).max())
             assert np.abs(r0[k] - single[k]).max() <= tol, (k, np.abs(r0[k] - single[k]).max())
     for k in single:                     # overlapped == synchronous, bit for bit
         assert np.array_equal(res[0][0][k], res[1][0][k]), k
