@@ -213,6 +213,24 @@ int  mdbn_free_energy(mdbn_ctx *ctx, void *stream, const float *x, int64_t N, in
                       const float *vbias, int gauss, float *out,
                       void *workspace, int64_t workspace_bytes);
 
+/* Pieces of get_pseudo_likelihood_cost (src/rbm.py:421-447): out = round(x) (tensor.round: half away from
+ * zero) with column flip_col replaced by 1 - round(x) (flip_col < 0: no flip); then, from the free energies of
+ * the two matrices, cost_out[0] = -mean(n_visible * softplus(fe - fe_flip)). */
+int  mdbn_round_flip(mdbn_ctx *ctx, void *stream, const float *x, int64_t rows, int64_t cols, int64_t ld,
+                     int64_t flip_col, float *out);
+int  mdbn_pl_cost(mdbn_ctx *ctx, void *stream, const float *fe, const float *fe_flip, int64_t rows,
+                  int64_t n_visible, float *cost_out);
+/* get_reconstruction_cost on given arrays: RBM src/rbm.py:449-482 (cross-entropy of sigmoid(pre) against
+ * target, summed over units, mean over rows), GRBM src/rbm.py:690-699 (mean of (sigmoid(pre) - target)^2). */
+int  mdbn_recon_cost(mdbn_ctx *ctx, void *stream, const float *pre, int64_t ld_pre, const float *target,
+                     int64_t ld_target, int64_t rows, int64_t cols, int gauss, float *cost_out,
+                     void *workspace, int64_t workspace_bytes);
+/* HiddenLayer's tanh activation (src/mlp.py:36-110 default), in place on the live columns */
+int  mdbn_tanh(mdbn_ctx *ctx, void *stream, float *x, int64_t rows, int64_t cols, int64_t ld);
+/* count[0] += number of NaN / Inf values in x[0..n): the check NanGuardMode would make (src/rbm.py:542-543,
+ * src/dbn.py:311); the caller zeroes count */
+int  mdbn_count_nonfinite(mdbn_ctx *ctx, void *stream, const float *x, int64_t n, int32_t *count);
+
 /* the random matrices themselves (tests, and sampling utilities) */
 int  mdbn_rng_uniform(mdbn_ctx *ctx, void *stream, float *out, int64_t rows, int64_t cols,
                       int64_t ld, const mdbn_rng *rng);

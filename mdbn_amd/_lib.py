@@ -71,6 +71,11 @@ SIGNATURES = {
     "mdbn_cd_train_step": [_vp, _vp, C.POINTER(CdArgs), C.POINTER(UpdateArgs)],
     "mdbn_free_energy": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i32, _vp,
                          _vp, _i64],
+    "mdbn_round_flip": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
+    "mdbn_pl_cost": [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
+    "mdbn_recon_cost": [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _i64],
+    "mdbn_tanh": [_vp, _vp, _vp, _i64, _i64, _i64],
+    "mdbn_count_nonfinite": [_vp, _vp, _vp, _i64, _vp],
     "mdbn_rng_uniform": [_vp, _vp, _vp, _i64, _i64, _i64, _rngp],
     "mdbn_rng_normal": [_vp, _vp, _vp, _i64, _i64, _i64, _rngp],
     "mdbn_philox_host": [_vp, _i64, _i64, _i64, _rngp],

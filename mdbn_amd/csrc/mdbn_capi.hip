@@ -977,6 +977,49 @@ int mdbn_free_energy(mdbn_ctx* ctx, void* stream, const float* x, int64_t N, int
     return MDBN_OK;
 }
 
+int mdbn_round_flip(mdbn_ctx* ctx, void* stream, const float* x, int64_t rows, int64_t cols, int64_t ld, int64_t flip_col,
+                    float* out)
+{
+    REQUIRE(ctx && x && out && rows >= 0 && cols > 0 && ld >= cols && flip_col < cols, "bad arguments");
+    HIP_OK(launch_round_flip(x, out, rows, cols, ld, flip_col, (hipStream_t)stream));
+    return MDBN_OK;
+}
+
+int mdbn_pl_cost(mdbn_ctx* ctx, void* stream, const float* fe, const float* fe_flip, int64_t rows, int64_t n_visible,
+                 float* cost_out)
+{
+    REQUIRE(ctx && fe && fe_flip && cost_out && rows > 0 && n_visible > 0, "bad arguments");
+    HIP_OK(launch_pl_cost(fe, fe_flip, rows, (float)n_visible, cost_out, (hipStream_t)stream));
+    return MDBN_OK;
+}
+
+int mdbn_recon_cost(mdbn_ctx* ctx, void* stream, const float* pre, int64_t ld_pre, const float* target, int64_t ld_target,
+                    int64_t rows, int64_t cols, int gauss, float* cost_out, void* workspace, int64_t workspace_bytes)
+{
+    REQUIRE(ctx && pre && target && cost_out && rows > 0 && cols > 0 && ld_pre >= cols && ld_target >= cols, "bad arguments");
+    REQUIRE(workspace != nullptr && workspace_bytes >= 4096, "workspace of >= 4096 bytes needed");
+    const int nb = (int)std::min<int64_t>(std::min<int64_t>(1024, workspace_bytes / 4), (rows * cols + 255) / 256);
+    // rbm.py:479-480: sum over units, mean over rows; rbm.py:697: mean over everything
+    const float scale = gauss ? 1.0f / ((float)rows * (float)cols) : 1.0f / (float)rows;
+    HIP_OK(launch_recon_cost(pre, ld_pre, target, ld_target, rows, cols, gauss, scale, reinterpret_cast<float*>(workspace), nb,
+                             cost_out, (hipStream_t)stream));
+    return MDBN_OK;
+}
+
+int mdbn_tanh(mdbn_ctx* ctx, void* stream, float* x, int64_t rows, int64_t cols, int64_t ld)
+{
+    REQUIRE(ctx && x && rows >= 0 && cols > 0 && ld >= cols, "bad arguments");
+    HIP_OK(launch_tanh(x, rows, cols, ld, (hipStream_t)stream));
+    return MDBN_OK;
+}
+
+int mdbn_count_nonfinite(mdbn_ctx* ctx, void* stream, const float* x, int64_t n, int32_t* count)
+{
+    REQUIRE(ctx && x && count && n >= 0, "bad arguments");
+    HIP_OK(launch_count_nonfinite(x, n, count, (hipStream_t)stream));
+    return MDBN_OK;
+}
+
 int mdbn_rng_uniform(mdbn_ctx* ctx, void* stream, float* out, int64_t rows, int64_t cols, int64_t ld,
                      const mdbn_rng* rng)
 {

@@ -113,6 +113,12 @@ hipError_t launch_update(const mdbn_update_args& a, hipStream_t s, const float* 
 hipError_t launch_free_energy(const float* slabs, int nsplit, int64_t slab_stride, int64_t ldh, int H,
                               const float* hbias, const float* x, int64_t ldv, int V, const float* vbias,
                               int gauss, int64_t rows, float* out, hipStream_t s);
+hipError_t launch_round_flip(const float* x, float* out, int64_t rows, int64_t cols, int64_t ld, int64_t flip_col, hipStream_t s);
+hipError_t launch_pl_cost(const float* fe, const float* fe_flip, int64_t rows, float n_visible, float* out, hipStream_t s);
+hipError_t launch_recon_cost(const float* pre, int64_t ldp, const float* tgt, int64_t ldt, int64_t rows, int64_t cols, int gauss,
+                             float scale, float* partials, int n_partials, float* out, hipStream_t s);
+hipError_t launch_tanh(float* x, int64_t rows, int64_t cols, int64_t ld, hipStream_t s);
+hipError_t launch_count_nonfinite(const float* x, int64_t n, int* count, hipStream_t s);
 hipError_t launch_rng_fill(float* out, int64_t rows, int64_t cols, int64_t ld, const PhiloxKey& k,
                            int normal, hipStream_t s);
 

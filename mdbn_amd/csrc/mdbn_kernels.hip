@@ -1957,4 +1957,122 @@ hipError_t launch_rng_fill(float* out, int64_t rows, int64_t cols, int64_t ld, c
     return hipGetLastError();
 }
 
+
+// ----------------------------------------------------------------------------------
+// small elementwise / reduction kernels around the path (monitoring and host-side helpers that were
+// torch expressions before): pseudo-likelihood pieces (rbm.py:421-447), reconstruction cost of given
+// arrays (rbm.py:449-482, :690-699), tanh for HiddenLayer (mlp.py:103-107), finite check (the role of
+// NanGuardMode, rbm.py:542-543).
+// ----------------------------------------------------------------------------------
+// xi = tensor.round(x) (round half away from zero); flip_col >= 0: that column becomes 1 - xi
+__global__ __launch_bounds__(256) void round_flip_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                         int64_t cols, int64_t ld, int64_t flip_col)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * ld) return;
+    const int64_t c = i % ld;
+    float v = 0.f;
+    if (c < cols) {
+        const float a = x[i];
+        v = copysignf(floorf(fabsf(a) + 0.5f), a);
+        if (c == flip_col) v = 1.0f - v;
+    }
+    out[i] = v;
+}
+
+hipError_t launch_round_flip(const float* x, float* out, int64_t rows, int64_t cols, int64_t ld, int64_t flip_col, hipStream_t s)
+{
+    const int64_t n = rows * ld;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(round_flip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, rows, cols, ld, flip_col);
+    return hipGetLastError();
+}
+
+// out[0] = -mean_r( n_visible * softplus(F(xi)_r - F(xi_flip)_r) )   (rbm.py:442); one block, fixed order
+__global__ __launch_bounds__(256) void pl_cost_kernel(const float* __restrict__ fe, const float* __restrict__ fe_flip,
+                                                      int64_t rows, float n_visible, float* __restrict__ out)
+{
+    __shared__ float red[8];
+    float a = 0.f;
+    for (int64_t r = threadIdx.x; r < rows; r += blockDim.x) a += softplusf_(fe[r] - fe_flip[r]);
+    const float tot = block_sum(a, red);
+    if (threadIdx.x == 0) out[0] = -(n_visible * tot) / (float)rows;
+}
+
+hipError_t launch_pl_cost(const float* fe, const float* fe_flip, int64_t rows, float n_visible, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(pl_cost_kernel, dim3(1), dim3(256), 0, s, fe, fe_flip, rows, n_visible, out);
+    return hipGetLastError();
+}
+
+// reconstruction cost of given arrays: partial sums per block of BCE(sigmoid(pre), t) (gauss = 0) or
+// (sigmoid(pre) - t)^2 (gauss = 1) over the live columns; summed by finalize (fixed order)
+__global__ __launch_bounds__(256) void recon_cost_kernel(const float* __restrict__ pre, int64_t ldp, const float* __restrict__ tgt,
+                                                         int64_t ldt, int64_t rows, int64_t cols, int gauss,
+                                                         float* __restrict__ partials)
+{
+    __shared__ float red[8];
+    float a = 0.f;
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols, c = i - r * cols;
+        const float x = pre[r * ldp + c], t = tgt[r * ldt + c];
+        if (gauss) { const float d = sigmoidf_(x) - t; a += d * d; }
+        else a += t * softplusf_(-x) + (1.0f - t) * softplusf_(x);
+    }
+    const float tot = block_sum(a, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(64) void sum_partials_kernel(const float* __restrict__ partials, int n, float scale, float* __restrict__ out)
+{
+    float a = 0.f;
+    for (int k = threadIdx.x; k < n; k += 64) a += partials[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if (threadIdx.x == 0) out[0] = a * scale;
+}
+
+hipError_t launch_recon_cost(const float* pre, int64_t ldp, const float* tgt, int64_t ldt, int64_t rows, int64_t cols, int gauss,
+                             float scale, float* partials, int n_partials, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(recon_cost_kernel, dim3(n_partials), dim3(256), 0, s, pre, ldp, tgt, ldt, rows, cols, gauss, partials);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, partials, n_partials, scale, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void tanh_kernel(float* __restrict__ x, int64_t rows, int64_t cols, int64_t ld)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * ld) return;
+    if (i % ld < cols) x[i] = tanhf(x[i]);
+}
+
+hipError_t launch_tanh(float* x, int64_t rows, int64_t cols, int64_t ld, hipStream_t s)
+{
+    const int64_t n = rows * ld;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tanh_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, rows, cols, ld);
+    return hipGetLastError();
+}
+
+// count[0] += number of NaN / Inf entries of x[0..n)
+__global__ __launch_bounds__(256) void count_nonfinite_kernel(const float* __restrict__ x, int64_t n, int* __restrict__ count)
+{
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        bad += (__builtin_bit_cast(unsigned, x[i]) & 0x7f800000u) == 0x7f800000u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, bad);
+}
+
+hipError_t launch_count_nonfinite(const float* x, int64_t n, int* count, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(count_nonfinite_kernel, dim3(grid), dim3(256), 0, s, x, n, count);
+    return hipGetLastError();
+}
+
 }  // namespace mdbn

@@ -383,6 +383,51 @@ class HipEngine(object):
         _lib.check(self.lib.mdbn_apply_update(self.ctx, self._stream(), C.byref(u)), "mdbn_apply_update")
         return cost
 
+    # ------------------------------------------------------------------ monitoring helpers (all HIP)
+    def round_flip(self, x, flip_col=-1):
+        """tensor.round(x) with column ``flip_col`` replaced by 1 - round(x) (rbm.py:428-436)."""
+        x = self.as_matrix(x)
+        out = self.alloc_matrix(x.shape[0], x.shape[1], x.stride(0))
+        if x.shape[0]:
+            _lib.check(self.lib.mdbn_round_flip(self.ctx, self._stream(), self._p(x), x.shape[0], x.shape[1],
+                                                x.stride(0), int(flip_col), self._p(out)), "mdbn_round_flip")
+        return out
+
+    def pl_cost(self, fe, fe_flip, n_visible):
+        """-mean(n_visible * softplus(fe - fe_flip)) (rbm.py:442) as a 0-d device tensor."""
+        out = torch.zeros(1, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mdbn_pl_cost(self.ctx, self._stream(), self._p(fe), self._p(fe_flip), fe.numel(),
+                                         int(n_visible), self._p(out)), "mdbn_pl_cost")
+        return out[0]
+
+    def recon_cost(self, pre, target, gauss):
+        """get_reconstruction_cost on given arrays (rbm.py:449-482, :690-699): 0-d device tensor."""
+        pre, target = self.as_matrix(pre), self.as_matrix(target)
+        assert pre.shape == target.shape
+        out = torch.zeros(1, dtype=torch.float32, device=self.device)
+        ws = self.workspace(1, 1, 1)
+        _lib.check(self.lib.mdbn_recon_cost(self.ctx, self._stream(), self._p(pre), pre.stride(0), self._p(target),
+                                            target.stride(0), pre.shape[0], pre.shape[1], int(bool(gauss)),
+                                            self._p(out), self._p(ws), ws.numel() * 4), "mdbn_recon_cost")
+        return out[0]
+
+    def tanh_(self, x):
+        """In-place tanh on a device matrix (HiddenLayer's default activation, mlp.py:36-110)."""
+        x = self.as_matrix(x)
+        _lib.check(self.lib.mdbn_tanh(self.ctx, self._stream(), self._p(x), x.shape[0], x.shape[1], x.stride(0)),
+                   "mdbn_tanh")
+        return x
+
+    def count_nonfinite(self, *tensors):
+        """Number of NaN / Inf values in the given device tensors (synchronises): the check the
+        reference's commented-out NanGuardMode would make (rbm.py:542-543, dbn.py:311)."""
+        count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        for t in tensors:
+            base = t._base if t._base is not None else t           # a padded matrix: scan the whole storage
+            _lib.check(self.lib.mdbn_count_nonfinite(self.ctx, self._stream(), self._p(base), base.numel(),
+                                                     self._p(count)), "mdbn_count_nonfinite")
+        return int(count.item())
+
     # ------------------------------------------------------------------ RNG (tests / utilities)
     def rng_uniform(self, rows, cols, rng, normal=False):
         out = self.alloc_matrix(rows, cols)

@@ -61,4 +61,8 @@ class HiddenLayer(object):
             return mean
         pre, _, _ = self.engine.propup(x, self.W.tensor, self.b.tensor,
                                        want_mean=False, want_sample=False)
-        return pre if self.activation is None else self.engine.as_matrix(self.activation(pre))
+        if self.activation is None:
+            return pre
+        if self.activation is tanh:
+            return self.engine.tanh_(pre)
+        return self.engine.as_matrix(self.activation(pre))      # a caller-supplied torch callable

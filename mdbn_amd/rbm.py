@@ -110,6 +110,9 @@ class StepFunction(object):
         # update reads them a whole call later, so another step function of the same shape (two
         # equal-sized modalities, alternating layers) must not share them
         self._stats_slots = [None, None]
+        # nan_guard: check cost and parameters for NaN / Inf after every call (synchronises; what the
+        # reference's commented-out NanGuardMode would do, rbm.py:542-543, dbn.py:311)
+        self.nan_guard = bool(getattr(self.engine, "nan_guard", False))
         if self.group is not None and self.group.world_size > 1 and hasattr(self.engine, "set_option"):
             # RCCL's all-reduce kernels run beside the next step's GEMMs.  A GEMM block with two MFMA
             # waves per SIMD fills the CU's register file (3 x 168 VGPRs per SIMD), so a collective
@@ -192,6 +195,8 @@ class StepFunction(object):
                                     lr, p.lambda_1, p.lambda_2, p.weightcost, momentum, batch_size,
                                     n_global, cost_scale, sample_stats=p.symbolic_grad)
             rbm._n_updates += 1
+            if self.nan_guard:
+                self._check_finite(out)
             return out
         slot = self._n_calls & 1 if self.overlap else 0     # the other buffer may still be reducing
         self._n_calls += 1
@@ -243,7 +248,18 @@ class StepFunction(object):
         out = eng.apply_update(*args, stats, lr, p.lambda_1, p.lambda_2, p.weightcost, momentum,
                                batch_size, n_global, cost_scale, ldv=data.stride(0))
         rbm._n_updates += 1
+        if self.nan_guard:
+            self._check_finite(cost if cost is not None else out)
         return cost if cost is not None else out
+
+    def _check_finite(self, cost):
+        rbm = self.rbm
+        c = float(cost)
+        bad = self.engine.count_nonfinite(rbm.W.tensor, rbm.W_speed.tensor, rbm.hbias.tensor, rbm.vbias.tensor) \
+            if hasattr(self.engine, "count_nonfinite") else 0
+        if bad or not numpy.isfinite(c):
+            raise FloatingPointError("step %d of %s: cost = %r, %d non-finite parameter / speed values (learning rate "
+                                     "too large for this data?)" % (rbm._n_updates, self.name or "step function", c, bad))
 
 
 def function(updates, train_set_x=None, input_fn=None, name=None, data_parallel="auto", overlap=True):
@@ -419,14 +435,12 @@ class RBM(object):
 
     def _pseudo_likelihood_value(self, x):
         """rbm.py:421-447 on the current minibatch; advances bit_i_idx (rbm.py:445)."""
-        xi = torch.sign(x) * torch.floor(torch.abs(x) + 0.5)          # tensor.round, SURVEY 8c
-        xi = self.engine.as_matrix(xi)
-        fe_xi = self.engine.free_energy(xi, self.W.tensor, self.hbias.tensor, self.vbias.tensor, self.gauss)
-        xi_flip = xi.clone()
-        xi_flip[:, self.bit_i_idx] = 1 - xi[:, self.bit_i_idx]
-        fe_flip = self.engine.free_energy(self.engine.as_matrix(xi_flip), self.W.tensor, self.hbias.tensor,
-                                          self.vbias.tensor, self.gauss)
-        cost = -torch.mean(self.n_visible * torch.nn.functional.softplus(fe_xi - fe_flip))
+        eng = self.engine
+        xi = eng.round_flip(x)                                        # tensor.round (SURVEY 8c)
+        fe_xi = eng.free_energy(xi, self.W.tensor, self.hbias.tensor, self.vbias.tensor, self.gauss)
+        xi_flip = eng.round_flip(x, self.bit_i_idx)                   # bit i flipped (rbm.py:436)
+        fe_flip = eng.free_energy(xi_flip, self.W.tensor, self.hbias.tensor, self.vbias.tensor, self.gauss)
+        cost = eng.pl_cost(fe_xi, fe_flip, self.n_visible)            # rbm.py:442
         self.bit_i_idx = (self.bit_i_idx + 1) % self.n_visible
         return cost
 
@@ -437,10 +451,8 @@ class RBM(object):
     def get_reconstruction_cost(self, pre_sigmoid_nv, v0):
         """rbm.py:449-482 evaluated on given arrays (monitoring helper; the step function
         computes the same quantity fused into the last propdown)."""
-        x = as_tensor(pre_sigmoid_nv, self.engine)
-        t = as_tensor(v0, self.engine)
-        sp = torch.nn.functional.softplus
-        return float((t * sp(-x) + (1 - t) * sp(x)).sum(dim=1).mean())
+        return float(self.engine.recon_cost(as_tensor(pre_sigmoid_nv, self.engine), as_tensor(v0, self.engine),
+                                            gauss=False))
 
     # ------------------------------------------------------------------ stand-alone trainer
     def training(self, train_set_x, validation_set_x, training_epochs, batch_size=10,
@@ -540,9 +552,8 @@ class GRBM(RBM):
 
     def get_reconstruction_cost(self, pre_sigmoid_nv, v0):
         """mean((sigmoid(v1_mean) - v0)^2) over samples and features (rbm.py:690-699)."""
-        x = as_tensor(pre_sigmoid_nv, self.engine)
-        t = as_tensor(v0, self.engine)
-        return float(((torch.sigmoid(x) - t) ** 2).mean())
+        return float(self.engine.recon_cost(as_tensor(pre_sigmoid_nv, self.engine), as_tensor(v0, self.engine),
+                                            gauss=True))
 
     def training(self, train_set_x, validation_set_x, training_epochs, batch_size=10,
                  learning_rate=0.01, k=1, initial_momentum=0.0, final_momentum=0.0,

@@ -14,6 +14,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4n __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef ABL
+#define ABL 0   // diagnostic: 1 no DMA issued, 2 no MFMA (fragment reads kept alive), 3 no fragment reads, 4 consumers only pass barriers
+#endif
 enum { ROW = 0, COL = 1 };
 constexpr int PLANE = 8192, STAGE = 6 * PLANE, NSTAGE = 3;
 
@@ -64,7 +67,7 @@ __device__ __forceinline__ void loader(const PArgs& g, char* smem, int w, int la
     do {                                                                                      \
         const unsigned so = ((T) % NSTAGE) * STAGE;                                           \
         _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                     \
-            glds16(src[j], so + dst[j], smem);                                                \
+            if (ABL != 1) glds16(src[j], so + dst[j], smem);                                  \
             src[j] += step[j];                                                                \
         }                                                                                     \
     } while (0)
@@ -167,13 +170,22 @@ __global__ __launch_bounds__(64 * (4 + LW)) void planes_gemm_kernel(PArgs g)
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
     bf16x8 f0a[3][2], f0b[3][2], f1a[3][2], f1b[3][2];
+    if (ABL == 3 || ABL == 4) {
+        for (int pl = 0; pl < 3; ++pl) for (int a = 0; a < 2; ++a) {
+            const s16x8 z = {(short)lane, 1, 2, 3, 4, 5, 6, (short)pl};
+            f0a[pl][a] = f0b[pl][a] = f1a[pl][a] = f1b[pl][a] = __builtin_bit_cast(bf16x8, z);
+        }
+    }
 #define FRAGS(FA, FB, BASE, S)                                                                \
+    if (ABL != 3 && ABL != 4) {                                                               \
     _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                          \
         _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                       \
             if (pl < AP) FA[pl][a] = frag<LA>((BASE) + pl * PLANE, offA[a][S][0], offA[a][S][1]); \
             FB[pl][a] = frag<LB>((BASE) + (3 + pl) * PLANE, offB[a][S][0], offB[a][S][1]);     \
-        }
+            if (ABL == 2) { if (pl < AP) asm volatile("" :: "v"(FA[pl][a])); asm volatile("" :: "v"(FB[pl][a])); } \
+        } }
 #define MMA(FA, FB)                                                                           \
+    if (ABL != 2 && ABL != 4)                                                                 \
     _Pragma("unroll") for (int a = 0; a < 2; ++a)                                             \
         _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                       \
             if constexpr (AP == 3) {                                                          \

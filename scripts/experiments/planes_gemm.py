@@ -10,16 +10,17 @@ here = os.path.dirname(os.path.abspath(__file__))
 so = os.path.join(ROOT, "scripts", "libplanes_exp.so")
 
 
-def build():
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-                           os.path.join(here, "planes_gemm.hip"), "-o", so])
+def build(flags=(), out=so):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"] + list(flags) +
+                          [os.path.join(here, "planes_gemm.hip"), "-o", out])
+    return out
 
 
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     build()
     sys.exit(0)
-if not os.path.exists(so):
-    build()
+ABLATE = len(sys.argv) > 1 and sys.argv[1] == "ablate"
+build()
 
 import numpy as np, torch
 import mdbn_amd
@@ -100,5 +101,24 @@ for name, M, N, K, la, lb, ap, sk in cases:
         row = {"case": name + "_engine_bf16x6", "us": round(ms * 1e3 / max(n, 1), 2),
                "bitwise_equal_to_planes": bool(torch.equal(pre[:, :N].double(), got))}
         res.append(row); print(json.dumps(row), flush=True)
+if ABLATE:
+    # where does a stage's time go?  diagnostic builds (wrong results): 1 no DMA, 2 no MFMA, 3 no fragment reads, 4 barriers only
+    names = {0: "full", 1: "no_dma", 2: "no_mfma", 3: "no_frag_reads", 4: "consumers_idle"}
+    libs = {}
+    for abl in names:
+        libs[abl] = C.CDLL(build(["-DABL=%d" % abl], so.replace(".so", "_abl%d.so" % abl)))
+        libs[abl].exp_gemm.argtypes = lib.exp_gemm.argtypes
+    for name, M, N, K, la, lb, ap, sk in cases:
+        A = torch.randn((M, K) if la == ROW else (K, M)).to(dev)
+        B = (0.05 * torch.randn((N, K) if lb == ROW else (K, N))).to(dev)
+        Ap, Bp = split(A), split(B)
+        Cs = torch.zeros((sk, M, N), device=dev)
+        for lw in (4, 8):
+            row = {"case": name, "lw": lw, "stages_per_job": K // sk // 32}
+            for abl, nm in names.items():
+                f = lambda: libs[abl].exp_gemm(la, lb, ap, lw, Ap.data_ptr(), A.shape[1], A.numel(), Bp.data_ptr(), B.shape[1],
+                                               B.numel(), Cs.data_ptr(), N, M * N, M, N, K, sk, stream())
+                row[nm + "_us"] = round(timeit(f), 2)
+            res.append(row); print(json.dumps(row), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "planes_gemm.json"), "w"), indent=1)

@@ -174,6 +174,27 @@ class OracleEngine(object):
         return self.apply_update(W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats, lr, lambda_1,
                                  lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale)
 
+    def round_flip(self, x, flip_col=-1):
+        x = self.as_matrix(x).numpy()
+        xi = np.sign(x) * np.floor(np.abs(x) + 0.5)
+        if flip_col >= 0:
+            xi[:, flip_col] = 1 - xi[:, flip_col]
+        return self._t(xi)
+
+    def pl_cost(self, fe, fe_flip, n_visible):
+        return torch.tensor(-np.mean(n_visible * rbm_np.softplus(fe.numpy() - fe_flip.numpy())), dtype=self.t_dtype)
+
+    def recon_cost(self, pre, target, gauss):
+        s = rbm_np.RBMState(1, 1, dtype=self.np_dtype, gauss=gauss)
+        return torch.tensor(rbm_np.reconstruction_cost(s, self.as_matrix(pre).numpy(), self.as_matrix(target).numpy()),
+                            dtype=self.t_dtype)
+
+    def tanh_(self, x):
+        return x.tanh_()
+
+    def count_nonfinite(self, *tensors):
+        return int(sum((~torch.isfinite(t)).sum().item() for t in tensors))
+
     def rng_uniform(self, rows, cols, rng, normal_=False):
         f = normal if normal_ else uniform
         return torch.from_numpy(f(rows, cols, rng.seed, rng.stream_id, rng.step, rng.draw, rng.row_offset))

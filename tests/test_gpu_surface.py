@@ -233,3 +233,62 @@ def test_hundred_step_drift_teacher_forced(shadow, V, H, B, gauss, hp):
     F = rbm.free_energy(data[:B]).get_value()
     F_o = rbm_np.free_energy(st, data[:B].astype(np.float64))
     assert np.abs(F - F_o).max() <= 1e-4 * np.abs(F_o).max()            # the north star's parity quantity
+
+
+@pytest.mark.parametrize("gauss", [False, True])
+def test_monitoring_costs_on_device(hip_engine, gauss):
+    """get_reconstruction_cost (rbm.py:449-482, :690-699) and get_pseudo_likelihood_cost (rbm.py:421-447) as HIP
+    kernels against the oracle, including the rotating bit index and tensor.round's half-away-from-zero."""
+    import mdbn_amd
+    V, H, B = 130, 70, 37
+    rs = np.random.RandomState(5)
+    cls = mdbn_amd.GRBM if gauss else mdbn_amd.RBM
+    rbm = cls(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(9), engine=hip_engine)
+    rbm.hbias.set_value(rs.normal(0, 0.3, H).astype(np.float32))
+    rbm.vbias.set_value(rs.normal(0, 0.3, V).astype(np.float32))
+    st = rbm_np.RBMState(V, H, W=rbm.W.get_value(), hbias=rbm.hbias.get_value(), vbias=rbm.vbias.get_value(), gauss=gauss)
+    pre = rs.normal(0, 2, (B, V)).astype(np.float32)
+    v0 = rs.normal(size=(B, V)).astype(np.float32) if gauss else (rs.uniform(size=(B, V)) < 0.3).astype(np.float32)
+    got = rbm.get_reconstruction_cost(pre, v0)
+    want = rbm_np.reconstruction_cost(st, pre.astype(np.float64), v0.astype(np.float64))
+    assert abs(got - want) <= 2e-6 * abs(want)
+    x = (rs.randint(0, 7, (B, V)) / 4.0 - 0.5).astype(np.float32)        # quarters: exercises x.5 -> away from zero
+    for step in range(3):
+        st.bit_i_idx = rbm.bit_i_idx
+        got = rbm.get_pseudo_likelihood_cost(x)
+        want = rbm_np.pseudo_likelihood_cost(st, x.astype(np.float64))
+        assert abs(got - want) <= 1e-4 * abs(want) + 1e-6
+    assert rbm.bit_i_idx == 3
+
+
+def test_tanh_hidden_layer_and_finite_check(hip_engine):
+    import mdbn_amd
+    from mdbn_amd import mlp
+    rs = np.random.RandomState(0)
+    layer = mdbn_amd.HiddenLayer(rng=np.random.RandomState(1), input=None, n_in=37, n_out=21, activation=mlp.tanh,
+                                 engine=hip_engine)
+    x = rs.normal(size=(9, 37)).astype(np.float32)
+    out = layer.forward(x)
+    want = np.tanh(x.astype(np.float64) @ layer.W.get_value().astype(np.float64) + layer.b.get_value())
+    assert np.abs(out.cpu().numpy() - want).max() <= 2e-6
+    assert not out._base[:, 21:].any()                              # pad columns stay zero
+    t = hip_engine.alloc_matrix(5, 6)
+    assert hip_engine.count_nonfinite(t) == 0
+    t[2, 3] = float("nan"); t[4, 0] = float("inf"); t[0, 5] = -float("inf")
+    assert hip_engine.count_nonfinite(t) == 3
+
+
+def test_nan_guard_raises_on_divergence(hip_engine):
+    """The c2 hyper-parameters of MDBN.py:49 (lr 0.005) diverge on N(0,1) data of this width; with nan_guard the
+    step function says so instead of training on NaNs (NanGuardMode's role, rbm.py:542-543)."""
+    import mdbn_amd
+    V, H, B = 1024, 256, 128
+    rs = np.random.RandomState(0)
+    data = (40 * rs.normal(size=(4 * B, V))).astype(np.float32)
+    rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123), engine=hip_engine)
+    _, up = rbm.get_cost_updates(lr=0.5, k=1, lambda_2=0.0, batch_size=B)
+    fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=hip_engine), data_parallel=None)
+    fn.nan_guard = True
+    with pytest.raises(FloatingPointError):
+        for t in range(200):
+            fn(indexes=np.arange(B) + B * (t % 4), momentum=0.0)

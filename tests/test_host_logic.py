@@ -265,3 +265,16 @@ def test_symbolic_grad_step(oracle_engine, cls):
     np.testing.assert_allclose(rbm.W.tensor.numpy(), st.W, rtol=1e-12)
     np.testing.assert_allclose(rbm.W_speed.tensor.numpy(), st.W_speed, rtol=1e-11, atol=1e-14)
     np.testing.assert_allclose(rbm.vbias_speed.tensor.numpy(), st.vbias_speed, rtol=1e-11, atol=1e-14)
+
+
+def test_nan_guard_on_checker_engine(oracle_engine):
+    V, H, B = 12, 7, 8
+    rs = np.random.RandomState(0)
+    data = 50 * rs.normal(size=(32, V))
+    rbm = GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(5))
+    _, up = rbm.get_cost_updates(lr=5.0, k=1, lambda_2=0.0, batch_size=B)
+    fn = function(up, shared(data))
+    fn.nan_guard = True
+    with np.errstate(all="ignore"), pytest.raises(FloatingPointError):
+        for t in range(1000):                # |W| grows ~4x per step: float64 overflows after ~450
+            fn(indexes=np.arange(B) + B * (t % 4), momentum=0.0)
