@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include "philox.h"
 #include "mdbn_kernels.h"
+#include "mdbn_device.h"
 
 namespace mdbn {
 
@@ -138,145 +139,6 @@ __device__ __forceinline__ float frag(const float* __restrict__ T, int mn, int k
 #endif
 }
 
-// ----------------------------------------------------------------------------------
-// float4 component access and the parameter-update rule (used by the GEMM's fused epilogues too)
-// ----------------------------------------------------------------------------------
-__device__ __forceinline__ float comp(const float4& v, int j)
-{
-    return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
-}
-__device__ __forceinline__ void setc(float4& v, int j, float x)
-{
-    if (j == 0) v.x = x; else if (j == 1) v.y = x; else if (j == 2) v.z = x; else v.w = x;
-}
-
-// The update rule (rbm.py:347-365) on 4 weights, shared by update_kernel and the fused epilogues of
-// the statistics GEMM.  Floating-point contraction is switched off inside these helpers (hipcc
-// otherwise fuses a*b+c into an fma or not depending on what the helper is inlined into -- the
-// __f*_rn intrinsics are plain operators to it), so every call site agrees bit for bit, and with the
-// float32 restatement, which rounds every operation.
-__device__ __forceinline__ float upd_grad(float st, float inv_bs, float wc, float w0)
-{
-#pragma clang fp contract(off)
-    const float a = st * inv_bs, b = wc * w0;
-    return a - b;
-}
-__device__ __forceinline__ float upd_speed(float g, float sp, float mu)     // g + (s - g) * mu
-{
-#pragma clang fp contract(off)
-    const float d = sp - g;
-    const float e = d * mu;
-    return g + e;
-}
-__device__ __forceinline__ float upd_param(float w, float m, float sp, float lr)   // w * m + s_old * lr
-{
-#pragma clang fp contract(off)
-    const float a = w * m, b = sp * lr;
-    return a + b;
-}
-__device__ __forceinline__ float upd_scale(float x, float s)
-{
-#pragma clang fp contract(off)
-    return x * s;
-}
-__device__ __forceinline__ float upd_decay(float lr, float l2)          // 1 - 2 lr l2
-{
-#pragma clang fp contract(off)
-    const float a = 2.0f * lr;
-    const float b = a * l2;
-    return 1.0f - b;
-}
-__device__ __forceinline__ float upd_two_lr_l1(float lr, float l1)
-{
-#pragma clang fp contract(off)
-    const float a = 2.0f * lr;
-    return a * l1;
-}
-__device__ __forceinline__ float upd_shrink(float two_lr_l1, float w)    // 1 + 2 lr l1 / (|w| + eps)
-{
-#pragma clang fp contract(off)
-    const float d = fabsf(w) + 0.001f;
-    const float q = __fdiv_rn(two_lr_l1, d);
-    return 1.0f + q;
-}
-
-__device__ __forceinline__ void update_rule4(const float4& w, const float4& sp, const float4& st, const float4& wc0,
-                                             float inv_bs, float wc, float decay, float l1, float two_lr_l1,
-                                             float mu, float lr, float4& wn, float4& sn)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float wj = comp(w, j), spj = comp(sp, j);
-        float g = upd_grad(comp(st, j), inv_bs, wc, comp(wc0, j));
-        float m = decay;
-        if (l1 != 0.0f) {
-            const float shrink = upd_shrink(two_lr_l1, wj);
-            g = __fdiv_rn(g, shrink);
-            m = __fdiv_rn(decay, shrink);
-        }
-        setc(sn, j, upd_speed(g, spj, mu));
-        setc(wn, j, upd_param(wj, m, spj, lr));
-    }
-}
-
-// ----------------------------------------------------------------------------------
-// Bias statistics (rbm.py:416-417) from the epilogues' 4-row column partials, the cost total, and the
-// bias half of the update, in units one WAVE computes on its own (no LDS, no barrier): unit u < n_units
-// = 16 columns x 4 group quarters (lane = 4 * column + quarter; quarter sums run over ascending groups,
-// combined as (q0 + q1) + (q2 + q3)); unit n_units = the cost total.  Fixed order: deterministic, and
-// identical whether finalize_stats_kernel or the statistics GEMM's consumer waves run the units.
-// ----------------------------------------------------------------------------------
-__device__ __forceinline__ int fin_units(const FinArgs& f) { return (int)((f.ldh + f.ldv + 15) / 16); }
-
-__device__ __forceinline__ void finalize_unit(const FinArgs& f, int unit, int lane)
-{
-    const int n_units = fin_units(f);
-    if (unit < n_units) {
-        const int cl = lane >> 2, qd = lane & 3;
-        const int64_t i = (int64_t)unit * 16 + cl;
-        const int per = (f.ngroups + 3) / 4;
-        const int gbeg = qd * per, gend = min(f.ngroups, gbeg + per);
-        float a = 0.f;
-        if (i < f.ldh) {
-#pragma unroll 16
-            for (int g = gbeg; g < gend; ++g) a += f.posP[(int64_t)g * f.ldh + i] + f.negP[(int64_t)g * f.ldh + i];
-        } else if (i < f.ldh + f.ldv) {
-            const int64_t j = i - f.ldh;
-#pragma unroll 16
-            for (int g = gbeg; g < gend; ++g) a += f.partV[(int64_t)g * f.ldv + j];
-        }
-        const int l0 = lane & ~3;
-        const float r0 = __shfl(a, l0, 64), r1 = __shfl(a, l0 + 1, 64), r2 = __shfl(a, l0 + 2, 64), r3 = __shfl(a, l0 + 3, 64);
-        const float t = (r0 + r1) + (r2 + r3);
-        if (qd == 0) {
-            if (i < f.ldh) f.s_h[i] = t;
-            else if (i < f.ldh + f.ldv) f.s_v[i - f.ldh] = t;
-            if (f.do_bias) {    // bias half of the update (rbm.py:356-365; same helpers as update_kernel)
-                const BiasUpd& bu = f.bu;
-                if (i < bu.H) {
-                    const float sp = bu.hbs[i];
-                    bu.hbs[i] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
-                    bu.hb[i] = upd_param(bu.hb[i], 1.0f, sp, bu.lr);
-                } else if (i >= f.ldh && i - f.ldh < bu.V) {
-                    const int64_t j = i - f.ldh;
-                    const float sp = bu.vbs[j];
-                    bu.vbs[j] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
-                    bu.vb[j] = upd_param(bu.vb[j], 1.0f, sp, bu.lr);
-                }
-            }
-        }
-    } else if (unit == n_units && f.cost_partials) {
-        float a = 0.f;
-        for (int k = lane; k < f.n_cost; k += 64) a += f.cost_partials[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
-        if (lane == 0) {
-            f.cost[0] = a; f.cost[1] = 0.f; f.cost[2] = 0.f; f.cost[3] = 0.f;
-            if (f.do_bias && f.bu.cost_out) f.bu.cost_out[0] = a * f.bu.cost_scale;
-        }
-    }
-}
-
 #ifdef MDBN_STAMP
 // diagnostic build: s_memtime stamps of one block's phases (never compiled into the product)
 #define STAMP(slot)                                                                          \
@@ -307,10 +169,6 @@ __device__ __forceinline__ void finalize_unit(const FinArgs& f, int unit, int la
 // ----------------------------------------------------------------------------------
 constexpr int GEMM_THREADS = 512;
 
-template <int BM, int BN, int NT = 512>
-__device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, int m0, int n0);
-template <int BM, int BN, int NT = 512>
-__device__ __forceinline__ void fused_update_epilogue(const UpdEpi& u, const float* T, int m0, int n0);
 #ifndef ABLATE_STORE
 #define ABLATE_STORE 0    // diagnostic builds only: timing ablations of the producer
 #endif
@@ -1017,142 +875,6 @@ hipError_t launch_gemm(int la, int lb, const GemmArgs& g, hipStream_t s)
 }
 
 // ----------------------------------------------------------------------------------
-// small device helpers
-// ----------------------------------------------------------------------------------
-// sigmoid / softplus on the hardware transcendentals (v_exp_f32, v_log_f32, v_rcp_f32: ~1 ulp
-// each).  |error| of sigmoid <= ~1e-7 absolute: the exponent's argument rounding |x|*6e-8 is
-// multiplied by sigmoid' = p(1-p) <= 1/4.  The libm-grade expf/division these replace made
-// the epilogue VALU-bound (14 us per call at B*H = 512K elements).
-__device__ __forceinline__ float sigmoidf_(float x)
-{
-    return __frcp_rn(1.0f + __expf(-x));
-}
-__device__ __forceinline__ float softplusf_(float x)
-{
-    // max(x, 0) + log1p(exp(-|x|)): the log argument is in (1, 2], no cancellation
-    return fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x)));
-}
-
-__device__ __forceinline__ float block_sum(float v, float* red /* >= 4 floats */)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    float t = 0.f;
-    const int nw = (blockDim.x + 63) >> 6;
-    for (int k = 0; k < nw; ++k) t += red[k];      // fixed order: deterministic
-    return t;
-}
-
-// 4 uniform words for rows g0..g0+3 of column col (one Philox block when g0 % 4 == 0)
-__device__ __forceinline__ void philox_rows4(const PhiloxKey& k, uint32_t draw, uint64_t g0,
-                                             uint32_t col, uint32_t (&w)[4])
-{
-    uint32_t lo[4];
-    philox4x32_10(col, (uint32_t)(g0 >> 2), draw, k.step, k.k0, k.k1, lo);
-    const uint32_t ph = (uint32_t)(g0 & 3);
-    if (ph == 0) {
-        w[0] = lo[0]; w[1] = lo[1]; w[2] = lo[2]; w[3] = lo[3];
-    } else {
-        uint32_t hi[4];
-        philox4x32_10(col, (uint32_t)(g0 >> 2) + 1u, draw, k.step, k.k0, k.k1, hi);
-        // rows g0..g0+3 straddle two blocks: element r is word (ph + r) of the 8 words lo|hi.
-        // Selected with compile-time indices only (a runtime index would put lo/hi in scratch).
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            uint32_t v = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t cand = j < 4 ? lo[j & 3] : hi[j & 3];
-                v = (ph + (uint32_t)r == (uint32_t)j) ? cand : v;
-            }
-            w[r] = v;
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------------
-// Activation epilogue fused into the GEMM (jobs that need no split-K): the arithmetic of
-// act_epilogue_kernel below applied to the block's own 128 x BN tile, which the consumer waves
-// parked in LDS (row stride BN + 8); all 8 waves take part.  A thread owns one column and walks
-// 4-row groups -- one Philox4x32-10 block per (group, column), as everywhere.  One cost partial
-// per block (cost_partials[blockIdx.x]); column partials [row_group][col] as below.
-// ----------------------------------------------------------------------------------
-// One (4-row group, column) of an activation epilogue: x[j] = pre-activation (bias included) of
-// row r0 + j.  Stores pre / mean / sample, the group's column partial, and adds to `cost`.
-__device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, float x2, float x3, int r0, int col, bool live, float& cost)
-{
-    const bool need_u = e.sample != nullptr;
-    const bool need_z = need_u && e.gauss;
-    uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
-    if (need_u) {
-        const uint64_t g0 = e.rng.row_offset + (uint64_t)r0;
-        philox_rows4(e.rng, e.rng.draw, g0, (uint32_t)col, wa);
-        if (need_z) philox_rows4(e.rng, e.rng.draw | MDBN_NORMAL_BIT, g0, (uint32_t)col, wb);
-    }
-    float csum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = r0 + j;
-        float xj = j == 0 ? x0 : (j == 1 ? x1 : (j == 2 ? x2 : x3));
-        if (row < e.rows) {
-            const int64_t off = (int64_t)row * e.ld + col;
-            float m, sv = 0.f;
-            if (e.gauss) {
-                m = xj;
-                if (need_u) {
-                    const float u1 = philox_u01(wa[j]), u2 = philox_u01(wb[j]);
-                    sv = m + sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
-                }
-            } else {
-                m = sigmoidf_(xj);
-                if (need_u) sv = philox_u01(wa[j]) < m ? 1.0f : 0.0f;
-            }
-            float tg = 0.f;
-            if (e.target && live) {
-                tg = e.target[(int64_t)row * e.ld_target + col];
-                if (e.gauss) { const float d = sigmoidf_(xj) - tg; cost += d * d; }
-                else cost += tg * softplusf_(-xj) + (1.0f - tg) * softplusf_(xj);
-            }
-            if (!live) { m = 0.f; sv = 0.f; xj = 0.f; }          // keep pad columns zero
-            const float ms = m * e.mean_scale;
-            if (e.pre) e.pre[off] = xj;
-            if (e.mean) e.mean[off] = ms;
-            if (e.sample) e.sample[off] = sv;
-            if (live) csum += e.colsum_kind == 0 ? ms : (e.colsum_kind == 1 ? tg - m : tg - sv);
-        }
-    }
-    if (e.colsum) e.colsum[(int64_t)(r0 >> 2) * e.ld + col] = csum;
-}
-
-template <int BM, int BN, int NT>
-__device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, int m0, int n0)
-{
-    constexpr int LDT = BN + 8;
-    const int c = threadIdx.x & (BN - 1), rg0 = threadIdx.x / BN;
-    const int col = n0 + c;
-    const bool live = col < e.cols, incol = col < (int)e.ld;
-    const float bias = live ? e.bias[col] : 0.f;
-    float cost = 0.f;
-#pragma unroll 1
-    for (int rg = rg0; rg < BM / 4; rg += NT / BN) {
-        const int r0 = m0 + 4 * rg;
-        if (r0 >= e.rows || !incol) continue;
-        float x[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = T[(4 * rg + j) * LDT + c] + bias;
-        act_quad(e, x[0], x[1], x[2], x[3], r0, col, live, cost);
-    }
-    if (e.cost_partials) {
-        const float tot = block_sum(cost, T + BM * LDT);
-        if (threadIdx.x == 0) e.cost_partials[blockIdx.x] = tot;
-    }
-}
-
-// ----------------------------------------------------------------------------------
 // Register-streaming ("skinny") GEMM: no LDS staging, operands go from global memory / L2
 // straight into the MFMA operand registers.  Two regimes use it:
 //  * minibatches of <= 64 rows (the reference trains with batch_size 20, dbn.py / MDBN.py): at
@@ -1711,47 +1433,6 @@ hipError_t launch_colsum_groups(const float* X, const float* Y, int rows, int64_
 {
     hipLaunchKernelGGL(colsum_groups_kernel, dim3(epilogue_blocks(rows, ld)), dim3(256), 0, s, X, Y, rows, ld, out);
     return hipGetLastError();
-}
-
-// Parameter update applied by the statistics GEMM to the tile it just computed (parked in LDS, row
-// stride BN + 8): W and W_speed are read and written once, S never touches HBM.  The GEMM reads
-// only V2 / P2, so updating W in place under it is safe.  A thread owns one float4 column group and
-// walks rows; 4 rows of loads are in flight per round.
-template <int BM, int BN, int NT>
-__device__ __forceinline__ void fused_update_epilogue(const UpdEpi& u, const float* T, int m0, int n0)
-{
-    constexpr int LDT = BN + 8, C4 = BN / 4, RSTEP = NT / C4, RB = 4;
-    const int c4 = threadIdx.x % C4, rr = threadIdx.x / C4;
-    const int col = n0 + 4 * c4;
-    if (col >= (int)u.ld) return;
-    const float two_lr_l1 = upd_two_lr_l1(u.lr, u.l1);
-    const float decay = upd_decay(u.lr, u.l2);
-#pragma unroll 1
-    for (int r = rr; r < BM; r += RSTEP * RB) {
-        float4 w[RB], sp[RB], w0[RB];
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const int row = m0 + r + b * RSTEP;
-            if (r + b * RSTEP < BM && row < u.rows) {
-                const int64_t off = (int64_t)row * u.ld + col;
-                w[b] = *reinterpret_cast<const float4*>(u.W + off);
-                sp[b] = *reinterpret_cast<const float4*>(u.Ws + off);
-                w0[b] = u.W0 ? *reinterpret_cast<const float4*>(u.W0 + off) : w[b];
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const int row = m0 + r + b * RSTEP;
-            if (r + b * RSTEP < BM && row < u.rows) {
-                const int64_t off = (int64_t)row * u.ld + col;
-                const float4 st = *reinterpret_cast<const float4*>(T + (r + b * RSTEP) * LDT + 4 * c4);
-                float4 wn, sn;
-                update_rule4(w[b], sp[b], st, w0[b], u.inv_bs, u.wc, decay, u.l1, two_lr_l1, u.mu, u.lr, wn, sn);
-                *reinterpret_cast<float4*>(u.W + off) = wn;
-                *reinterpret_cast<float4*>(u.Ws + off) = sn;
-            }
-        }
-    }
 }
 
 // ----------------------------------------------------------------------------------

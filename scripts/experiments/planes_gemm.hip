@@ -14,6 +14,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4n __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef LORDER
+#define LORDER 0    // loaders: 0 = issue stage it+2, wait, barrier; 1 = wait, barrier, issue stage it+3 (issue off the barrier's path)
+#endif
+#ifndef LPRIO
+#define LPRIO 0     // s_setprio of the loader waves
+#endif
+#ifndef AUXBITS
+#define AUXBITS 0   // cache-policy bits of the LDS-DMA loads (1 sc0, 2 nt, 16 sc1)
+#endif
+#ifndef SCHED
+#define SCHED 0 // 0: compiler's order; 1: next step's fragment reads interleaved under this step's MFMAs; 2: all reads in front
+#endif
 #ifndef ABL
 #define ABL 0   // diagnostic: 1 no DMA issued, 2 no MFMA (fragment reads kept alive), 3 no fragment reads, 4 consumers only pass barriers
 #endif
@@ -25,12 +37,13 @@ struct PArgs {
     const unsigned short* B; int64_t ldb, pb;
     float* C; int64_t ldc, slab_stride;
     int M, N, K, kchunk, splitk, tiles_m, tiles_n;
+    unsigned long long* dbg;      // [grid][4]: s_memtime at entry / loop start / loop end, s_memrealtime span
 };
 
 __device__ __forceinline__ void glds16(const void* g, unsigned lds_off, char* smem)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, AUXBITS);
 }
 
 // One loader wave's share of the staging: instructions q = w, w + LW, ... of the NQ = 8 * (AP + 3) per stage.
@@ -71,6 +84,8 @@ __device__ __forceinline__ void loader(const PArgs& g, char* smem, int w, int la
             src[j] += step[j];                                                                \
         }                                                                                     \
     } while (0)
+    if (LPRIO) __builtin_amdgcn_s_setprio(LPRIO);
+#if LORDER == 0
     ISSUE(0);
     if (nt > 1) { ISSUE(1); }
     if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
@@ -85,6 +100,23 @@ __device__ __forceinline__ void loader(const PArgs& g, char* smem, int w, int la
         }
         __builtin_amdgcn_s_barrier();
     }
+#else
+    // three stages in flight; the refill of a slot is issued right AFTER the barrier that frees it
+    ISSUE(0);
+    if (nt > 1) { ISSUE(1); }
+    if (nt > 2) { ISSUE(2); }
+    if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER) : "memory");
+    else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // stage 0 landed
+    for (int it = 0; it < nt; ++it) {
+        // stage it + 1 must have landed before the consumers pass barrier `it`; stage it + 2 may still fly
+        if (it + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // every read of stage `it` is done: its slot is free
+        if (it + 3 < nt) { ISSUE(it + 3); }
+    }
+#endif
 #undef ISSUE
 }
 
@@ -124,6 +156,8 @@ __global__ __launch_bounds__(64 * (4 + LW)) void planes_gemm_kernel(PArgs g)
         loader<LA, LB, AP, LW>(g, smem, wave - 4, lane, m0, n0, kbeg, nt);
         return;
     }
+    unsigned long long t_in = 0, rt_in = 0;
+    if (g.dbg) { t_in = __builtin_amdgcn_s_memtime(); rt_in = __builtin_amdgcn_s_memrealtime(); }
     const int r = lane & 31, h = lane >> 5;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     // fragment byte offsets inside a plane image, [32-row block][k16 step][first / second half (COL only)]
@@ -201,19 +235,48 @@ __global__ __launch_bounds__(64 * (4 + LW)) void planes_gemm_kernel(PArgs g)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[0][b], acc[a][b], 0, 0, 0); \
             }                                                                                 \
         }
+    // DS-read instructions of one FRAGS block and MFMAs of one MMA block (for the issue-order directives)
+    constexpr int NRD = 2 * (AP * (LA == COL ? 2 : 1) + 3 * (LB == COL ? 2 : 1)), NMM = 4 * (AP == 3 ? 6 : 3);
+#if SCHED == 1
+#define ORDER()                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < (NRD < NMM ? NRD : NMM); ++i_) {                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+    }                                                                                         \
+    if (NRD > NMM) __builtin_amdgcn_sched_group_barrier(0x100, NRD - NMM, 0);                 \
+    if (NMM > NRD) __builtin_amdgcn_sched_group_barrier(0x008, NMM - NRD, 0);
+#define MID() do { } while (0)
+#elif SCHED == 2
+#define ORDER() do { } while (0)
+#define MID() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ORDER() do { } while (0)
+#define MID() do { } while (0)
+#endif
     __syncthreads();                                 // stage 0 landed
+    unsigned long long t_loop = 0;
+    if (g.dbg) t_loop = __builtin_amdgcn_s_memtime();
     FRAGS(f0a, f0b, smem, 0);
     for (int it = 0; it < nt; ++it) {
         const char* base = smem + (it % NSTAGE) * STAGE;
         const char* next = smem + ((it + 1) % NSTAGE) * STAGE;
         FRAGS(f1a, f1b, base, 1);
+        MID();
         MMA(f0a, f0b);
+        ORDER();
         __syncthreads();                             // all reads of stage `it` done; stage it + 1 landed
         FRAGS(f0a, f0b, next, 0);
+        MID();
         MMA(f1a, f1b);
+        ORDER();
     }
 #undef FRAGS
 #undef MMA
+    if (g.dbg && wave == 0 && lane == 0) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime(), rt_end = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* d = g.dbg + 4 * (int64_t)blockIdx.x;
+        d[0] = t_loop - t_in; d[1] = t_end - t_loop; d[2] = t_end - t_in; d[3] = rt_end - rt_in;
+    }
     float* C = g.C + (int64_t)ks * g.slab_stride;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -277,10 +340,10 @@ extern "C" int exp_split(const float* X, int64_t rows, int64_t ld, unsigned shor
 
 extern "C" int exp_gemm(int la, int lb, int ap, int lw, const unsigned short* A, int64_t lda, int64_t pa,
                         const unsigned short* B, int64_t ldb, int64_t pb, float* C, int64_t ldc, int64_t slab_stride,
-                        int M, int N, int K, int splitk, void* stream)
+                        int M, int N, int K, int splitk, void* stream, unsigned long long* dbg)
 {
     if (M % 128 || N % 128 || K % (32 * splitk)) return -1;
-    PArgs g{A, lda, pa, B, ldb, pb, C, ldc, slab_stride, M, N, K, K / splitk, splitk, M / 128, N / 128};
+    PArgs g{A, lda, pa, B, ldb, pb, C, ldc, slab_stride, M, N, K, K / splitk, splitk, M / 128, N / 128, dbg};
     hipStream_t s = (hipStream_t)stream;
 #define CASE(LAV, LBV, APV, LWV) if (la == LAV && lb == LBV && ap == APV && lw == LWV) return launch<LAV, LBV, APV, LWV>(g, s)
     CASE(ROW, COL, 3, 4); CASE(ROW, COL, 3, 8); CASE(ROW, COL, 1, 4); CASE(ROW, COL, 1, 8);

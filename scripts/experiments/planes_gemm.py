@@ -27,7 +27,7 @@ import mdbn_amd
 lib = C.CDLL(so)
 vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
 lib.exp_split.argtypes = [vp, i64, i64, vp, vp]
-lib.exp_gemm.argtypes = [i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]
+lib.exp_gemm.argtypes = [i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp, vp]
 eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
 dev = eng.device
 ROW, COL = 0, 1
@@ -60,7 +60,8 @@ cases = [("propup", 512, 1024, 4096, ROW, COL, 3, 8), ("propup_hs", 512, 1024, 4
          ("propdown", 512, 4096, 1024, ROW, ROW, 1, 2), ("propdown3", 512, 4096, 1024, ROW, ROW, 3, 2),
          ("stats", 4096, 1024, 1024, COL, COL, 3, 1), ("steady_up", 4096, 1024, 4096, ROW, COL, 3, 1),
          ("steady_stats", 4096, 4096, 4096, COL, COL, 3, 1)]
-for name, M, N, K, la, lb, ap, sk in cases:
+VARIANTS = len(sys.argv) > 2 and sys.argv[1] == "variants"
+for name, M, N, K, la, lb, ap, sk in ([] if (ABLATE or VARIANTS) else cases):
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
     A = torch.randn((M, K) if la == ROW else (K, M), generator=g).to(dev)
     if ap == 1:
@@ -74,7 +75,7 @@ for name, M, N, K, la, lb, ap, sk in cases:
     for lw in (4, 8):
         def run():
             rc = lib.exp_gemm(la, lb, ap, lw, Ap.data_ptr(), A.shape[1], A.numel(), Bp.data_ptr(), B.shape[1], B.numel(),
-                              Cs.data_ptr(), N, M * N, M, N, K, sk, stream())
+                              Cs.data_ptr(), N, M * N, M, N, K, sk, stream(), None)
             assert rc == 0, rc
         Cs.zero_()
         run(); torch.cuda.synchronize()
@@ -117,8 +118,39 @@ if ABLATE:
             row = {"case": name, "lw": lw, "stages_per_job": K // sk // 32}
             for abl, nm in names.items():
                 f = lambda: libs[abl].exp_gemm(la, lb, ap, lw, Ap.data_ptr(), A.shape[1], A.numel(), Bp.data_ptr(), B.shape[1],
-                                               B.numel(), Cs.data_ptr(), N, M * N, M, N, K, sk, stream())
+                                               B.numel(), Cs.data_ptr(), N, M * N, M, N, K, sk, stream(), None)
                 row[nm + "_us"] = round(timeit(f), 2)
             res.append(row); print(json.dumps(row), flush=True)
+if len(sys.argv) > 2 and sys.argv[1] == "variants":
+    # python planes_gemm.py variants "-DSCHED=1" "-DSCHED=2 -DFOO=3" ...: full kernels, checked and timed per build
+    for vi, flags in enumerate([""] + sys.argv[2:]):
+        vlib = C.CDLL(build(flags.split(), so.replace(".so", "_v%d.so" % vi)))
+        vlib.exp_gemm.argtypes = lib.exp_gemm.argtypes
+        for name, M, N, K, la, lb, ap, sk in cases:
+            g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+            A = torch.randn((M, K) if la == ROW else (K, M), generator=g).to(dev)
+            if ap == 1:
+                A = (A > 0).float()
+            B = (0.05 * torch.randn((N, K) if lb == ROW else (K, N), generator=g)).to(dev)
+            Ap, Bp = split(A), split(B)
+            Cs = torch.zeros((sk, M, N), device=dev)
+            ref = (A.double() if la == ROW else A.double().t()) @ (B.double().t() if lb == ROW else B.double())
+            for lw in (4, 8):
+                f = lambda: vlib.exp_gemm(la, lb, ap, lw, Ap.data_ptr(), A.shape[1], A.numel(), Bp.data_ptr(), B.shape[1],
+                                          B.numel(), Cs.data_ptr(), N, M * N, M, N, K, sk, stream(), None)
+                Cs.zero_()
+                rc = f(); torch.cuda.synchronize()
+                err = float((Cs.sum(0).double() - ref).abs().max() / ref.abs().max())
+                row = {"variant": flags or "base", "case": name, "lw": lw, "rc": rc, "us": round(timeit(f), 2), "relerr": err}
+                nblk = (M // 128) * (N // 128) * sk
+                dbg = torch.zeros((nblk, 4), dtype=torch.int64, device=dev)
+                for _ in range(20): f()                      # clock under sustained load
+                vlib.exp_gemm(la, lb, ap, lw, Ap.data_ptr(), A.shape[1], A.numel(), Bp.data_ptr(), B.shape[1], B.numel(),
+                              Cs.data_ptr(), N, M * N, M, N, K, sk, stream(), dbg.data_ptr())
+                torch.cuda.synchronize()
+                d = dbg.double().median(0).values.tolist()
+                nst = K // sk // 32
+                row.update({"prologue_cyc": d[0], "cyc_per_stage": round(d[1] / nst, 1), "clock_ghz": round(d[2] / d[3] * 0.1, 3)})
+                res.append(row); print(json.dumps(row), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "planes_gemm.json"), "w"), indent=1)
