@@ -82,6 +82,18 @@ typedef struct mdbn_cd_args {
     float       *trace_h;     /* [k+1][B][ldh]: slot 0 = positive-phase sample, slot t = hidden sample of
                                * Gibbs step t (slot k only when that sample is materialised: PCD)      */
     float       *trace_v;     /* [k][B][ldv]: slot t-1 = Bernoulli visible sample of step t (RBM only)   */
+    /* bf16 plane path (optional).  With both pointers set and a shape made of whole 128-row/column tiles
+     * (B, V, H multiples of 128, ldv == V, ldh == H, CD without persistent chain) every tensor of the step is
+     * split ONCE into three bf16 planes where it is produced and the GEMMs copy plane tiles into LDS by LDS-DMA
+     * (csrc/mdbn_planes.hip); otherwise the GEMMs split their f32 operands themselves.  Same arithmetic, same
+     * results up to fp32 summation order. */
+    void        *planes;      /* scratch of >= mdbn_planes_bytes(B, ldv, ldh) bytes, 16-byte aligned          */
+    int64_t      planes_bytes;
+    void        *W_planes;    /* [3][V][ldh] bf16: the exact split of W (W = p1 + p2 + p3)                    */
+    int32_t      W_planes_valid; /* 1: W_planes already hold the split of the current W; 0: split W first.
+                               * mdbn_cd_train_step / mdbn_apply_update (with its W_planes set) keep them in
+                               * step with W, so a caller passes 0 only after writing W itself            */
+    int32_t      reserved1;
 } mdbn_cd_args;
 
 /* Parameter update of src/rbm.py:347-365 from (all-reduced) statistics. */
@@ -97,6 +109,8 @@ typedef struct mdbn_update_args {
     float n_rows;                   /* divisor of s_h, s_v: rows actually present (rbm.py:416-417) */
     float cost_scale;               /* monitoring cost = stats.cost_sum * cost_scale ...          */
     float *cost_out;                /* ... written here (device scalar) if not NULL               */
+    void *W_planes;                 /* NULL, or [3][V][ldh] bf16 planes rewritten with the split of the new W
+                                     * whenever this call changes W (phases 0, 2, 3)                          */
     int32_t phase;                  /* 0 = whole rule; 1 = speeds (+cost) only; 2 = parameters only;
                                      * 3 = 1 then 2 in one pass (parameters from the NEW speeds).
                                      * Because the parameter step uses the OLD speed (rbm.py:364-365),
@@ -136,6 +150,8 @@ int  mdbn_ctx_destroy(mdbn_ctx *ctx);
  * "skinny_gemm" (default 1): GEMMs of <= 64 output rows, and tiny GEMMs at any row count, use the
  *   register-streaming kernel (no LDS staging); "skinny_fused_max_k" (default 1024) largest K one
  *   block streams alone, "skinny_max_macs" (default 32 Mi) size limit above 64 rows.
+ * "gemm_planes" (default 1): use the bf16 plane path of mdbn_cd_args when its buffers are given and the
+ *   shape qualifies.
  * "update_overlap": 1 = mdbn_cd_train_step overlaps part of the update with the statistics GEMM
  * on a side stream (default 0: measured slower, see csrc/mdbn_capi.hip). */
 int  mdbn_set_option(mdbn_ctx *ctx, const char *name, int64_t value);
@@ -158,6 +174,11 @@ int  mdbn_workspace_bytes(int64_t B, int64_t V, int64_t H, int64_t *bytes);
 /* leading dimension this library recommends for a [., cols] matrix (currently round_up(cols, 4);
  * see the measurement note in csrc/mdbn_capi.hip).  Any ld % 4 == 0, ld >= cols is accepted. */
 int  mdbn_padded_ld(int64_t cols, int64_t *ld);
+/* bytes of plane scratch (mdbn_cd_args.planes) for a minibatch of B rows: planes of [v0; nv], [ph; -nh],
+ * the hidden and the visible sample */
+int  mdbn_planes_bytes(int64_t B, int64_t ldv, int64_t ldh, int64_t *bytes);
+/* exact three-way bf16 split of an f32 matrix [rows, ld] into planes [3][rows][ld] (x = p1 + p2 + p3) */
+int  mdbn_split_planes(mdbn_ctx *ctx, void *stream, const float *x, int64_t rows, int64_t ld, void *planes);
 /* floats in the packed statistics buffer [S (V*ldh) | s_h (ldh) | s_v (ldv) | 4] */
 int  mdbn_stats_floats(int64_t V, int64_t ldv, int64_t ldh, int64_t *n);
 

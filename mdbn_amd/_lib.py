@@ -25,7 +25,9 @@ class CdArgs(C.Structure):
                 ("persistent", C.c_void_p),
                 ("V2", C.c_void_p), ("P2", C.c_void_p), ("hs", C.c_void_p), ("vs", C.c_void_p),
                 ("stats", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("rng", Rng), ("trace_h", C.c_void_p), ("trace_v", C.c_void_p)]
+                ("rng", Rng), ("trace_h", C.c_void_p), ("trace_v", C.c_void_p),
+                ("planes", C.c_void_p), ("planes_bytes", C.c_int64), ("W_planes", C.c_void_p),
+                ("W_planes_valid", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class UpdateArgs(C.Structure):
@@ -37,7 +39,7 @@ class UpdateArgs(C.Structure):
                 ("lr", C.c_float), ("lambda_1", C.c_float), ("lambda_2", C.c_float),
                 ("weightcost", C.c_float), ("momentum", C.c_float),
                 ("batch_size", C.c_float), ("n_rows", C.c_float),
-                ("cost_scale", C.c_float), ("cost_out", C.c_void_p),
+                ("cost_scale", C.c_float), ("cost_out", C.c_void_p), ("W_planes", C.c_void_p),
                 ("phase", C.c_int32), ("reserved", C.c_int32)]
 
 
@@ -59,6 +61,8 @@ SIGNATURES = {
                                   C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(_i64)],
     "mdbn_workspace_bytes": [_i64, _i64, _i64, C.POINTER(_i64)],
     "mdbn_padded_ld": [_i64, C.POINTER(_i64)],
+    "mdbn_planes_bytes": [_i64, _i64, _i64, C.POINTER(_i64)],
+    "mdbn_split_planes": [_vp, _vp, _vp, _i64, _i64, _vp],
     "mdbn_stats_floats": [_i64, _i64, _i64, C.POINTER(_i64)],
     "mdbn_gather_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _i64, _vp, _i64],
     "mdbn_propup_sample": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp,

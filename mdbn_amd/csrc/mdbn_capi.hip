@@ -190,6 +190,9 @@ bool prefer_skinny(int64_t M, int64_t N, int64_t K)
 // split operands (f32 accuracy, see gemm_bf16x6_kernel); bit 0 = statistics GEMM, bit 1 = forward
 // passes; default 3
 static int g_opt_gemm_bf16x6 = 3;
+// mdbn_set_option("gemm_planes"): the CD step runs on pre-split bf16 planes (mdbn_planes.hip) when the caller
+// supplies the plane buffers and the shape is made of whole 128-row / 128-column tiles (default on)
+static int g_opt_gemm_planes = 1;
 
 // Turn an LDS-tiled plan into a bf16x6 plan (128x128 tiles, 32-deep slices) when that leaves enough
 // jobs to spread over the chip; `unsplit` = the caller needs splitk == 1 (fused statistics epilogue).
@@ -383,7 +386,7 @@ int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_
             R = std::max<int64_t>(4, (R / 2 + 3) & ~int64_t(3));
             p = plan_forward(R, Ndim, Kdim, a.ldo);
         }
-        GemmArgs g;
+        GemmArgs g{};
         g.A = a.x + r0 * a.ldx;  g.lda = a.ldx;
         g.B = a.W;               g.ldb = a.ldw;
         g.C = ws.slabs;          g.ldc = a.ldo;
@@ -392,7 +395,7 @@ int run_affine(const Affine& a, const Workspace& ws, hipStream_t s, int* n_cost_
         p.fill(g);
         if (p.x6 && a.x_binary) g.x6 = 2;
 
-        EpiArgs e;
+        EpiArgs e{};
         e.slabs = ws.slabs; e.slab_stride = g.slab_stride; e.nsplit = p.splitk;
         e.rows = (int)R; e.cols = (int)Ndim; e.ld = a.ldo;
         e.bias = a.bias;
@@ -440,6 +443,203 @@ int check_mat(const void* p, int64_t ld, int64_t cols, const char* name)
 }
 
 #define CHECK(expr) do { int _rc = (expr); if (_rc != MDBN_OK) return _rc; } while (0)
+
+
+// ---------------------------------------------------------------------------------- bf16 plane path
+hipError_t timed_gemm_planes(int la, int lb, const PlaneGemmArgs& g, hipStream_t s)
+{
+    if (!g_timing.enabled || g_timing.used >= 8192) return launch_gemm_planes(la, lb, g, s);
+    if (g_timing.used == g_timing.pool.size()) {
+        hipEvent_t a, b;
+        hipError_t e = hipEventCreate(&a);
+        if (e != hipSuccess) return e;
+        e = hipEventCreate(&b);
+        if (e != hipSuccess) return e;
+        g_timing.pool.emplace_back(a, b);
+    }
+    {
+        const double alg = 2.0 * (double)g.M * (double)g.N * (double)g.K;
+        const int pipe = g.ap == 3 ? 1 : 2;
+        GemmTiming::Meta m{2000 + 100 * pipe + 10 * g.fused + 2 * la + lb, alg, alg * (pipe == 1 ? 6.0 : 3.0)};
+        if (g_timing.meta.size() <= g_timing.used) g_timing.meta.resize(g_timing.used + 1);
+        g_timing.meta[g_timing.used] = m;
+    }
+    auto& ev = g_timing.pool[g_timing.used++];
+    hipError_t e = hipEventRecord(ev.first, s);
+    if (e != hipSuccess) return e;
+    e = launch_gemm_planes(la, lb, g, s);
+    if (e != hipSuccess) return e;
+    return hipEventRecord(ev.second, s);
+}
+
+// carve-up of mdbn_cd_args.planes (bf16 elements): planes of X2 = [v0; nv] and P2 = [ph; -nh], hs, vs
+struct PlaneBufs {
+    unsigned short *Xp, *Pp, *hsp, *vsp;
+    int64_t px, pp;          // elements between the planes of Xp / Pp
+};
+inline int64_t planes_elems(int64_t B, int64_t ldv, int64_t ldh) { return 6 * B * ldv + 6 * B * ldh + B * ldh + B * ldv; }
+
+// split factor of a plane GEMM over K: about one job per CU, >= kMinSplitK of reduction per job, K / sk a multiple of 32
+int planes_splitk(int64_t tiles, int64_t K)
+{
+    int64_t sk = std::min(std::max<int64_t>(1, kTargetJobs / tiles), std::max<int64_t>(1, K / kMinSplitK));
+    while (sk > 1 && K % (32 * sk) != 0) --sk;
+    return (int)sk;
+}
+
+bool planes_eligible(const mdbn_cd_args* a, bool fused_update)
+{
+    if (!g_opt_gemm_planes || !a->planes || !a->W_planes) return false;
+    if (a->persistent || a->sample_stats || (a->gauss && a->add_noise)) return false;
+    const int64_t B = a->B, V = a->V, H = a->H;
+    if (B % 128 || V % 128 || H % 128 || a->ldv != V || a->ldh != H || B > 65535) return false;
+    if (a->planes_bytes < 2 * planes_elems(B, V, H) || !aligned16(a->planes) || !aligned16(a->W_planes)) return false;
+    const int64_t t_up = (B / 128) * (H / 128), t_down = (B / 128) * (V / 128), t_st = (V / 128) * (H / 128);
+    if (t_up * planes_splitk(t_up, V) < g_opt_x6_min_jobs || t_down * planes_splitk(t_down, H) < g_opt_x6_min_jobs) return false;
+    if (t_st < g_opt_x6_min_jobs) return false;          // the statistics GEMM runs unsplit (fused update / plain S)
+    (void)fused_update;
+    return true;
+}
+
+// One forward pass on planes: A planes [rows, K] (ROW), W planes as COL (dir 0: propup) or ROW (dir 1: propdown);
+// `e` arrives with outputs / bias / rng / colsum set, this fills in the slab side and the cost partials.
+int run_affine_planes(const unsigned short* A, int64_t lda, int64_t pa, int ap, int dir, const unsigned short* Wp,
+                      int64_t V, int64_t H, int64_t rows, EpiArgs e, bool want_cost, const Workspace& ws, hipStream_t s,
+                      int* n_cost_out)
+{
+    const int64_t Kdim = dir == 0 ? V : H, Ndim = dir == 0 ? H : V;
+    PlaneGemmArgs g{};
+    g.A = A; g.lda = lda; g.pa = pa; g.ap = ap;
+    g.B = Wp; g.ldb = H; g.pb = V * H;
+    g.M = (int)rows; g.N = (int)Ndim; g.K = (int)Kdim;
+    g.tiles_m = (int)(rows / 128); g.tiles_n = (int)(Ndim / 128);
+    g.splitk = planes_splitk((int64_t)g.tiles_m * g.tiles_n, Kdim);
+    g.kchunk = (int)(Kdim / g.splitk);
+    const bool fuse = g_opt_fused_epilogue && g.splitk == 1;
+    const int nb = fuse ? g.tiles_m * g.tiles_n : epilogue_blocks(rows, e.ld);
+    e.rows = (int)rows; e.cols = (int)Ndim;
+    e.cost_partials = nullptr;
+    if (want_cost) {
+        if (nb > ws.cost_floats) return fail(MDBN_ENOSPC, "cost scratch exhausted");
+        e.cost_partials = ws.cost_partials;
+        if (n_cost_out) *n_cost_out = nb;
+    }
+    const int lb = dir == 0 ? LAY_MN : LAY_K;
+    if (fuse) {
+        g.fused = 1; g.epi = e;
+        HIP_OK(timed_gemm_planes(LAY_K, lb, g, s));
+    } else {
+        REQUIRE((int64_t)g.splitk * rows * e.ld <= ws.slab_floats, "internal: plane GEMM slabs exceed the workspace");
+        g.fused = 0; g.C = ws.slabs; g.ldc = e.ld; g.slab_stride = rows * e.ld;
+        e.slabs = ws.slabs; e.slab_stride = g.slab_stride; e.nsplit = g.splitk;
+        HIP_OK(timed_gemm_planes(LAY_K, lb, g, s));
+        HIP_OK(launch_act_epilogue(e, s));
+    }
+    return MDBN_OK;
+}
+
+// The CD-k step on planes (same sequence, draws and outputs as cd_step_impl below; GRBM without noise and
+// Bernoulli RBM, CD only).  upd != NULL: single-device step with the update fused into the statistics GEMM.
+int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const mdbn_update_args* upd, const Workspace& ws)
+{
+    (void)ctx;
+    const int64_t B = a->B, V = a->V, H = a->H, ldv = V, ldh = H;
+    PlaneBufs pb;
+    {
+        unsigned short* p = reinterpret_cast<unsigned short*>(a->planes);
+        pb.Xp = p; pb.px = 2 * B * ldv; p += 6 * B * ldv;
+        pb.Pp = p; pb.pp = 2 * B * ldh; p += 6 * B * ldh;
+        pb.hsp = p; p += B * ldh;
+        pb.vsp = p;
+    }
+    unsigned short* Wp = reinterpret_cast<unsigned short*>(a->W_planes);
+    if (!a->W_planes_valid) HIP_OK(launch_split_planes(a->W, V, ldh, Wp, V * ldh, s));
+
+    float* v0 = a->V2;
+    float* nv = a->V2 + B * ldv;
+    float* ph = a->P2;
+    float* nh = a->P2 + B * ldh;
+    // x = train_set_x[indexes] (dbn.py:307), as f32 (cost target, bias statistics) and as planes
+    HIP_OK(launch_gather_planes(a->data, a->n_data, ldv, ldv, a->indexes, a->index_is_64, B, v0, ldv, pb.Xp, pb.px, s));
+
+    auto key = [&](uint32_t draw) { PhiloxKey k = make_key(a->rng, draw); return k; };
+    {   // positive phase: ph_mean (+ planes), h0 sample (f32 for the taps, plane for the chain)   (rbm.py:303)
+        EpiArgs e{};
+        e.ld = ldh; e.bias = a->hbias; e.mean = ph; e.sample = a->hs; e.mean_scale = 1.0f; e.gauss = 0;
+        e.colsum = ws.colPpos; e.colsum_kind = 0; e.rng = key(0);
+        e.mean_planes = pb.Pp; e.plane_stride = pb.pp; e.sample_plane = pb.hsp;
+        CHECK(run_affine_planes(pb.Xp, ldv, pb.px, 3, 0, Wp, V, H, B, e, false, ws, s, nullptr));
+        if (a->trace_h) HIP_OK(hipMemcpyAsync(a->trace_h, a->hs, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
+    }
+    int n_cost = 0;
+    for (int t = 1; t <= a->k; ++t) {                                  // gibbs_hvh x k (rbm.py:318-336)
+        const bool last = t == a->k;
+        {   // v_t | h_{t-1}: the chain state is our own 0/1 sample: one plane, three products
+            EpiArgs e{};
+            e.ld = ldv; e.bias = a->vbias; e.mean = nv; e.mean_scale = 1.0f; e.gauss = a->gauss;
+            e.sample = a->gauss ? nullptr : a->vs; e.rng = key((uint32_t)(2 * t - 1));
+            e.mean_planes = pb.Xp + B * ldv; e.plane_stride = pb.px;      // rows B..2B-1 of the X2 planes
+            e.sample_plane = a->gauss ? nullptr : pb.vsp;
+            if (last) { e.target = v0; e.ld_target = ldv; e.colsum = ws.colV; e.colsum_kind = 1; }
+            CHECK(run_affine_planes(pb.hsp, ldh, B * ldh, 1, 1, Wp, V, H, B, e, last, ws, s, last ? &n_cost : nullptr));
+            if (a->trace_v && !a->gauss)
+                HIP_OK(hipMemcpyAsync(a->trace_v + (int64_t)(t - 1) * B * ldv, a->vs, sizeof(float) * B * ldv,
+                                      hipMemcpyDeviceToDevice, s));
+        }
+        {   // h_t | v_t: from the mean for GRBM (rbm.py:669), from the 0/1 sample for RBM (rbm.py:246)
+            const bool need_sample = !last;
+            EpiArgs e{};
+            e.ld = ldh; e.bias = a->hbias; e.mean = nh; e.mean_scale = -1.0f; e.gauss = 0;
+            e.sample = need_sample ? a->hs : nullptr; e.rng = key((uint32_t)(2 * t));
+            e.mean_planes = pb.Pp + B * ldh; e.plane_stride = pb.pp;       // rows B..2B-1 of the P2 planes: -nh_mean
+            e.sample_plane = need_sample ? pb.hsp : nullptr;
+            if (last) { e.colsum = ws.colPneg; e.colsum_kind = 0; }
+            if (a->gauss) CHECK(run_affine_planes(pb.Xp + B * ldv, ldv, pb.px, 3, 0, Wp, V, H, B, e, false, ws, s, nullptr));
+            else CHECK(run_affine_planes(pb.vsp, ldv, B * ldv, 1, 0, Wp, V, H, B, e, false, ws, s, nullptr));
+            if (a->trace_h && need_sample)
+                HIP_OK(hipMemcpyAsync(a->trace_h + (int64_t)t * B * ldh, a->hs, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
+        }
+    }
+
+    float* S = a->stats;
+    float* s_h = a->stats + V * ldh;
+    float* s_v = s_h + ldh;
+    float* cost = s_v + ldv;
+    // S = [v0; nv]^T [ph; -nh]: one GEMM over the stacked batch dimension, both operands used transposed
+    PlaneGemmArgs g{};
+    g.A = pb.Xp; g.lda = ldv; g.pa = pb.px; g.ap = 3;
+    g.B = pb.Pp; g.ldb = ldh; g.pb = pb.pp;
+    g.M = (int)V; g.N = (int)H; g.K = (int)(2 * B);
+    g.tiles_m = (int)(V / 128); g.tiles_n = (int)(H / 128); g.splitk = 1; g.kchunk = g.K;
+    g.fin_enabled = 0;
+    const bool fuse_upd = upd != nullptr && g_opt_fused_update;
+    if (fuse_upd) {
+        BiasUpd bu;
+        bu.hb = upd->hbias; bu.hbs = upd->hbias_speed; bu.vb = upd->vbias; bu.vbs = upd->vbias_speed;
+        bu.H = H; bu.V = V; bu.lr = upd->lr; bu.mu = upd->momentum; bu.inv_rows = 1.0f / upd->n_rows;
+        bu.cost_scale = upd->cost_scale; bu.cost_out = upd->cost_out;
+        g.fused = 2;
+        g.fin_enabled = 1;
+        g.fin = make_fin_args(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials, n_cost, s_h, s_v,
+                              cost, &bu);
+        g.upd.W = upd->W; g.upd.Ws = upd->W_speed; g.upd.W0 = upd->W0; g.upd.ld = ldh; g.upd.rows = (int)V;
+        g.upd.lr = upd->lr; g.upd.l1 = upd->lambda_1; g.upd.l2 = upd->lambda_2; g.upd.wc = upd->weightcost;
+        g.upd.mu = upd->momentum; g.upd.inv_bs = 1.0f / upd->batch_size;
+        g.upd.Wp = Wp; g.upd.wp_stride = V * ldh;
+        HIP_OK(timed_gemm_planes(LAY_MN, LAY_MN, g, s));
+        return MDBN_OK;
+    }
+    HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials, n_cost, s_h,
+                                 s_v, cost, nullptr, s));
+    g.fused = 0; g.C = S; g.ldc = ldh; g.slab_stride = 0;
+    HIP_OK(timed_gemm_planes(LAY_MN, LAY_MN, g, s));
+    if (upd) {
+        mdbn_update_args u = *upd;
+        u.phase = 0;
+        HIP_OK(launch_update(u, s, nullptr, 1, 0, Wp));
+    }
+    return MDBN_OK;
+}
 
 }  // namespace
 
@@ -544,6 +744,10 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
         g_opt_gemm_bf16x6 = (int)value & 3;
         return MDBN_OK;
     }
+    if (strcmp(name, "gemm_planes") == 0) {
+        g_opt_gemm_planes = value != 0;
+        return MDBN_OK;
+    }
     if (strcmp(name, "fused_finalize") == 0) {
         g_opt_fused_finalize = value != 0;
         return MDBN_OK;
@@ -615,6 +819,21 @@ int mdbn_padded_ld(int64_t cols, int64_t* ld)
 {
     REQUIRE(ld != nullptr && cols > 0, "bad arguments");
     *ld = padded_ld(cols);
+    return MDBN_OK;
+}
+
+int mdbn_planes_bytes(int64_t B, int64_t ldv, int64_t ldh, int64_t* bytes)
+{
+    REQUIRE(bytes != nullptr && B > 0 && ldv > 0 && ldh > 0, "bad arguments");
+    *bytes = 2 * planes_elems(B, ldv, ldh);
+    return MDBN_OK;
+}
+
+int mdbn_split_planes(mdbn_ctx* ctx, void* stream, const float* x, int64_t rows, int64_t ld, void* planes)
+{
+    REQUIRE(ctx && x && planes && rows > 0 && ld > 0 && ld % 4 == 0, "bad arguments");
+    REQUIRE(aligned16(x) && aligned16(planes), "x and planes must be 16-byte aligned");
+    HIP_OK(launch_split_planes(x, rows, ld, reinterpret_cast<unsigned short*>(planes), rows * ld, (hipStream_t)stream));
     return MDBN_OK;
 }
 
@@ -717,7 +936,7 @@ int mdbn_cd_stats(mdbn_ctx* ctx, void* stream, const float* V2, const float* P2,
 
     // S = [v0 ; nv]^T [ph ; -nh]  : one GEMM over the stacked batch dimension (K = 2B)
     const Plan p = plan_stats(V, H, 2 * B, ldh);
-    GemmArgs g;
+    GemmArgs g{};
     g.A = V2; g.lda = ldv; g.B = P2; g.ldb = ldh;
     g.ldc = ldh; g.slab_stride = V * ldh;
     g.M = (int)V; g.N = (int)H; g.K = (int)(2 * B); g.Nst = (int)ldh;
@@ -741,7 +960,9 @@ int mdbn_apply_update(mdbn_ctx* ctx, void* stream, const mdbn_update_args* a)
 {
     REQUIRE(ctx != nullptr && a != nullptr, "NULL argument");
     CHECK(check_update_args(a));
-    HIP_OK(launch_update(*a, (hipStream_t)stream));
+    // phases that write W also rewrite its bf16 planes when the caller keeps some
+    HIP_OK(launch_update(*a, (hipStream_t)stream, nullptr, 1, 0,
+                         a->phase != 1 ? reinterpret_cast<unsigned short*>(a->W_planes) : nullptr));
     return MDBN_OK;
 }
 
@@ -756,6 +977,7 @@ static int check_update_args(const mdbn_update_args* a)
     REQUIRE(a->hbias && a->hbias_speed && a->vbias && a->vbias_speed, "bias pointers are NULL");
     REQUIRE(a->batch_size > 0.f && a->n_rows > 0.f, "bad divisors");
     REQUIRE(a->phase >= 0 && a->phase <= 3, "phase must be 0, 1, 2 or 3");
+    REQUIRE(a->W_planes == nullptr || (aligned16(a->W_planes) && a->ldh % 4 == 0), "W_planes not aligned");
     REQUIRE(a->phase == 0 || (a->lambda_1 == 0.f && (a->weightcost == 0.f || a->W0 != nullptr)),
             "split update phases need lambda_1 == 0 and weightcost == 0 or a frozen W0");
     return MDBN_OK;
@@ -782,6 +1004,13 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
     Workspace ws;
     CHECK(carve(a->workspace, a->workspace_bytes, B, V, H, ws, true));
     hipStream_t s = (hipStream_t)stream;
+    if (upd) {
+        REQUIRE(upd->stats == a->stats && upd->W == a->W && upd->ldh == ldh && upd->ldv == ldv && upd->V == V && upd->H == H,
+                "update arguments do not match the step's buffers");
+        REQUIRE(upd->W_planes == nullptr || upd->W_planes == a->W_planes, "update and step disagree about W_planes");
+    }
+    if (planes_eligible(a, upd != nullptr) && !(upd && g_opt_update_overlap))
+        return cd_step_planes(ctx, s, a, upd, ws);
 
     float* v0 = a->V2;
     float* nv = a->V2 + B * ldv;
@@ -857,7 +1086,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials,
                                      n_cost, s_h, s_v, cost, nullptr, ctx->side));
         u.phase = 2;
-        HIP_OK(launch_update(u, ctx->side));
+        HIP_OK(launch_update(u, ctx->side, nullptr, 1, 0, reinterpret_cast<unsigned short*>(u.W_planes)));
         HIP_OK(hipEventRecord(ctx->ev_join, ctx->side));
     }
     const Plan p = plan_stats(V, H, 2 * B, ldh);
@@ -878,7 +1107,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
     if (!overlap && !fin_in_gemm && !fin_in_plain_gemm)
         HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials,
                                      n_cost, s_h, s_v, cost, fuse_upd ? &bu : nullptr, s));
-    GemmArgs g;
+    GemmArgs g{};
     g.A = a->V2; g.lda = ldv; g.B = a->P2; g.ldb = ldh;
     g.ldc = ldh; g.slab_stride = V * ldh;
     g.M = (int)V; g.N = (int)H; g.K = (int)(2 * B); g.Nst = (int)ldh;
@@ -895,6 +1124,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         g.upd.W = u.W; g.upd.Ws = u.W_speed; g.upd.W0 = u.W0; g.upd.ld = ldh; g.upd.rows = (int)V;
         g.upd.lr = u.lr; g.upd.l1 = u.lambda_1; g.upd.l2 = u.lambda_2; g.upd.wc = u.weightcost;
         g.upd.mu = u.momentum; g.upd.inv_bs = 1.0f / u.batch_size;
+        g.upd.Wp = reinterpret_cast<unsigned short*>(u.W_planes); g.upd.wp_stride = V * ldh;
         HIP_OK(timed_gemm(LAY_MN, LAY_MN, g, s));
         return MDBN_OK;
     }
@@ -913,7 +1143,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
             // single device: the update sums the slabs itself (same order as sum_slabs_kernel, so the
             // same bits); S is not materialised, as in the fused unsplit case
             u.phase = 0;
-            HIP_OK(launch_update(u, s, ws.slabs, p.splitk, g.slab_stride));
+            HIP_OK(launch_update(u, s, ws.slabs, p.splitk, g.slab_stride, reinterpret_cast<unsigned short*>(u.W_planes)));
             return MDBN_OK;
         }
         HIP_OK(launch_sum_slabs(ws.slabs, p.splitk, g.slab_stride, V * ldh, S, s));
@@ -925,7 +1155,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         } else {
             u.phase = 0;
         }
-        HIP_OK(launch_update(u, s));
+        HIP_OK(launch_update(u, s, nullptr, 1, 0, u.phase != 1 ? reinterpret_cast<unsigned short*>(u.W_planes) : nullptr));
     }
     return MDBN_OK;
 }
@@ -963,7 +1193,7 @@ int mdbn_free_energy(mdbn_ctx* ctx, void* stream, const float* x, int64_t N, int
             R = std::max<int64_t>(4, (R / 2 + 3) & ~int64_t(3));
             p = plan_gemm(R, H, V);
         }
-        GemmArgs g;
+        GemmArgs g{};
         g.A = x + r0 * ldv; g.lda = ldv; g.B = W; g.ldb = ldh; g.C = ws.slabs; g.ldc = ldh;
         g.slab_stride = R * ldh;
         g.M = (int)R; g.N = (int)H; g.K = (int)V; g.Nst = (int)ldh;

@@ -217,6 +217,35 @@ __device__ __forceinline__ void philox_rows4(const PhiloxKey& k, uint32_t draw, 
 // ----------------------------------------------------------------------------------
 // One (4-row group, column) of an activation epilogue: x[j] = pre-activation (bias included) of
 // row r0 + j.  Stores pre / mean / sample, the group's column partial, and adds to `cost`.
+// exact three-way split of an f32 into bf16 pieces by truncation: x = p1 + p2 + p3 (bf16 keeps f32's exponent
+// range, three 8-bit significands cover the 24 bits).  The upper half of an f32 IS a bf16.
+__device__ __forceinline__ void split3(float a, unsigned short& p1, unsigned short& p2, unsigned short& p3)
+{
+    const unsigned ua = __builtin_bit_cast(unsigned, a);
+    const float ra = a - __builtin_bit_cast(float, ua & 0xffff0000u);
+    const unsigned va = __builtin_bit_cast(unsigned, ra);
+    const float sa = ra - __builtin_bit_cast(float, va & 0xffff0000u);
+    p1 = (unsigned short)(ua >> 16); p2 = (unsigned short)(va >> 16);
+    p3 = (unsigned short)(__builtin_bit_cast(unsigned, sa) >> 16);
+}
+
+// four consecutive values -> one 8-byte store per plane
+__device__ __forceinline__ void store_planes4(unsigned short* P, int64_t plane_stride, int64_t off, const float4& v)
+{
+    unsigned short q[3][4];
+    split3(v.x, q[0][0], q[1][0], q[2][0]);
+    split3(v.y, q[0][1], q[1][1], q[2][1]);
+    split3(v.z, q[0][2], q[1][2], q[2][2]);
+    split3(v.w, q[0][3], q[1][3], q[2][3]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        uint2 w;
+        w.x = q[p][0] | ((unsigned)q[p][1] << 16);
+        w.y = q[p][2] | ((unsigned)q[p][3] << 16);
+        *reinterpret_cast<uint2*>(P + p * plane_stride + off) = w;
+    }
+}
+
 __device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, float x2, float x3, int r0, int col, bool live, float& cost)
 {
     const bool need_u = e.sample != nullptr;
@@ -256,6 +285,12 @@ __device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, f
             if (e.pre) e.pre[off] = xj;
             if (e.mean) e.mean[off] = ms;
             if (e.sample) e.sample[off] = sv;
+            if (e.mean_planes) {
+                unsigned short p1, p2, p3;
+                split3(ms, p1, p2, p3);
+                e.mean_planes[off] = p1; e.mean_planes[e.plane_stride + off] = p2; e.mean_planes[2 * e.plane_stride + off] = p3;
+            }
+            if (e.sample_plane) e.sample_plane[off] = (unsigned short)(__builtin_bit_cast(unsigned, sv) >> 16);
             if (live) csum += e.colsum_kind == 0 ? ms : (e.colsum_kind == 1 ? tg - m : tg - sv);
         }
     }
@@ -323,6 +358,7 @@ __device__ __forceinline__ void fused_update_epilogue(const UpdEpi& u, const flo
                 update_rule4(w[b], sp[b], st, w0[b], u.inv_bs, u.wc, decay, u.l1, two_lr_l1, u.mu, u.lr, wn, sn);
                 *reinterpret_cast<float4*>(u.W + off) = wn;
                 *reinterpret_cast<float4*>(u.Ws + off) = sn;
+                if (u.Wp) store_planes4(u.Wp, u.wp_stride, off, wn);
             }
         }
     }

@@ -27,6 +27,11 @@ struct EpiArgs {
     float* colsum;         // nullable: [ceil(rows/4)][ld] partial column sums over each 4-row group
     int colsum_kind;       // 0: sum of stored (scaled) mean ; 1: sum of (target - mean) ; 2: sum of (target - sample)
     PhiloxKey rng;
+    // bf16 plane outputs (mdbn_planes.hip): the stored (scaled) mean split exactly into three bf16 planes
+    // [3][rows][ld] (plane p at mean_planes + p * plane_stride), the 0/1 sample as one bf16 plane
+    unsigned short* mean_planes;   // nullable
+    int64_t plane_stride;          // elements between planes
+    unsigned short* sample_plane;  // nullable (Bernoulli samples only)
 };
 
 // parameter update applied by the statistics GEMM to its own output tile (fused == 2)
@@ -35,6 +40,8 @@ struct UpdEpi {
     int64_t ld;
     int rows;
     float lr, l1, l2, wc, mu, inv_bs;
+    unsigned short* Wp;            // nullable: bf16 planes [3][rows][ld] of the NEW W, kept in step with it
+    int64_t wp_stride;
 };
 
 // bias half of the update + monitoring cost, applied by finalize_stats_kernel
@@ -87,6 +94,25 @@ struct GemmArgs {
 
 
 
+// GEMM on pre-split bf16 planes (mdbn_planes.hip): whole 128x128 tiles and 32-deep stages only
+struct PlaneGemmArgs {
+    const unsigned short* A; int64_t lda, pa;   // planes [ap][.][lda]; pa = elements between planes
+    const unsigned short* B; int64_t ldb, pb;   // planes [3][.][ldb]
+    float* C; int64_t ldc, slab_stride;         // fused == 0: slabs [splitk][M][ldc] (or plain C)
+    int M, N, K, kchunk, splitk, tiles_m, tiles_n;
+    int ap;                // planes of A: 3, or 1 when A holds 0/1 samples (three products instead of six)
+    int fused;             // 0 | 1 activation epilogue (epi) | 2 parameter update (upd) + finalize units (fin)
+    EpiArgs epi;
+    UpdEpi upd;
+    int fin_enabled;
+    FinArgs fin;
+};
+
+hipError_t launch_gemm_planes(int la, int lb, const PlaneGemmArgs& g, hipStream_t s);
+hipError_t launch_split_planes(const float* X, int64_t rows, int64_t ld, unsigned short* P, int64_t plane_stride, hipStream_t s);
+hipError_t launch_gather_planes(const float* src, int64_t n_rows, int64_t cols_ld, int64_t ld_src, const void* idx, int idx64,
+                                int64_t n_idx, float* dst, int64_t ld_dst, unsigned short* P, int64_t plane_stride, hipStream_t s);
+
 // blocks (= cost partials) the activation epilogue launches for a [rows, ld] output
 int epilogue_blocks(int64_t rows, int64_t ld);
 int epilogue_cw(int64_t rows, int64_t ld);
@@ -109,7 +135,7 @@ hipError_t launch_finalize_stats(const float* posP, const float* negP, const flo
                                  float* s_h, float* s_v, float* cost, const BiasUpd* bias_update, hipStream_t s);
 // slabs != NULL (phase 0 only): the S block is read as the sum of `nslab` split-K slabs
 hipError_t launch_update(const mdbn_update_args& a, hipStream_t s, const float* slabs = nullptr, int nslab = 1,
-                         int64_t slab_stride = 0);
+                         int64_t slab_stride = 0, unsigned short* Wp = nullptr);
 hipError_t launch_free_energy(const float* slabs, int nsplit, int64_t slab_stride, int64_t ldh, int H,
                               const float* hbias, const float* x, int64_t ldv, int V, const float* vbias,
                               int gauss, int64_t rows, float* out, hipStream_t s);

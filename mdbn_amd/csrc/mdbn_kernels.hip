@@ -258,6 +258,7 @@ __device__ __forceinline__ void gemm_produce(const GemmArgs& g, float* __restric
                 update_rule4(w[p], sp[p], st, w[p], u.inv_bs, u.wc, decay, u.l1, two_lr_l1, u.mu, u.lr, wn, sn);
                 *reinterpret_cast<float4*>(u.W + off) = wn;
                 *reinterpret_cast<float4*>(u.Ws + off) = sn;
+                if (u.Wp) store_planes4(u.Wp, u.wp_stride, off, wn);
             }
         }
     }
@@ -1053,6 +1054,11 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmArgs
                         const int64_t off = (int64_t)(r0w + j) * u.ld + col;
                         u.W[off] = comp(wn, j);
                         u.Ws[off] = comp(sn, j);
+                        if (u.Wp) {
+                            unsigned short p1, p2, p3;
+                            split3(comp(wn, j), p1, p2, p3);
+                            u.Wp[off] = p1; u.Wp[u.wp_stride + off] = p2; u.Wp[2 * u.wp_stride + off] = p3;
+                        }
                     }
             }
         } else {
@@ -1245,6 +1251,18 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
             if (e.pre) VecIO<CW>::store(e.pre + off, pre[r]);
             if (e.mean) VecIO<CW>::store(e.mean + off, mean);
             if (e.sample) VecIO<CW>::store(e.sample + off, samp);
+            if (e.mean_planes || e.sample_plane) {
+#pragma unroll
+                for (int j = 0; j < CW; ++j) {
+                    if (e.mean_planes) {
+                        unsigned short p1, p2, p3;
+                        split3(mean[j], p1, p2, p3);
+                        e.mean_planes[off + j] = p1; e.mean_planes[e.plane_stride + off + j] = p2;
+                        e.mean_planes[2 * e.plane_stride + off + j] = p3;
+                    }
+                    if (e.sample_plane) e.sample_plane[off + j] = (unsigned short)(__builtin_bit_cast(unsigned, samp[j]) >> 16);
+                }
+            }
         }
         if (e.colsum) VecIO<CW>::store(e.colsum + (int64_t)rg * e.ld + c0, csum);
     }
@@ -1453,7 +1471,8 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
                                                      float* __restrict__ vb, float* __restrict__ vbs,
                                                      const float* __restrict__ s_v, int64_t V, float inv_rows,
                                                      const float* __restrict__ cost_sum, float cost_scale,
-                                                     float* __restrict__ cost_out, int nslab, int64_t slab_stride4)
+                                                     float* __restrict__ cost_out, int nslab, int64_t slab_stride4,
+                                                     unsigned short* __restrict__ Wp)
 {
     // nslab > 1 (whole rule only): S points at the split-K slabs of the statistics GEMM, summed here
     // in slab order exactly as sum_slabs_kernel would -- one launch and one pass over S fewer
@@ -1497,6 +1516,7 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
             }
             Ws[i] = sn;
             W[i] = wn;
+            if (Wp) store_planes4(Wp, n4 * 4, i * 4, wn);
         } else if constexpr (DO_SPEED && DO_PARAMS) {
             const float4 w = W[i];
             float4 st;
@@ -1518,10 +1538,13 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
             update_rule4(w, sp, st, wc0, inv_bs, wc, decay, l1, two_lr_l1, mu, lr, wn, sn);
             W[i] = wn;
             Ws[i] = sn;
+            if (Wp) store_planes4(Wp, n4 * 4, i * 4, wn);
         } else if constexpr (DO_PARAMS) {           // lambda_1 == 0 (checked by the host): m = decay
             const float4 w = W[i];
-            W[i] = make_float4(upd_param(w.x, decay, sp.x, lr), upd_param(w.y, decay, sp.y, lr),
-                               upd_param(w.z, decay, sp.z, lr), upd_param(w.w, decay, sp.w, lr));
+            const float4 wn = make_float4(upd_param(w.x, decay, sp.x, lr), upd_param(w.y, decay, sp.y, lr),
+                                          upd_param(w.z, decay, sp.z, lr), upd_param(w.w, decay, sp.w, lr));
+            W[i] = wn;
+            if (Wp) store_planes4(Wp, n4 * 4, i * 4, wn);
         } else {                                    // speeds only; weight cost, if any, uses W0
             const float4 st = S[i];
             const float4 w0 = wc != 0.0f ? W0[i] : make_float4(0.f, 0.f, 0.f, 0.f);     // host: W0 != NULL when wc != 0
@@ -1534,7 +1557,7 @@ __global__ __launch_bounds__(256) void update_kernel(float4* __restrict__ W, flo
 }
 
 hipError_t launch_update(const mdbn_update_args& a, hipStream_t s, const float* slabs, int nslab,
-                         int64_t slab_stride)
+                         int64_t slab_stride, unsigned short* Wp)
 {
     const int64_t n4 = (a.V * a.ldh) >> 2;
     if (slabs && (a.phase != 0 || (slab_stride & 3))) return hipErrorInvalidValue;
@@ -1549,7 +1572,7 @@ hipError_t launch_update(const mdbn_update_args& a, hipStream_t s, const float* 
                        reinterpret_cast<const float4*>(S), n4, a.lr, a.lambda_1, a.lambda_2, a.weightcost, \
                        a.momentum, 1.0f / a.batch_size, a.hbias, a.hbias_speed, s_h, a.H, a.vbias,    \
                        a.vbias_speed, s_v, a.V, 1.0f / a.n_rows, s_v + a.ldv, a.cost_scale, a.cost_out, nslab, \
-                       slab_stride >> 2)
+                       slab_stride >> 2, Wp)
 #define LAUNCH_UPDATE(SP, PA) LAUNCH_UPDATE_(SP, PA, false)
 #define LAUNCH_UPDATE3() LAUNCH_UPDATE_(true, true, true)
     if (a.phase == 1) LAUNCH_UPDATE(true, false);

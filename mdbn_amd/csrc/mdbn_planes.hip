@@ -1,0 +1,361 @@
+// GEMMs of the CD step on PRE-SPLIT bf16 planes (gfx950 / MI355X).
+//
+// gemm_bf16x6_kernel (mdbn_kernels.hip) keeps every operand f32 in HBM and splits it into three bf16
+// pieces inside the kernel, in every block that loads it: its producer waves spend their time on split
+// arithmetic and LDS stores.  Here every tensor of the step is split ONCE, where it is produced (the gather,
+// the activation epilogues, the weight update), into three bf16 planes x = p1 + p2 + p3 (exact), and the
+// GEMM only COPIES plane tiles into LDS with LDS-DMA (global_load_lds_dwordx4: no VGPRs, no VALU, no
+// ds_write) and issues the six piece products (three when one operand holds 0/1 samples) on
+// v_mfma_f32_32x32x16_bf16 with f32 accumulation -- the same products in the same order as
+// gemm_bf16x6_kernel, so an unsplit GEMM gives the same bits.
+//
+// Operand layouts (planes are [3][rows][ld] bf16 in HBM, natural row-major like their f32 originals):
+//   ROW operand: the reduction index k is contiguous in memory ([rows][k]).  LDS image [128 rows][32 k]
+//       (64-byte rows), 16-byte chunk c of row r stored at chunk c ^ ((r >> 2) & 3): the MFMA fragment
+//       (8 consecutive k of one row) is ONE ds_read_b128, conflict-free.
+//   COL operand: k is the ROW index in memory ([k][rows]), i.e. the operand is used transposed
+//       (x^T, ph in the statistics GEMM; W in propup).  LDS image [32 k][128 rows] (256-byte rows), chunk c of
+//       k-row k stored at c ^ ((k & 3) << 2); the fragment is read with two ds_read_b64_tr_b16, gfx950's
+//       transposing LDS read -- no transposed copy of any tensor exists anywhere.
+//   LDS-DMA writes linearly (wave base + lane * 16), so the swizzles are applied to the per-lane SOURCE
+//   address (cdna_hip_programming.md rule 21).
+// Block: 128x128 tile, 32-deep stages, 3-stage LDS ring (144 KB), 4 MFMA waves (one per SIMD, 64x64 each)
+// + 4 loader waves.  A loader waits for stage it+1 (counted vmcnt), joins the barrier that ends stage it,
+// and only then issues stage it+3 into the slot just freed: issue latency stays off the barrier's path
+// and two stages are always in flight.  Measured (scripts/experiments/planes_gemm.py): ~1900 cycles per
+// stage against 1536 of MFMA issue; the chip holds only 1.3-1.6 GHz under this load, which is what bounds
+// the wall time.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <stdint.h>
+#include "mdbn_kernels.h"
+#include "mdbn_device.h"
+
+namespace mdbn {
+
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+typedef short ps16x4 __attribute__((ext_vector_type(4)));
+typedef short ps16x8 __attribute__((ext_vector_type(8)));
+typedef float pf32x16 __attribute__((ext_vector_type(16)));
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PL_PLANE = 8192, PL_STAGE = 6 * PL_PLANE, PL_NSTAGE = 3, PL_LW = 4;
+
+__device__ __forceinline__ void pl_glds16(const void* g, unsigned lds_off, char* smem)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
+}
+
+// One loader wave's share of the staging: instructions q = w, w + LW, ... of the 8 * (AP + 3) per stage
+// (8 per plane: 1 KiB each).
+template <int LA, int LB, int AP>
+__device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, int w, int lane, int m0, int n0, int kbeg, int nt)
+{
+    constexpr int NQ = 8 * (AP + 3), PER = NQ / PL_LW;
+    const char* src[PER];
+    unsigned dst[PER];
+    int64_t step[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int q = w + j * PL_LW;
+        const bool isA = q < 8 * AP;
+        const int plane = isA ? q / 8 : (q - 8 * AP) / 8, sub = q & 7;
+        const int lay = isA ? LA : LB;
+        const unsigned short* base = isA ? g.A + plane * g.pa : g.B + plane * g.pb;
+        const int64_t ld = isA ? g.lda : g.ldb;
+        const int mn0 = isA ? m0 : n0;
+        dst[j] = (isA ? plane : 3 + plane) * PL_PLANE + sub * 1024;
+        if (lay == LAY_K) {      // ROW: 16 rows x 64 B per instruction
+            const int row = 16 * sub + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            src[j] = reinterpret_cast<const char*>(base + (int64_t)(mn0 + row) * ld + kbeg + 8 * c);
+            step[j] = 64;
+        } else {                 // COL: 4 k-rows x 256 B per instruction
+            const int k = 4 * sub + (lane >> 4);
+            const int ch = (lane & 15) ^ ((k & 3) << 2);
+            src[j] = reinterpret_cast<const char*>(base + (int64_t)(kbeg + k) * ld + mn0 + 8 * ch);
+            step[j] = 64 * ld;
+        }
+    }
+#define PL_ISSUE(T)                                                                           \
+    do {                                                                                      \
+        const unsigned so = ((T) % PL_NSTAGE) * PL_STAGE;                                     \
+        _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                     \
+            pl_glds16(src[j], so + dst[j], smem);                                             \
+            src[j] += step[j];                                                                \
+        }                                                                                     \
+    } while (0)
+    PL_ISSUE(0);
+    if (nt > 1) { PL_ISSUE(1); }
+    if (nt > 2) { PL_ISSUE(2); }
+    if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER) : "memory");
+    else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // stage 0 landed
+    for (int it = 0; it < nt; ++it) {
+        // stage it + 1 must have landed before the MFMA waves pass barrier `it`; stage it + 2 may still fly
+        if (it + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // every read of stage `it` is done: its slot is free
+        if (it + 3 < nt) { PL_ISSUE(it + 3); }
+    }
+#undef PL_ISSUE
+}
+
+template <int LAY>
+__device__ __forceinline__ pbf16x8 pl_frag(const char* plane, int off0, int off1)
+{
+    if constexpr (LAY == LAY_K) {
+        return *reinterpret_cast<const pbf16x8*>(plane + off0);
+    } else {
+        const ps16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4*)(plane + off0));
+        const ps16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4*)(plane + off1));
+        const ps16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(pbf16x8, v);
+    }
+}
+
+// FUSED: 0 = split-K slab / plain C store; 1 = activation + sampling epilogue on the parked tile (unsplit
+// forward pass); 2 = statistics GEMM: finalize units on the ramp-up, parameter update (+ W planes) on the
+// parked tile.  AP = planes of A (3, or 1 for 0/1 samples).
+template <int LA, int LB, int AP, int FUSED>
+__global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemmArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // XCD-aware (split, tile) order, as the other GEMM kernels: placement only affects speed
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int qq = nwg >> 3, rem = nwg & 7;
+    const int w = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + slot;
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int ks = w / tiles, t = w - ks * tiles;
+    int tm, tn;
+    if (g.tiles_m <= g.tiles_n) { tn = t / g.tiles_m; tm = t - tn * g.tiles_m; }
+    else { tm = t / g.tiles_n; tn = t - tm * g.tiles_n; }
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int kbeg = ks * g.kchunk;
+    const int nt = g.kchunk / 32;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+
+    if (wave >= 4) {
+        pl_loader<LA, LB, AP>(g, smem, wave - 4, lane, m0, n0, kbeg, nt);
+        if constexpr (FUSED == 0) return;
+    } else {
+        const int r = lane & 31, h = lane >> 5;
+        const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+        if constexpr (FUSED == 2) {
+            if (g.fin_enabled) {        // statistics GEMM: finalize units while the first stages are in flight
+                const int nu = fin_units(g.fin);
+                for (int unit = wave * (int)gridDim.x + (int)blockIdx.x; unit <= nu; unit += 4 * (int)gridDim.x)
+                    finalize_unit(g.fin, unit, lane);
+            }
+        }
+        // fragment byte offsets inside a plane image: [32-row block][k16 step][first / second tr read]
+        int offA[2][2][2], offB[2][2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int gq = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
+                {
+                    const int row = wm + 32 * b + r;
+                    if (LA == LAY_K) {
+                        offA[b][s][0] = row * 64 + ((((2 * s + h) ^ ((row >> 2) & 3))) << 4);
+                        offA[b][s][1] = 0;
+                    } else {
+                        const int ch = (wm + 32 * b) / 8 + 2 * gq + (p >> 1);
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt)
+                            offA[b][s][tt] = (16 * s + 8 * h + 4 * tt + q) * 256 + ((ch ^ (q << 2)) << 4) + 8 * (p & 1);
+                    }
+                }
+                {
+                    const int row = wn + 32 * b + r;
+                    if (LB == LAY_K) {
+                        offB[b][s][0] = row * 64 + ((((2 * s + h) ^ ((row >> 2) & 3))) << 4);
+                        offB[b][s][1] = 0;
+                    } else {
+                        const int ch = (wn + 32 * b) / 8 + 2 * gq + (p >> 1);
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt)
+                            offB[b][s][tt] = (16 * s + 8 * h + 4 * tt + q) * 256 + ((ch ^ (q << 2)) << 4) + 8 * (p & 1);
+                    }
+                }
+            }
+        pf32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+        pbf16x8 f0a[3][2], f0b[3][2], f1a[3][2], f1b[3][2];
+#define PL_FRAGS(FA, FB, BASE, S)                                                             \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                          \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                       \
+            if (pl < AP) FA[pl][a] = pl_frag<LA>((BASE) + pl * PL_PLANE, offA[a][S][0], offA[a][S][1]); \
+            FB[pl][a] = pl_frag<LB>((BASE) + (3 + pl) * PL_PLANE, offB[a][S][0], offB[a][S][1]); \
+        }
+#define PL_MMA(FA, FB)                                                                        \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                             \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) {     /* smallest products first */     \
+            if constexpr (AP == 3) {                                                          \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[2][a], FB[0][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[2][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][a], FB[1][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][a], FB[0][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[1][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[0][b], acc[a][b], 0, 0, 0); \
+            } else {        /* A = a1 exactly: a1 b3 + a1 b2 + a1 b1 is the full product */   \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[2][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[1][b], acc[a][b], 0, 0, 0); \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[0][b], acc[a][b], 0, 0, 0); \
+            }                                                                                 \
+        }
+        // issue order: the NEXT step's fragment reads interleaved one by one under this step's MFMAs
+        constexpr int NRD = 2 * (AP * (LA == LAY_MN ? 2 : 1) + 3 * (LB == LAY_MN ? 2 : 1)), NMM = 4 * (AP == 3 ? 6 : 3);
+#define PL_ORDER()                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < (NRD < NMM ? NRD : NMM); ++i_) {                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+    }                                                                                         \
+    if (NRD > NMM) __builtin_amdgcn_sched_group_barrier(0x100, NRD - NMM, 0);                 \
+    if (NMM > NRD) __builtin_amdgcn_sched_group_barrier(0x008, NMM - NRD, 0);
+        __syncthreads();                             // stage 0 landed
+        PL_FRAGS(f0a, f0b, smem, 0);
+        // The F0 reload at the end of the body is unconditional (on the last stage it reads a slot that is no
+        // longer written and the values are never used): see the note on the guarded reload in DESIGN.md.
+        for (int it = 0; it < nt; ++it) {
+            const char* base = smem + (it % PL_NSTAGE) * PL_STAGE;
+            const char* next = smem + ((it + 1) % PL_NSTAGE) * PL_STAGE;
+            PL_FRAGS(f1a, f1b, base, 1);
+            PL_MMA(f0a, f0b);
+            PL_ORDER();
+            __syncthreads();                         // every read of stage `it` is done; stage it + 1 has landed
+            PL_FRAGS(f0a, f0b, next, 0);
+            PL_MMA(f1a, f1b);
+            PL_ORDER();
+        }
+#undef PL_FRAGS
+#undef PL_MMA
+#undef PL_ORDER
+        // accumulator (32x32): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+        if constexpr (FUSED != 0) {
+            float* T = reinterpret_cast<float*>(smem);
+            constexpr int LDT = 128 + 8;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        T[(wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h) * LDT + wn + 32 * b + r] = acc[a][b][e];
+        } else {
+            float* C = g.C + (int64_t)ks * g.slab_stride;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int col = n0 + wn + 32 * b + r;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = m0 + wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        C[(int64_t)row * g.ldc + col] = acc[a][b][e];
+                    }
+                }
+            return;
+        }
+    }
+    if constexpr (FUSED != 0) {     // all 8 waves work on the parked tile (every DMA has landed: the loaders drained vmcnt)
+        __syncthreads();
+        float* T = reinterpret_cast<float*>(smem);
+        if constexpr (FUSED == 1) fused_tile_epilogue<128, 128, 64 * (4 + PL_LW)>(g.epi, T, m0, n0);
+        else fused_update_epilogue<128, 128, 64 * (4 + PL_LW)>(g.upd, T, m0, n0);
+    }
+}
+
+template <int LA, int LB, int AP, int FUSED>
+static hipError_t launch_planes_t(const PlaneGemmArgs& g, hipStream_t s)
+{
+    auto kern = gemm_planes_kernel<LA, LB, AP, FUSED>;
+    static bool attr_set = false;
+    constexpr int lds = PL_NSTAGE * PL_STAGE;        // 144 KB (the parked tile of the epilogues, 70 KB, reuses it)
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n * g.splitk), dim3(64 * (4 + PL_LW)), lds, s, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_planes(int la, int lb, const PlaneGemmArgs& g, hipStream_t s)
+{
+    if (g.M % 128 || g.N % 128 || g.kchunk % 32 || g.kchunk * g.splitk != g.K || g.tiles_m != g.M / 128 ||
+        g.tiles_n != g.N / 128 || (g.lda & 7) || (g.ldb & 7) || (g.fused && g.splitk != 1) || (g.ap != 1 && g.ap != 3))
+        return hipErrorInvalidValue;
+#define PL_CASE(LAV, LBV, APV, FV) \
+    if (la == LAV && lb == LBV && g.ap == APV && g.fused == FV) return launch_planes_t<LAV, LBV, APV, FV>(g, s)
+    // propup: x planes (ROW) x W planes (COL)
+    PL_CASE(LAY_K, LAY_MN, 3, 0); PL_CASE(LAY_K, LAY_MN, 3, 1); PL_CASE(LAY_K, LAY_MN, 1, 0); PL_CASE(LAY_K, LAY_MN, 1, 1);
+    // propdown: h planes (ROW) x W planes (ROW)
+    PL_CASE(LAY_K, LAY_K, 3, 0); PL_CASE(LAY_K, LAY_K, 3, 1); PL_CASE(LAY_K, LAY_K, 1, 0); PL_CASE(LAY_K, LAY_K, 1, 1);
+    // statistics: [v0; nv]^T planes (COL) x [ph; -nh] planes (COL)
+    PL_CASE(LAY_MN, LAY_MN, 3, 0); PL_CASE(LAY_MN, LAY_MN, 3, 2);
+#undef PL_CASE
+    return hipErrorInvalidValue;
+}
+
+// ----------------------------------------------------------------------------------
+// f32 matrix -> three bf16 planes (same shape, same ld): W once per externally written W, and any tensor a
+// caller hands in as f32.  One float4 per thread.
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split_planes_kernel(const float4* __restrict__ X, int64_t n4,
+                                                           unsigned short* __restrict__ P, int64_t plane_stride)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        store_planes4(P, plane_stride, i * 4, X[i]);
+}
+
+hipError_t launch_split_planes(const float* X, int64_t rows, int64_t ld, unsigned short* P, int64_t plane_stride, hipStream_t s)
+{
+    const int64_t n4 = rows * ld / 4;
+    if (n4 <= 0) return hipSuccess;
+    const int grid = (int)std::min<int64_t>((n4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(X), n4, P, plane_stride);
+    return hipGetLastError();
+}
+
+// minibatch gather (dbn.py:307) that also writes the rows' planes: dst f32 [n_idx][ld] + planes [3][.][ld]
+__global__ __launch_bounds__(256) void gather_planes_kernel(const float* __restrict__ src, int64_t n_rows, int64_t ld_src,
+                                                            const void* __restrict__ idx, int idx64, int64_t ld4,
+                                                            float* __restrict__ dst, int64_t ld_dst,
+                                                            unsigned short* __restrict__ P, int64_t plane_stride)
+{
+    const int64_t r = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ld4) return;
+    int64_t s = r;
+    if (idx) s = idx64 ? reinterpret_cast<const int64_t*>(idx)[r] : (int64_t)reinterpret_cast<const int32_t*>(idx)[r];
+    if (s < 0) s += n_rows;
+    s = s < 0 ? 0 : (s >= n_rows ? n_rows - 1 : s);
+    const float4 v = reinterpret_cast<const float4*>(src + s * ld_src)[c];
+    reinterpret_cast<float4*>(dst + r * ld_dst)[c] = v;
+    store_planes4(P, plane_stride, r * ld_dst + 4 * c, v);
+}
+
+hipError_t launch_gather_planes(const float* src, int64_t n_rows, int64_t cols_ld, int64_t ld_src, const void* idx, int idx64,
+                                int64_t n_idx, float* dst, int64_t ld_dst, unsigned short* P, int64_t plane_stride, hipStream_t s)
+{
+    if (n_idx <= 0) return hipSuccess;
+    if (n_idx > 65535) return hipErrorInvalidValue;
+    const int64_t ld4 = cols_ld >> 2;
+    hipLaunchKernelGGL(gather_planes_kernel, dim3((unsigned)((ld4 + 255) / 256), (unsigned)n_idx), dim3(256), 0, s, src, n_rows,
+                       ld_src, idx, idx64, ld4, dst, ld_dst, P, plane_stride);
+    return hipGetLastError();
+}
+
+}  // namespace mdbn

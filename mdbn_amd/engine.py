@@ -68,6 +68,12 @@ class CDScratch(object):
         self.hs = engine.alloc_matrix(B, H, ldh)
         self.vs = engine.alloc_matrix(B, V, ldv) if need_vs else None
         self.trace_h = self.trace_v = None      # chain taps (HipEngine.trace_chain), [k+1, B, ldh] / [k, B, ldv]
+        # bf16 plane scratch (mdbn_cd_args.planes) for shapes made of whole 128-row / 128-column tiles
+        self.planes = None
+        if engine.plane_shape(B, V, H, ldv, ldh):
+            n = C.c_int64()
+            _lib.check(engine.lib.mdbn_planes_bytes(B, ldv, ldh, C.byref(n)), "mdbn_planes_bytes")
+            self.planes = torch.empty(n.value // 2, dtype=torch.int16, device=engine.device)
 
 
 class HipEngine(object):
@@ -90,6 +96,7 @@ class HipEngine(object):
         self._cost_ring = torch.zeros(1024, dtype=torch.float32, device=self.device)
         self._cost_slot = 0
         self.last_scratch = None        # CDScratch of the most recent CD step (inspection / chain taps)
+        self._wplanes = {}              # W.data_ptr() -> [planes tensor, W._version they were valid for]
 
     def __del__(self):
         try:
@@ -205,6 +212,32 @@ class HipEngine(object):
     def _p(t):
         return C.c_void_p(t.data_ptr()) if t is not None else None
 
+    # ------------------------------------------------------------------ bf16 planes of W
+    @staticmethod
+    def plane_shape(B, V, H, ldv, ldh):
+        """Shapes the plane path of the library takes (include/mdbn_hip.h): whole 128-row / column tiles."""
+        return B > 0 and B % 128 == 0 and V % 128 == 0 and H % 128 == 0 and ldv == V and ldh == H and B <= 65535
+
+    def w_planes(self, W, create=False):
+        """(planes, valid) for a weight matrix: the [3, V, ldh] bf16 planes the library keeps in step with W, and
+        whether they hold the split of the CURRENT W.  A torch-side write to W (set_value, checkpoint load) bumps
+        the tensor's version and invalidates them; the library's own updates rewrite them."""
+        key = W.data_ptr()
+        ent = self._wplanes.get(key)
+        if ent is None or tuple(ent[0].shape[1:]) != (W.shape[0], W.stride(0)):
+            if not create:
+                return None, False
+            if len(self._wplanes) > 16:
+                self._wplanes.clear()
+            ent = [torch.empty((3, W.shape[0], W.stride(0)), dtype=torch.int16, device=self.device), None]
+            self._wplanes[key] = ent
+        return ent[0], ent[1] == W._version
+
+    def _w_planes_written(self, W):
+        ent = self._wplanes.get(W.data_ptr())
+        if ent is not None:
+            ent[1] = W._version
+
     # ------------------------------------------------------------------ propagation
     def propup(self, v, W, hbias, rng=None, want_pre=True, want_mean=True, want_sample=True):
         """[pre, mean, sample] of rbm.py:187-213; entries not wanted are None."""
@@ -319,6 +352,10 @@ class HipEngine(object):
         a.stats = stats.data_ptr()
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         a.rng = rng.c()
+        if sc.planes is not None:
+            wp, valid = self.w_planes(W, create=True)
+            a.planes, a.planes_bytes = sc.planes.data_ptr(), sc.planes.numel() * 2
+            a.W_planes, a.W_planes_valid = wp.data_ptr(), int(valid)
         if self.trace_chain:
             if sc.trace_h is None or sc.trace_h.shape[0] != k + 1:
                 sc.trace_h = torch.zeros((k + 1, B, ldh), dtype=torch.float32, device=self.device)
@@ -335,6 +372,8 @@ class HipEngine(object):
         a, stats, sc, _keep = self._cd_args(data, indexes, W, hbias, vbias, gauss, k, rng, persistent,
                                             add_noise, stats_slot, sample_stats, stats)
         _lib.check(self.lib.mdbn_cd_step(self.ctx, self._stream(), C.byref(a)), "mdbn_cd_step")
+        if a.W_planes:
+            self._w_planes_written(W)            # (split on entry if they were stale)
         return stats, sc
 
     def _update_args(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats, lr, lambda_1,
@@ -355,6 +394,8 @@ class HipEngine(object):
         u.batch_size, u.n_rows, u.cost_scale = float(batch_size), float(n_rows), float(cost_scale)
         u.cost_out = cost.data_ptr()
         u.phase = int(phase)
+        wp, _ = self.w_planes(W)
+        u.W_planes = wp.data_ptr() if wp is not None else None    # kept in step with W by every update that writes W
         return u, cost
 
     def cd_train_step(self, data, indexes, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, gauss, k,
@@ -370,6 +411,7 @@ class HipEngine(object):
                                     0, a.ldv)
         _lib.check(self.lib.mdbn_cd_train_step(self.ctx, self._stream(), C.byref(a), C.byref(u)),
                    "mdbn_cd_train_step")
+        self._w_planes_written(W)
         return cost
 
     def apply_update(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats,
@@ -381,6 +423,8 @@ class HipEngine(object):
                                     lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale,
                                     phase, ldv)
         _lib.check(self.lib.mdbn_apply_update(self.ctx, self._stream(), C.byref(u)), "mdbn_apply_update")
+        if phase != 1:
+            self._w_planes_written(W)
         return cost
 
     # ------------------------------------------------------------------ monitoring helpers (all HIP)

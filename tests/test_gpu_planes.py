@@ -1,0 +1,153 @@
+"""The bf16 plane path (csrc/mdbn_planes.hip): every tensor of the CD step split once into three bf16 planes,
+GEMMs fed by LDS-DMA with row / transposed LDS reads.  Checked: the split is exact (and what it does with
+non-finite values), the plane step equals the f32-operand step BIT FOR BIT (same products, same order), the
+planes of W stay in step with W through every update path, and the oracle comparison at the c2 / c4 shapes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rbm_np
+from oracle.philox_np import PhiloxDraws
+
+pytestmark = pytest.mark.gpu
+
+
+def planes_to_f32(P):
+    """[3, rows, ld] int16 planes -> the three f32 pieces."""
+    return [((P[i].to(torch.int32) & 0xffff) << 16).view(torch.float32) for i in range(3)]
+
+
+def split(eng, x):
+    from mdbn_amd import _lib
+    x = eng.as_matrix(x)
+    rows, ld = x.shape[0], x.stride(0)
+    P = torch.empty((3, rows, ld), dtype=torch.int16, device=eng.device)
+    base = x._base if x._base is not None else x
+    _lib.check(eng.lib.mdbn_split_planes(eng.ctx, eng._stream(), C.c_void_p(base.data_ptr()), rows, ld,
+                                         C.c_void_p(P.data_ptr())), "mdbn_split_planes")
+    return P
+
+
+def test_split_is_exact_over_the_whole_exponent_range(hip_engine):
+    rs = np.random.RandomState(0)
+    mant = rs.uniform(1, 2, (254, 64)).astype(np.float32)
+    expo = np.arange(-126, 128, dtype=np.float32)[:, None]
+    x = (mant * np.exp2(expo) * rs.choice([-1.0, 1.0], (254, 64))).astype(np.float32)
+    denorm = (rs.randint(1, 1 << 23, (2, 64)).astype(np.uint32)).view(np.float32)        # f32 subnormals
+    x = np.concatenate([x, denorm, np.zeros((1, 64), np.float32), -np.zeros((1, 64), np.float32) * -1.0])
+    xd = hip_engine.to_device(x)
+    p1, p2, p3 = planes_to_f32(split(hip_engine, xd))
+    back = (p3 + p2) + p1                       # the residuals are exact f32 values: two exact additions
+    assert torch.equal(back.cpu(), torch.from_numpy(x)), "x != p1 + p2 + p3"
+    # every piece is a bf16 (low 16 bits clear by construction) and the pieces shrink by >= 2^-8 each
+    a1, a2, a3 = [t.abs().cpu().numpy().astype(np.float64) for t in (p1, p2, p3)]
+    assert np.all(a2 <= a1 * 2.0 ** -7 + 1e-300) and np.all(a3 <= np.maximum(a2, a1 * 2.0 ** -8) * 2.0 ** -7 + 1e-300)
+
+
+def test_split_of_non_finite_values(hip_engine):
+    """+-Inf: p1 = +-Inf and the remainder Inf - Inf = NaN, so a product with such an operand comes out NaN where
+    an f32 GEMM would give +-Inf (or NaN); NaN stays NaN.  Non-finite operands are therefore never silently
+    turned into finite results; the NaN guard (StepFunction.nan_guard) is the tool to locate them."""
+    x = np.array([[np.inf, -np.inf, np.nan, 1.0]], dtype=np.float32)
+    p1, p2, p3 = [t.cpu().numpy()[0] for t in planes_to_f32(split(hip_engine, hip_engine.to_device(x)))]
+    assert p1[0] == np.inf and p1[1] == -np.inf and np.isnan(p1[2]) and p1[3] == 1.0
+    assert np.isnan(p2[0]) and np.isnan(p2[1]) and np.isnan(p2[2]) and p2[3] == 0.0 and p3[3] == 0.0
+
+
+def _run_steps(eng, gauss, planes, V, H, B, k, steps=3, seed=0):
+    import mdbn_amd
+    eng.set_option("gemm_planes", int(planes))
+    rs = np.random.RandomState(seed)
+    N = 4 * B
+    data = rs.normal(size=(N, V)).astype(np.float32) if gauss else (rs.uniform(size=(N, V)) < 0.3).astype(np.float32)
+    cls = mdbn_amd.GRBM if gauss else mdbn_amd.RBM
+    rbm = cls(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123), theano_rng=mdbn_amd.RandomStreams(5), engine=eng)
+    hp = dict(lr=0.001, lambda_2=0.1) if gauss else dict(lr=0.05, weightcost=2e-4)
+    _, up = rbm.get_cost_updates(k=k, batch_size=B, **hp)
+    fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=eng), data_parallel=None)
+    costs = [float(fn(indexes=rs.permutation(N)[:B], momentum=0.5)) for _ in range(steps)]
+    out = dict(costs=np.array(costs), W=rbm.W.get_value(), Ws=rbm.W_speed.get_value(), hb=rbm.hbias.get_value(),
+               vbs=rbm.vbias_speed.get_value())
+    wp, valid = eng.w_planes(rbm.W.tensor)
+    eng.set_option("gemm_planes", 1)
+    return out, rbm, wp, valid
+
+
+@pytest.mark.parametrize("gauss,V,H,B,k", [(True, 4096, 1024, 512, 1), (False, 1024, 512, 512, 1), (True, 1024, 768, 256, 3),
+                                           (False, 2048, 1024, 384, 2)])
+def test_plane_step_equals_f32_operand_step_bit_for_bit(hip_engine, gauss, V, H, B, k):
+    a, _, _, _ = _run_steps(hip_engine, gauss, False, V, H, B, k)
+    b, rbm, wp, valid = _run_steps(hip_engine, gauss, True, V, H, B, k)
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+    # the planes of W followed every update
+    assert wp is not None and valid
+    p1, p2, p3 = planes_to_f32(wp)
+    assert torch.equal((p3 + p2) + p1, rbm.W.tensor._base if rbm.W.tensor._base is not None else rbm.W.tensor)
+
+
+def test_w_planes_follow_every_way_w_changes(hip_engine):
+    """set_value (a torch-side write) invalidates the planes and the next step re-splits; the data-parallel update
+    phases (mdbn_apply_update 0 / 2 / 3) rewrite them; an in-library update on the f32 path does too."""
+    import mdbn_amd
+    eng = hip_engine
+    V, H, B = 1024, 512, 256
+    out, rbm, wp, valid = _run_steps(eng, True, True, V, H, B, 1, steps=2)
+    assert valid
+    rbm.W.set_value(rbm.W.get_value() * 0.5)
+    assert not eng.w_planes(rbm.W.tensor)[1]
+    data = mdbn_amd.shared(np.random.RandomState(1).normal(size=(2 * B, V)).astype(np.float32), engine=eng)
+    _, up = rbm.get_cost_updates(lr=0.001, k=1, lambda_2=0.1, batch_size=B)
+    fn = mdbn_amd.function(up, data, data_parallel=None)
+    fn(indexes=np.arange(B), momentum=0.0)
+
+    def in_step():
+        wp, valid = eng.w_planes(rbm.W.tensor)
+        p1, p2, p3 = planes_to_f32(wp)
+        return valid and torch.equal((p3 + p2) + p1, rbm.W.tensor)
+    assert in_step()
+    # the statistics + separate update path (what a data-parallel rank runs), every phase that writes W
+    from mdbn_amd import RngAddr
+    stats, _ = eng.cd_step(data.tensor, torch.arange(B, device=eng.device), rbm.W.tensor, rbm.hbias.tensor, rbm.vbias.tensor,
+                           True, 1, RngAddr(1, 0, 7, 0, 0))
+    for phase in (0, 2, 1, 3):
+        eng.apply_update(rbm.W.tensor, rbm.W_speed.tensor, None, rbm.hbias.tensor, rbm.hbias_speed.tensor, rbm.vbias.tensor,
+                         rbm.vbias_speed.tensor, stats, 0.001, 0.0, 0.1, 0.0, 0.5, B, B, 1.0, phase=phase, ldv=V)
+        assert in_step(), phase
+    # f32-operand path with planes present: the fused update still rewrites them
+    eng.set_option("gemm_planes", 0)
+    fn(indexes=np.arange(B) + B, momentum=0.0)
+    eng.set_option("gemm_planes", 1)
+    assert in_step()
+
+
+def test_plane_step_against_oracle_teacher_forced(hip_engine):
+    """One CD-2 step of a Bernoulli RBM on the plane path with the chain taps on, oracle following the device."""
+    from mdbn_amd import RngAddr
+    V, H, B, k = 1024, 512, 256, 2
+    rs = np.random.RandomState(3)
+    W = rbm_np.init_W(rs, V, H, np.float32)
+    hb, vb = rs.normal(0, 0.2, H).astype(np.float32), rs.normal(0, 0.2, V).astype(np.float32)
+    x = (rs.uniform(size=(B, V)) < 0.3).astype(np.float32)
+    eng = hip_engine
+    dW, dhb, dvb, dx = [eng.to_device(a) for a in (W, hb, vb, x)]
+    eng.trace_chain = True
+    try:
+        stats, sc = eng.cd_step(dx, None, dW, dhb, dvb, False, k, RngAddr(11, 1, 2, 0, 0))
+        assert sc.planes is not None
+        th, tv = sc.trace_h.cpu().numpy(), sc.trace_v.cpu().numpy()
+    finally:
+        eng.trace_chain = False
+    st = rbm_np.RBMState(V, H, W=W, hbias=hb, vbias=vb, gauss=False)
+    v0 = x.astype(np.float64)
+    ph, _, out, flips = rbm_np.cd_chain_forced(st, v0, PhiloxDraws(11, 1, 2, 0), k, th, tv)
+    S_o, s_h_o, s_v_o = rbm_np.cd_statistics(v0, ph, out[1], out[4])
+    d = stats.cpu().numpy()
+    S, s_h, s_v = d[:V * H].reshape(V, H), d[V * H:V * H + H], d[V * H + H:V * H + H + V]
+    assert np.abs(S - S_o).max() <= 1e-5 * np.abs(S_o).max()
+    assert np.abs(s_h - s_h_o).max() <= 1e-5 * max(1.0, np.abs(s_h_o).max())
+    assert np.abs(s_v - s_v_o).max() <= 1e-5 * max(1.0, np.abs(s_v_o).max())
+    assert np.abs(sc.P2[:B].cpu().numpy() - ph).max() <= 2e-6
+    assert flips <= 3
