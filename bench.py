@@ -174,13 +174,16 @@ def kernel_breakdown(detail):
     rows = {}
     for kind, v in sorted(groups.items()):
         p = (kind // 100) % 10
-        name = KIND_NAMES.get(kind % 10, "gemm%d" % (kind % 10)) + ("" if kind < 1000 else "_streaming")
+        family = {0: "", 1: "_streaming", 2: "_planes"}.get(kind // 1000, "_%d" % (kind // 1000))
+        name = KIND_NAMES.get(kind % 10, "gemm%d" % (kind % 10)) + family
         t = sum(x[0] for x in v) * 1e-3
         alg, pipe = sum(x[1] for x in v), sum(x[2] for x in v)
         peak = MFMA_BF16_PEAK_TFLOPS if p else MFMA_F32_PEAK_TFLOPS
         key = name if name not in rows else "%s_%d" % (name, kind)
         rows[key] = {"launches": len(v), "avg_us": 1e6 * t / len(v),
                      "pipe": ("bf16 MFMA, %d products per algorithmic product" % (6 if p == 1 else 3)) if p else "f32 MFMA",
+                     "kernel": {0: "gemm_bf16x6_kernel / gemm_splitk_kernel (f32 operands in HBM)", 1: "skinny_gemm_kernel",
+                                2: "gemm_planes_kernel (pre-split bf16 planes, LDS-DMA)"}.get(kind // 1000, "?"),
                      "issued_tflops": pipe / t / 1e12, "pipe_peak_tflops": peak, "frac_of_pipe": pipe / t / 1e12 / peak,
                      "algorithmic_f32_tflops": alg / t / 1e12, "fused_epilogue": (kind // 10) % 10}
     return rows
@@ -295,6 +298,7 @@ def main():
     exact_rows = None
     if world == 1:
         eng.set_option("gemm_bf16x6", 0)
+        eng.set_option("gemm_planes", 0)
         run(args.warmup, 0)
         ewins, _, _ = measure(args.warmup)
         exact_ms = 1e3 * float(np.median(ewins)) / args.steps
@@ -304,6 +308,7 @@ def main():
         exact_rows = kernel_breakdown(eng.kernel_timing_detail())
         eng.kernel_timing(False)
         eng.set_option("gemm_bf16x6", 3)
+        eng.set_option("gemm_planes", 1)
 
     # free-energy parity of the trained model vs the float64 oracle (north star: <= 1e-4 rel)
     fe_rel = fe_rel_elem = None

@@ -163,7 +163,8 @@ int  mdbn_kernel_timing(mdbn_ctx *ctx, int enable);
 int  mdbn_kernel_timing_read(mdbn_ctx *ctx, int64_t *n_launches, double *total_ms);
 /* Per recorded launch (up to `cap`): duration, algorithmic FLOPs 2*M*N*K, FLOPs issued on the matrix
  * pipe the kernel runs on (x6 / x3 for the split-operand bf16 kernels), and
- * kind = 1000*skinny + 100*pipe (0 exact-f32 MFMA, 1 bf16 six products, 2 bf16 three products)
+ * kind = 1000*family (0 LDS-tiled, f32 operands; 1 register-streaming; 2 bf16 planes)
+ *        + 100*pipe (0 exact-f32 MFMA, 1 bf16 six products, 2 bf16 three products)
  *        + 10*fused + 2*la + lb  ((la, lb): 1 = propup, 0 = propdown, 3 = statistics).
  * *n_launches receives the number recorded (may exceed cap). */
 int  mdbn_kernel_timing_detail(mdbn_ctx *ctx, int64_t cap, double *ms, double *alg_flop,
@@ -204,6 +205,19 @@ int  mdbn_propdown_sample(mdbn_ctx *ctx, void *stream, const float *h, int64_t B
                           int gauss, int add_noise, float *pre, float *mean, float *sample,
                           const mdbn_rng *rng, const float *v0, float *cost_sum,
                           void *workspace, int64_t workspace_bytes);
+
+/* n_steps of gibbs_vhv (src/rbm.py:250-256; GRBM :673-682) in one call, in place and without allocation: the
+ * sampling loop of src/rbm.py:806-865 (theano.scan over gibbs_vhv, 500 steps x 20 chains).  v [B, ldv] holds
+ * the chain's visible state on entry and vis_samples[-1] on return; h_mean / h_sample [B, ldh] and v_mean
+ * [B, ldv] are scratch during the chain and the LAST step's values on return (pre_h / pre_v: optional).
+ * Random draws: step t (0-based) uses rng->step + 2t for the hidden and rng->step + 2t + 1 for the visible
+ * draw, both with draw index 0 -- exactly what 2 * n_steps eager sample_* calls consume, so a chain equals
+ * n_steps eager gibbs_vhv calls bit for bit; the caller advances its step counter by 2 * n_steps. */
+int  mdbn_gibbs_chain(mdbn_ctx *ctx, void *stream, float *v, int64_t B, int64_t ldv, const float *W,
+                      int64_t V, int64_t H, int64_t ldh, const float *hbias, const float *vbias, int gauss,
+                      int add_noise, int64_t n_steps, float *pre_h, float *h_mean, float *h_sample,
+                      float *pre_v, float *v_mean, const mdbn_rng *rng, void *workspace,
+                      int64_t workspace_bytes);
 
 /* compute_rbm_grad's products (src/rbm.py:411-417) from the stacked buffers of mdbn_cd_args:
  * stats = [S = v0'ph - nv'nh | s_h | s_v | (cost untouched)] */

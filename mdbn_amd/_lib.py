@@ -69,6 +69,8 @@ SIGNATURES = {
                            _vp, _vp, _f32, _vp, _rngp, _vp, _i64],
     "mdbn_propdown_sample": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i32, _i32,
                              _vp, _vp, _vp, _rngp, _vp, _vp, _vp, _i64],
+    "mdbn_gibbs_chain": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i32, _i32, _i64,
+                         _vp, _vp, _vp, _vp, _vp, _rngp, _vp, _i64],
     "mdbn_cd_stats": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _i64],
     "mdbn_apply_update": [_vp, _vp, C.POINTER(UpdateArgs)],
     "mdbn_cd_step": [_vp, _vp, C.POINTER(CdArgs)],

@@ -911,6 +911,48 @@ int mdbn_propdown_sample(mdbn_ctx* ctx, void* stream, const float* h, int64_t B,
     return MDBN_OK;
 }
 
+int mdbn_gibbs_chain(mdbn_ctx* ctx, void* stream, float* v, int64_t B, int64_t ldv, const float* W, int64_t V, int64_t H,
+                     int64_t ldh, const float* hbias, const float* vbias, int gauss, int add_noise, int64_t n_steps,
+                     float* pre_h, float* h_mean, float* h_sample, float* pre_v, float* v_mean, const mdbn_rng* rng,
+                     void* workspace, int64_t workspace_bytes)
+{
+    REQUIRE(ctx != nullptr && rng != nullptr, "NULL argument");
+    REQUIRE(B > 0 && V > 0 && H > 0 && n_steps >= 1, "bad shape / step count");
+    CHECK(check_mat(v, ldv, V, "v"));
+    CHECK(check_mat(W, ldh, H, "W"));
+    CHECK(check_mat(h_mean, ldh, H, "h_mean"));
+    CHECK(check_mat(h_sample, ldh, H, "h_sample"));
+    CHECK(check_mat(v_mean, ldv, V, "v_mean"));
+    REQUIRE(hbias && vbias, "bias pointers are NULL");
+    REQUIRE((pre_h == nullptr || aligned16(pre_h)) && (pre_v == nullptr || aligned16(pre_v)), "pre outputs not aligned");
+    Workspace ws;
+    CHECK(carve(workspace, workspace_bytes, B, V, H, ws, false));
+    hipStream_t s = (hipStream_t)stream;
+    const bool noisy = gauss && add_noise;
+    for (int64_t t = 0; t < n_steps; ++t) {
+        const bool last = t + 1 == n_steps;
+        mdbn_rng rh = *rng, rv = *rng;
+        rh.step = rng->step + (uint32_t)(2 * t);     rh.draw = 0;      // what 2 * n_steps eager sample_* calls would use
+        rv.step = rng->step + (uint32_t)(2 * t + 1); rv.draw = 0;
+        // h | v: RBM feeds the SAMPLE on, GRBM the MEAN (rbm.py:253-254, :680)
+        const bool need_mean = gauss || last;
+        Affine up{v, B, ldv, W, V, H, ldh, 0, hbias, last ? pre_h : nullptr, need_mean ? h_mean : nullptr,
+                  (!gauss || last) ? h_sample : nullptr, ldh, 1.0f, 0, nullptr, 0, false, &rh, 0u};
+        up.x_binary = !gauss && t > 0;              // from the second step on v holds our own 0/1 samples
+        CHECK(run_affine(up, ws, s, nullptr));
+        // v | h: the chain state v becomes the visible SAMPLE (RBM: Bernoulli; GRBM: mean, + N(0,1) if noisy)
+        Affine down{gauss ? h_mean : h_sample, B, ldh, W, V, H, ldh, 1, vbias, (last && !gauss) ? pre_v : nullptr,
+                    (gauss && !noisy) ? v : ((last || noisy) ? v_mean : nullptr), (!gauss || noisy) ? v : nullptr,
+                    ldv, 1.0f, gauss, nullptr, 0, false, &rv, 0u};
+        down.x_binary = !gauss;
+        CHECK(run_affine(down, ws, s, nullptr));
+    }
+    // noise-free GRBM: sample == mean (rbm.py:652-653); the chain state is the mean itself
+    if (gauss && !noisy) HIP_OK(hipMemcpyAsync(v_mean, v, sizeof(float) * B * ldv, hipMemcpyDeviceToDevice, s));
+    if (gauss && pre_v) HIP_OK(hipMemcpyAsync(pre_v, v_mean, sizeof(float) * B * ldv, hipMemcpyDeviceToDevice, s));
+    return MDBN_OK;
+}
+
 int mdbn_cd_stats(mdbn_ctx* ctx, void* stream, const float* V2, const float* P2, int64_t B, int64_t V,
                   int64_t H, int64_t ldv, int64_t ldh, float* stats, void* workspace, int64_t workspace_bytes)
 {

@@ -295,6 +295,30 @@ class HipEngine(object):
             return pre, mean, sample, cost[0]
         return pre, mean, sample
 
+    def gibbs_chain(self, v, W, hbias, vbias, gauss, n_steps, rng, add_noise=False, want_pre=True):
+        """n_steps of gibbs_vhv from the visible state ``v`` in ONE library call (mdbn_gibbs_chain): returns
+        [pre_h, h_mean, h_sample, pre_v, v_mean, v_sample] of the last step; ``v`` itself is not modified."""
+        v = self.as_matrix(v)
+        B, V = v.shape
+        H = W.shape[1]
+        ldh = W.stride(0)
+        state = self.alloc_matrix(B, V, v.stride(0))
+        state.copy_(v)
+        h_mean, h_sample = self.alloc_matrix(B, H, ldh), self.alloc_matrix(B, H, ldh)
+        v_mean = self.alloc_matrix(B, V, v.stride(0))
+        pre_h = self.alloc_matrix(B, H, ldh) if want_pre else None
+        pre_v = self.alloc_matrix(B, V, v.stride(0)) if want_pre else None
+        if B == 0:
+            return [pre_h, h_mean, h_sample, pre_v, v_mean, state]
+        ws = self.workspace(min(B, 4096), V, H)
+        r = rng.c()
+        _lib.check(self.lib.mdbn_gibbs_chain(
+            self.ctx, self._stream(), self._p(state), B, state.stride(0), self._p(W), V, H, ldh, self._p(hbias),
+            self._p(vbias), int(bool(gauss)), int(bool(add_noise)), int(n_steps), self._p(pre_h), self._p(h_mean),
+            self._p(h_sample), self._p(pre_v), self._p(v_mean), C.byref(r), self._p(ws), ws.numel() * 4),
+            "mdbn_gibbs_chain")
+        return [pre_h, h_mean, h_sample, pre_v, v_mean, state]
+
     def free_energy(self, x, W, hbias, vbias, gauss):
         x = self.as_matrix(x)
         N, V = x.shape

@@ -398,6 +398,36 @@ class RBM(object):
         return [pre_sigmoid_h1, h1_mean, h1_sample,
                 pre_sigmoid_v1, v1_mean, v1_sample]
 
+    def gibbs_vhv_chain(self, v0_sample, n_steps):
+        """``n_steps`` of ``gibbs_vhv`` as ONE device call (the ``theano.scan`` over gibbs_vhv of rbm.py:822-838):
+        the six outputs of the LAST step, identical bit for bit to calling ``gibbs_vhv`` ``n_steps`` times,
+        without the per-step allocations and launches' host overhead.  Consumes 2 * n_steps RNG steps."""
+        step = self._rng_step
+        self._rng_step += 2 * int(n_steps)
+        if not hasattr(self.engine, "gibbs_chain"):          # checker engine: compose the eager steps
+            self._rng_step = step
+            out, v = None, v0_sample
+            for _ in range(int(n_steps)):
+                out = self.gibbs_vhv(v)
+                v = out[5]
+            return out
+        out = self.engine.gibbs_chain(as_tensor(v0_sample, self.engine), self.W.tensor, self.hbias.tensor,
+                                      self.vbias.tensor, self.gauss, int(n_steps),
+                                      RngAddr(self.theano_rng.seed, self.stream_id, step, 0, 0),
+                                      add_noise=self.gauss and not getattr(self, "error_free", True))
+        return [self._wrap(t) for t in out]
+
+    def make_sample_fn(self, persistent_vis_chain, n_steps=500):
+        """The ``sample_fn`` of rbm.py:844-853: each call runs ``n_steps`` Gibbs steps from the persistent visible
+        chain, stores ``vis_samples[-1]`` back into it and returns ``(vis_mfs[-1], vis_samples[-1])`` as host arrays."""
+        chain = shared(persistent_vis_chain, engine=self.engine)
+
+        def sample_fn():
+            out = self.gibbs_vhv_chain(chain, n_steps)
+            chain.set_value(out[5])
+            return out[4].get_value(), out[5].get_value()
+        return sample_fn
+
     # ------------------------------------------------------------------ CD-k / PCD-k
     def get_cost_updates(self, lr=0.1, k=1, lambda_1=0.0, lambda_2=0.0, weightcost=0.0,
                          batch_size=None, persistent=None, symbolic_grad=False):

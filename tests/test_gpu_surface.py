@@ -292,3 +292,54 @@ def test_nan_guard_raises_on_divergence(hip_engine):
     with pytest.raises(FloatingPointError):
         for t in range(200):
             fn(indexes=np.arange(B) + B * (t % 4), momentum=0.0)
+
+
+@pytest.mark.parametrize("gauss", [False, True])
+def test_gibbs_chain_call_equals_eager_steps_and_oracle(hip_engine, gauss):
+    """The sampling loop of rbm.py:806-865 (20 chains, 500 gibbs_vhv steps, 784 -> 500) as ONE library call:
+    bit-identical to 500 eager gibbs_vhv calls, which are themselves checked against the oracle at EVERY step
+    (the oracle recomputes each half-step from the device's previous state: teacher forcing)."""
+    import mdbn_amd
+    V, H, B, n = 784, 500, 20, 500
+    rs = np.random.RandomState(0)
+    cls = mdbn_amd.GRBM if gauss else mdbn_amd.RBM
+
+    def make():
+        r = cls(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123), theano_rng=mdbn_amd.RandomStreams(77),
+                engine=hip_engine)
+        r.hbias.set_value(np.random.RandomState(1).normal(0, 0.1, H).astype(np.float32))
+        r.vbias.set_value(np.random.RandomState(2).normal(0, 0.1, V).astype(np.float32))
+        r.W.set_value((0.3 * r.W.get_value()).astype(np.float32))
+        return r
+    v0 = rs.normal(size=(B, V)).astype(np.float32) if gauss else (rs.uniform(size=(B, V)) < 0.2).astype(np.float32)
+    a, b = make(), make()
+    st = rbm_np.RBMState(V, H, W=a.W.get_value(), hbias=a.hbias.get_value(), vbias=a.vbias.get_value(), gauss=gauss)
+    out_chain = [t.get_value() for t in a.gibbs_vhv_chain(v0, n)]
+    assert a._rng_step == 2 * n
+    v, worst_h, worst_v, flips = v0, 0.0, 0.0, 0
+    for t in range(n):
+        out = [x.get_value() for x in b.gibbs_vhv(v)]
+        # oracle, from the device's state of the previous step
+        _, o_h_mean = rbm_np.propup(st, v.astype(np.float64))
+        worst_h = max(worst_h, np.abs(out[1] - o_h_mean).max())
+        u = philox_np.uniform(B, H, 77, b.stream_id, 2 * t, 0, 0)
+        bad = out[2] != (u < o_h_mean)
+        assert np.all(np.abs(u - o_h_mean)[bad] < 1e-6)
+        flips += int(bad.sum())
+        h_in = out[1] if gauss else out[2]
+        uv = philox_np.uniform(B, V, 77, b.stream_id, 2 * t + 1, 0, 0)
+        _, o_v_mean, _ = rbm_np.sample_v_given_h(st, h_in.astype(np.float64), uv)
+        worst_v = max(worst_v, np.abs(out[4] - o_v_mean).max() / max(1.0, np.abs(o_v_mean).max()))
+        if not gauss:
+            badv = out[5] != (uv < o_v_mean)
+            assert np.all(np.abs(uv - o_v_mean)[badv] < 1e-6)
+            flips += int(badv.sum())
+        v = out[5]
+    assert worst_h <= 2e-6 and worst_v <= 4e-6, (worst_h, worst_v)
+    for got, want in zip(out_chain, out):
+        assert np.array_equal(got, want)                       # one call == 500 eager calls, bit for bit
+    # the reference's sample_fn protocol on top of it
+    fn = a.make_sample_fn(v0, n_steps=7)
+    mf, smp = fn()
+    mf2, smp2 = fn()
+    assert mf.shape == (B, V) and not np.array_equal(smp, smp2) or gauss

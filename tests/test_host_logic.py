@@ -278,3 +278,22 @@ def test_nan_guard_on_checker_engine(oracle_engine):
     with np.errstate(all="ignore"), pytest.raises(FloatingPointError):
         for t in range(1000):                # |W| grows ~4x per step: float64 overflows after ~450
             fn(indexes=np.arange(B) + B * (t % 4), momentum=0.0)
+
+
+def test_gibbs_chain_composes_eager_steps_on_checker_engine(oracle_engine):
+    V, H, B = 9, 6, 4
+    rs = np.random.RandomState(0)
+    a = RBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(5), theano_rng=RandomStreams(3))
+    b = RBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(5), theano_rng=RandomStreams(3))
+    v0 = (rs.uniform(size=(B, V)) < 0.4).astype(np.float64)
+    out = a.gibbs_vhv_chain(v0, 5)
+    v = v0
+    for _ in range(5):
+        ref = b.gibbs_vhv(v)
+        v = ref[5]
+    assert a._rng_step == b._rng_step == 10
+    for x, y in zip(out, ref):
+        assert np.array_equal(x.get_value(), y.get_value())
+    fn = a.make_sample_fn(v0, n_steps=3)
+    mf, smp = fn()
+    assert mf.shape == (B, V) and set(np.unique(smp)) <= {0.0, 1.0}
