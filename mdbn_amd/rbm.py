@@ -177,13 +177,15 @@ class StepFunction(object):
         step = rbm._take_step()
         persistent = None
         if p.persistent is not None:
-            if distributed:
-                raise NotImplementedError("PCD chains are not sharded across ranks yet")
             persistent = p.persistent.tensor
             if persistent.shape[0] != n_global:
                 raise ValueError("persistent chain has %d rows but the minibatch has %d "
                                  "(the reference fails the same way, rbm.py:416)"
                                  % (persistent.shape[0], n_global))
+            if distributed:
+                # PCD under data parallelism: chain row g belongs to the rank that owns minibatch row g
+                # (rbm.py:308-311,369); a rank only ever reads and writes its own rows of the chain
+                persistent = persistent[lo:hi]
         if not distributed and p.persistent is None and hi > lo:
             # single device: the whole step function in one library call (mdbn_cd_train_step)
             cost_scale = 1.0 / (n_global * rbm.n_visible) if rbm.gauss else 1.0 / n_global
@@ -213,8 +215,18 @@ class StepFunction(object):
 
         if p.persistent is not None:
             # PCD monitors the pseudo-likelihood (rbm.py:371) with pre-update parameters
-            cost = rbm._pseudo_likelihood_value(eng.gather_rows(data, idx) if idx is not None else data)
+            if hi > lo:
+                cost = rbm._pseudo_likelihood_value(eng.gather_rows(data, idx) if idx is not None else data)
+            else:
+                cost = None
+                rbm.bit_i_idx = (rbm.bit_i_idx + 1) % rbm.n_visible
             cost_scale = 0.0
+            if distributed:
+                # a mean over rows: every rank contributes (its mean * its rows) through the cost slot of the
+                # statistics buffer, the update kernel divides the all-reduced sum by the global row count
+                slot_idx = rbm.n_visible * rbm.W.tensor.stride(0) + rbm.W.tensor.stride(0) + data.stride(0)
+                stats[slot_idx] = cost * float(hi - lo) if cost is not None else 0.0
+                cost, cost_scale = None, 1.0 / n_global
         else:
             cost = None
             # rbm.py:480 (sum over units, mean over rows) / rbm.py:697 (mean over everything)

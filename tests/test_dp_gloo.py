@@ -59,6 +59,26 @@ def run_steps(gauss, overlap, group_mode):
                 mid=mid_speed, costs=np.array(costs))
 
 
+def run_pcd(group_mode):
+    """PCD-2 with the persistent chain sharded by global row (rbm.py:308-311,369) and the pseudo-likelihood
+    monitor summed over ranks."""
+    import mdbn_amd
+    from _oracle_engine import OracleEngine
+    eng = mdbn_amd.set_engine(OracleEngine())
+    V, H, data, _ = make_problem(0)
+    rs = np.random.RandomState(3)
+    batches = [rs.permutation(len(data))[:9].astype(np.int64) for _ in range(5)]      # 9 rows: ragged over 2 ranks
+    rbm = mdbn_amd.RBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(5),
+                       theano_rng=mdbn_amd.RandomStreams(11), engine=eng)
+    chain = mdbn_amd.shared(np.zeros((9, H)), engine=eng)
+    _, up = rbm.get_cost_updates(lr=0.05, k=2, batch_size=9, weightcost=2e-4, persistent=chain)
+    fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=eng), data_parallel="auto" if group_mode else None)
+    costs = [float(fn(indexes=b, momentum=0.5)) for b in batches]
+    lo, hi = fn.group.shard(9) if fn.group is not None else (0, 9)
+    return dict(W=rbm.W.tensor.numpy().copy(), Ws=rbm.W_speed.tensor.numpy().copy(), costs=np.array(costs),
+                chain=chain.tensor.numpy().copy(), span=np.array([lo, hi]), bit=np.array([rbm.bit_i_idx]))
+
+
 def run_interleaved(overlap, group_mode):
     """Two step functions of the SAME shape (two equal-sized modalities) called alternately: with the
     all-reduce of each deferred by one call, neither may see the other's pending statistics."""
@@ -94,7 +114,10 @@ def worker(rank, world, port, outdir, gauss, overlap):
     torch.set_num_threads(1)
     from mdbn_amd import dist
     dist.init_from_env(backend="gloo")
-    out = run_interleaved(overlap, True) if gauss == 2 else run_steps(gauss, overlap, True)
+    if gauss == 3:
+        out = run_pcd(True)
+    else:
+        out = run_interleaved(overlap, True) if gauss == 2 else run_steps(gauss, overlap, True)
     np.savez(os.path.join(outdir, "rank%d_%d_%d.npz" % (rank, gauss, overlap)), **out)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -104,8 +127,8 @@ def worker(rank, world, port, outdir, gauss, overlap):
 def dp_results():
     res = {}
     with tempfile.TemporaryDirectory() as d:
-        for gauss in (1, 0, 2):             # 2 = the two-step-function interleaving case
-            for overlap in (0, 1):
+        for gauss in (1, 0, 2, 3):          # 2 = two step functions interleaved, 3 = PCD (synchronous only)
+            for overlap in ((0,) if gauss == 3 else (0, 1)):
                 mp.spawn(worker, args=(2, free_port(), d, gauss, overlap), nprocs=2, join=True)
                 res[(gauss, overlap)] = [dict(np.load(os.path.join(d, "rank%d_%d_%d.npz" % (r, gauss, overlap))))
                                          for r in range(2)]
@@ -138,6 +161,19 @@ def test_two_step_functions_of_equal_shape_do_not_share_pending_statistics(dp_re
         assert np.array_equal(sync[0][k], ovl[0][k]), k                 # overlapped == synchronous, bit for bit
         assert np.array_equal(ovl[0][k], ovl[1][k]), k                  # replicas agree
         np.testing.assert_allclose(ovl[0][k], single[k], rtol=1e-11, atol=1e-13, err_msg=k)
+
+
+def test_pcd_under_data_parallelism(dp_results):
+    sys.path.insert(0, HERE)
+    single = run_pcd(False)
+    r0, r1 = dp_results[(3, 0)]
+    for k in ("W", "Ws", "costs", "bit"):
+        assert np.array_equal(r0[k], r1[k]), k                        # replicas agree
+        np.testing.assert_allclose(r0[k], single[k], rtol=1e-11, atol=1e-13, err_msg=k)
+    # every rank holds the true chain on the rows it owns
+    for r in (r0, r1):
+        lo, hi = r["span"]
+        assert hi > lo and np.array_equal(r["chain"][lo:hi], single["chain"][lo:hi])
 
 
 def test_shard_bounds():
