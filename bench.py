@@ -369,7 +369,8 @@ def main():
         "distributed": {"ranks": world, "backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
                         "per_rank_ms_per_step": rank_ms, "allreduce_alone_us": allreduce_us,
                         "allreduce_bytes": 4 * (V * H + H + V + 4) if world > 1 else 0,
-                        "overlap": bool(getattr(step_fn, "overlap", False))},
+                        "overlap": bool(getattr(step_fn, "overlap", False)),
+                        "collective": step_fn.group.collective if getattr(step_fn, "group", None) is not None else None},
         # achieved = FLOPs ISSUED on the matrix pipe the GEMM kernels execute on (six / three bf16 products per
         # algorithmic f32 product), summed over the step's GEMM launches, / their summed HIP-event durations;
         # peak = that pipe's dense peak.  `kernels` has the same per GEMM; the f32-equivalent (algorithmic)

@@ -206,6 +206,17 @@ int  mdbn_propdown_sample(mdbn_ctx *ctx, void *stream, const float *h, int64_t B
                           const mdbn_rng *rng, const float *v0, float *cost_sum,
                           void *workspace, int64_t workspace_bytes);
 
+/* Data parallelism (added by this engine; the reference is single-process): one process per GPU, minibatch rows
+ * sharded over the ranks, ONE sum all-reduce of the packed statistics per CD step over RCCL / xGMI.
+ * mdbn_comm_unique_id fills 128 bytes on one rank (ncclGetUniqueId); the caller hands them to every rank (any
+ * channel: torch.distributed's store, a file) and each calls mdbn_comm_init_rank (ncclCommInitRank) on its
+ * context.  mdbn_allreduce_stats enqueues the in-place float32 sum of stats[0..n) on `stream`; like every entry
+ * point it does not synchronise.  librccl.so is opened on first use. */
+int  mdbn_comm_unique_id(char *id128);
+int  mdbn_comm_init_rank(mdbn_ctx *ctx, const char *id128, int nranks, int rank);
+int  mdbn_allreduce_stats(mdbn_ctx *ctx, void *stream, float *stats, int64_t n);
+int  mdbn_comm_destroy(mdbn_ctx *ctx);
+
 /* n_steps of gibbs_vhv (src/rbm.py:250-256; GRBM :673-682) in one call, in place and without allocation: the
  * sampling loop of src/rbm.py:806-865 (theano.scan over gibbs_vhv, 500 steps x 20 chains).  v [B, ldv] holds
  * the chain's visible state on entry and vis_samples[-1] on return; h_mean / h_sample [B, ldh] and v_mean

@@ -69,6 +69,10 @@ SIGNATURES = {
                            _vp, _vp, _f32, _vp, _rngp, _vp, _i64],
     "mdbn_propdown_sample": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i32, _i32,
                              _vp, _vp, _vp, _rngp, _vp, _vp, _vp, _i64],
+    "mdbn_comm_unique_id": [C.c_char_p],
+    "mdbn_comm_init_rank": [_vp, C.c_char_p, _i32, _i32],
+    "mdbn_allreduce_stats": [_vp, _vp, _vp, _i64],
+    "mdbn_comm_destroy": [_vp],
     "mdbn_gibbs_chain": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i32, _i32, _i64,
                          _vp, _vp, _vp, _vp, _vp, _rngp, _vp, _i64],
     "mdbn_cd_stats": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _i64],

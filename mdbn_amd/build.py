@@ -88,7 +88,7 @@ def build_lib(force=False, verbose=False):
         if os.path.join(objdir, old) not in objs and old.endswith(".o"):
             os.remove(os.path.join(objdir, old))
     tmp = LIB + ".tmp%d" % os.getpid()
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, cwd=CSRC, check=True)

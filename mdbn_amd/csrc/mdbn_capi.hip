@@ -2,6 +2,7 @@
 // planning, workspace carving and the launch sequence of one CD-k step.  No allocation,
 // no synchronisation: every entry point only enqueues kernels on the caller's stream.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -16,6 +17,8 @@ using namespace mdbn;
 struct mdbn_ctx {
     int device;
     int num_cu;
+    void* comm = nullptr;      // ncclComm_t of mdbn_comm_init_rank (RCCL), or NULL
+    int comm_ranks = 0;
     // side stream + events for mdbn_cd_train_step (memory-bound update work overlapped with the
     // compute-bound statistics GEMM); created on first use
     hipStream_t side = nullptr;
@@ -681,12 +684,15 @@ int mdbn_ctx_create(mdbn_ctx** out, int device)
     return MDBN_OK;
 }
 
+int mdbn_comm_destroy(mdbn_ctx* ctx);
+
 int mdbn_ctx_destroy(mdbn_ctx* ctx)
 {
     if (ctx) {
         if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
         if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
         if (ctx->side) (void)hipStreamDestroy(ctx->side);
+        if (ctx->comm) (void)mdbn_comm_destroy(ctx);
     }
     delete ctx;
     return MDBN_OK;
@@ -908,6 +914,86 @@ int mdbn_propdown_sample(mdbn_ctx* ctx, void* stream, const float* h, int64_t B,
     if (cost_sum)
         HIP_OK(launch_finalize_stats(nullptr, nullptr, nullptr, 0, 0, 0, ws.cost_partials, n_cost, nullptr,
                                      nullptr, cost_sum, nullptr, s));
+    return MDBN_OK;
+}
+
+// ---------------------------------------------------------------------------------- RCCL (data parallelism)
+// librccl is opened lazily: the library loads and every single-device entry point works without it.
+namespace {
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    void* CommInitRank = nullptr;          // ncclCommInitRank(ncclComm_t*, int, ncclUniqueId BY VALUE, int)
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+struct NcclId { char internal[128]; };
+
+int rccl_load()
+{
+    if (g_rccl.h) return MDBN_OK;
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(MDBN_EHIP, "cannot open librccl.so: %s", dlerror());
+    g_rccl.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclAllReduce"));
+    g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
+    g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(h, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(MDBN_EHIP, "librccl.so lacks an expected symbol");
+    g_rccl.h = h;
+    return MDBN_OK;
+}
+#define RCCL_OK(expr)                                                                          \
+    do {                                                                                       \
+        int _r = (expr);                                                                       \
+        if (_r != 0)                                                                           \
+            return fail(MDBN_EHIP, "%s failed: %s", #expr, g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "?"); \
+    } while (0)
+}  // namespace
+
+int mdbn_comm_unique_id(char* id128)
+{
+    REQUIRE(id128 != nullptr, "id buffer is NULL");
+    CHECK(rccl_load());
+    RCCL_OK(g_rccl.GetUniqueId(id128));
+    return MDBN_OK;
+}
+
+int mdbn_comm_init_rank(mdbn_ctx* ctx, const char* id128, int nranks, int rank)
+{
+    REQUIRE(ctx != nullptr && id128 != nullptr && nranks >= 1 && rank >= 0 && rank < nranks, "bad arguments");
+    REQUIRE(ctx->comm == nullptr, "this context already has a communicator");
+    CHECK(rccl_load());
+    HIP_OK(hipSetDevice(ctx->device));
+    typedef int (*init_fn)(void**, int, NcclId, int);          // ncclUniqueId is passed BY VALUE
+    NcclId id;
+    memcpy(id.internal, id128, 128);
+    RCCL_OK(reinterpret_cast<init_fn>(g_rccl.CommInitRank)(&ctx->comm, nranks, id, rank));
+    ctx->comm_ranks = nranks;
+    return MDBN_OK;
+}
+
+int mdbn_allreduce_stats(mdbn_ctx* ctx, void* stream, float* stats, int64_t n)
+{
+    REQUIRE(ctx != nullptr && ctx->comm != nullptr, "no communicator: call mdbn_comm_init_rank first");
+    REQUIRE(stats != nullptr && n > 0, "bad arguments");
+    // in place, float32 (ncclFloat32 = 7), sum (ncclSum = 0): the packed [S | s_h | s_v | cost] buffer of one CD step
+    RCCL_OK(g_rccl.AllReduce(stats, stats, (size_t)n, 7, 0, ctx->comm, (hipStream_t)stream));
+    return MDBN_OK;
+}
+
+int mdbn_comm_destroy(mdbn_ctx* ctx)
+{
+    REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (ctx->comm) {
+        RCCL_OK(g_rccl.CommDestroy(ctx->comm));
+        ctx->comm = nullptr;
+        ctx->comm_ranks = 0;
+    }
     return MDBN_OK;
 }
 

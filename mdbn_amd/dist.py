@@ -8,23 +8,82 @@ import torch
 import torch.distributed as td
 
 
+class _StreamWork(object):
+    """Handle of a collective enqueued on a side HIP stream: ``wait()`` makes the CURRENT stream wait for it."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 class Group(object):
-    def __init__(self, pg=None):
+    """The ranks of one data-parallel job.  The collective is ``torch.distributed``'s all-reduce (backend nccl =
+    RCCL) by default; with ``MDBN_DP_COLLECTIVE=capi`` (or ``native=True``) it is the library's own
+    ``mdbn_allreduce_stats`` on a communicator created through ``mdbn_comm_init_rank`` (include/mdbn_hip.h),
+    with torch.distributed used only to hand the 128-byte RCCL id to the ranks."""
+
+    def __init__(self, pg=None, native=None):
         self.pg = pg
         self.rank = td.get_rank(pg)
         self.world_size = td.get_world_size(pg)
+        self.native = (os.environ.get("MDBN_DP_COLLECTIVE") == "capi") if native is None else bool(native)
+        self._comm_engine = None
+        self._side = None
 
     def shard(self, n):
         """Contiguous rows [lo, hi) of an n-row minibatch owned by this rank."""
         return shard_bounds(n, self.rank, self.world_size)
 
-    def all_reduce_sum(self, tensor):
+    # -- the library's own RCCL communicator
+    def _native(self, engine):
+        if not self.native or engine is None or not hasattr(engine, "ctx") or not torch.cuda.is_available():
+            return False
+        if self._comm_engine is not engine:
+            import ctypes as C
+            from . import _lib
+            ident = [None]
+            if self.rank == 0:
+                buf = C.create_string_buffer(128)
+                _lib.check(engine.lib.mdbn_comm_unique_id(buf), "mdbn_comm_unique_id")
+                ident[0] = buf.raw
+            td.broadcast_object_list(ident, src=0, group=self.pg)
+            _lib.check(engine.lib.mdbn_comm_init_rank(engine.ctx, ident[0], self.world_size, self.rank),
+                       "mdbn_comm_init_rank")
+            self._comm_engine = engine
+            self._side = torch.cuda.Stream(device=engine.device)
+        return True
+
+    def _native_launch(self, tensor, engine, stream):
+        import ctypes as C
+        from . import _lib
+        _lib.check(engine.lib.mdbn_allreduce_stats(engine.ctx, C.c_void_p(stream.cuda_stream),
+                                                   C.c_void_p(tensor.data_ptr()), tensor.numel()),
+                   "mdbn_allreduce_stats")
+
+    @property
+    def collective(self):
+        return "mdbn_allreduce_stats (RCCL through the C-ABI)" if self._comm_engine is not None else \
+            "torch.distributed all_reduce (%s)" % td.get_backend(self.pg)
+
+    def all_reduce_sum(self, tensor, engine=None):
+        if self._native(engine):
+            self._native_launch(tensor, engine, torch.cuda.current_stream(engine.device))
+            return tensor
         td.all_reduce(tensor, op=td.ReduceOp.SUM, group=self.pg)
         return tensor
 
-    def all_reduce_sum_async(self, tensor):
+    def all_reduce_sum_async(self, tensor, engine=None):
         """Start the sum all-reduce and return the work handle; ``handle.wait()`` makes the
         current stream (not the host, on RCCL) wait for the result."""
+        if self._native(engine):
+            cur = torch.cuda.current_stream(engine.device)
+            self._side.wait_stream(cur)                    # the statistics are complete on the compute stream
+            self._native_launch(tensor, engine, self._side)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            return _StreamWork(ev)
         return td.all_reduce(tensor, op=td.ReduceOp.SUM, group=self.pg, async_op=True)
 
 

@@ -235,7 +235,7 @@ class StepFunction(object):
                 rbm.hbias.tensor, rbm.hbias_speed.tensor, rbm.vbias.tensor, rbm.vbias_speed.tensor)
 
         if self.overlap:
-            work = self.group.all_reduce_sum_async(stats)
+            work = self.group.all_reduce_sum_async(stats, self.engine)
             if self._pending is not None:
                 # speeds from the reduced statistics of step t-1, then theta(t+1) from those speeds:
                 # phases 1 and 2 back to back touch the same arrays, so they run as ONE pass (phase 3;
@@ -256,7 +256,7 @@ class StepFunction(object):
             return lazy
 
         if distributed:
-            self.group.all_reduce_sum(stats)
+            self.group.all_reduce_sum(stats, self.engine)
         out = eng.apply_update(*args, stats, lr, p.lambda_1, p.lambda_2, p.weightcost, momentum,
                                batch_size, n_global, cost_scale, ldv=data.stride(0))
         rbm._n_updates += 1

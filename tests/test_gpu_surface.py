@@ -343,3 +343,28 @@ def test_gibbs_chain_call_equals_eager_steps_and_oracle(hip_engine, gauss):
     mf, smp = fn()
     mf2, smp2 = fn()
     assert mf.shape == (B, V) and not np.array_equal(smp, smp2) or gauss
+
+
+def test_rccl_communicator_through_the_c_abi(hip_engine):
+    """mdbn_comm_unique_id / mdbn_comm_init_rank / mdbn_allreduce_stats / mdbn_comm_destroy with a one-rank
+    communicator (RCCL wants one GPU per rank, the box has one): the sum over one rank leaves the buffer as is,
+    on the caller's stream, without synchronising."""
+    import ctypes as C
+    from mdbn_amd import _lib
+    eng = hip_engine
+    buf = C.create_string_buffer(128)
+    _lib.check(eng.lib.mdbn_comm_unique_id(buf), "mdbn_comm_unique_id")
+    _lib.check(eng.lib.mdbn_comm_init_rank(eng.ctx, buf.raw, 1, 0), "mdbn_comm_init_rank")
+    try:
+        x = torch.randn(4096 * 1024 + 5124, device=eng.device)
+        want = x.clone()
+        side = torch.cuda.Stream(device=eng.device)
+        side.wait_stream(torch.cuda.current_stream())
+        _lib.check(eng.lib.mdbn_allreduce_stats(eng.ctx, C.c_void_p(side.cuda_stream), C.c_void_p(x.data_ptr()), x.numel()),
+                   "mdbn_allreduce_stats")
+        side.synchronize()
+        assert torch.equal(x, want)
+        assert eng.lib.mdbn_comm_init_rank(eng.ctx, buf.raw, 1, 0) != 0          # one communicator per context
+    finally:
+        _lib.check(eng.lib.mdbn_comm_destroy(eng.ctx), "mdbn_comm_destroy")
+    assert eng.lib.mdbn_allreduce_stats(eng.ctx, None, C.c_void_p(x.data_ptr()), 4) != 0
