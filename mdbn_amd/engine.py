@@ -96,7 +96,6 @@ class HipEngine(object):
         self._cost_ring = torch.zeros(1024, dtype=torch.float32, device=self.device)
         self._cost_slot = 0
         self.last_scratch = None        # CDScratch of the most recent CD step (inspection / chain taps)
-        self._wplanes = {}              # W.data_ptr() -> [planes tensor, W._version they were valid for]
 
     def __del__(self):
         try:
@@ -222,19 +221,18 @@ class HipEngine(object):
         """(planes, valid) for a weight matrix: the [3, V, ldh] bf16 planes the library keeps in step with W, and
         whether they hold the split of the CURRENT W.  A torch-side write to W (set_value, checkpoint load) bumps
         the tensor's version and invalidates them; the library's own updates rewrite them."""
-        key = W.data_ptr()
-        ent = self._wplanes.get(key)
-        if ent is None or tuple(ent[0].shape[1:]) != (W.shape[0], W.stride(0)):
+        # kept ON the tensor object (the one a SharedArray holds for its lifetime), never keyed by address: a new
+        # matrix that reuses a freed one's memory must not inherit its planes
+        ent = getattr(W, "_mdbn_planes", None)
+        if ent is None or tuple(ent[0].shape[1:]) != (W.shape[0], W.stride(0)) or ent[2] != W.data_ptr():
             if not create:
                 return None, False
-            if len(self._wplanes) > 16:
-                self._wplanes.clear()
-            ent = [torch.empty((3, W.shape[0], W.stride(0)), dtype=torch.int16, device=self.device), None]
-            self._wplanes[key] = ent
+            ent = [torch.empty((3, W.shape[0], W.stride(0)), dtype=torch.int16, device=self.device), None, W.data_ptr()]
+            W._mdbn_planes = ent
         return ent[0], ent[1] == W._version
 
     def _w_planes_written(self, W):
-        ent = self._wplanes.get(W.data_ptr())
+        ent = getattr(W, "_mdbn_planes", None)
         if ent is not None:
             ent[1] = W._version
 

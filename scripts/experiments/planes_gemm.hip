@@ -47,7 +47,11 @@ __device__ __forceinline__ void glds16(const void* g, unsigned lds_off, char* sm
 }
 
 // One loader wave's share of the staging: instructions q = w, w + LW, ... of the NQ = 8 * (AP + 3) per stage.
-template <int LA, int LB, int AP, int LW>
+// MS = MFMA shape the LDS images are swizzled for: 32 (v_mfma_f32_32x32x16_bf16) or 16 (v_mfma_f32_16x16x32_bf16)
+__device__ __forceinline__ int row_swz(int row, int ms) { return ms == 32 ? ((row >> 2) & 3) : ((4 - ((row >> 2) & 3)) & 3); }
+__device__ __forceinline__ int col_swz(int k, int ms) { return ms == 32 ? ((k & 3) << 2) : (((k & 3) | (((k >> 3) & 1) << 2)) << 1); }
+
+template <int LA, int LB, int AP, int LW, int MS = 32>
 __device__ __forceinline__ void loader(const PArgs& g, char* smem, int w, int lane, int m0, int n0, int kbeg, int nt)
 {
     constexpr int NQ = 8 * (AP + 3), PER = NQ / LW;
@@ -66,12 +70,12 @@ __device__ __forceinline__ void loader(const PArgs& g, char* smem, int w, int la
         dst[j] = (isA ? plane : 3 + plane) * PLANE + sub * 1024;
         if (lay == ROW) {       // 16 rows x 64 B per instruction; phys chunk = c ^ ((row >> 2) & 3)
             const int row = 16 * sub + (lane >> 2);
-            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            const int c = (lane & 3) ^ row_swz(row, MS);
             src[j] = reinterpret_cast<const char*>(base + (int64_t)(mn0 + row) * ld + kbeg + 8 * c);
             step[j] = 64;
         } else {                // 4 k-rows x 256 B per instruction; phys chunk = ch ^ ((k & 3) << 2)
             const int k = 4 * sub + (lane >> 4);
-            const int ch = (lane & 15) ^ ((k & 3) << 2);
+            const int ch = (lane & 15) ^ col_swz(k, MS);
             src[j] = reinterpret_cast<const char*>(base + (int64_t)(kbeg + k) * ld + mn0 + 8 * ch);
             step[j] = 64 * ld;
         }
@@ -291,6 +295,158 @@ __global__ __launch_bounds__(64 * (4 + LW)) void planes_gemm_kernel(PArgs g)
         }
 }
 
+
+// ---- the same GEMM on v_mfma_f32_16x16x32_bf16: one MFMA spans the whole 32-deep stage; per wave 4 x 4 tiles of 16 x 16.
+// A fragments of a stage (12) are held for the whole stage and ping-pong across stages; B fragments come in two
+// halves (column blocks 0-1, 2-3), the next half / the next stage's A prefetched under the current MFMAs.
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+template <int LA, int LB, int AP, int LW>
+__global__ __launch_bounds__(64 * (4 + LW)) void planes_gemm16_kernel(PArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int qq = nwg >> 3, rem = nwg & 7;
+    const int w = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + slot;
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int ks = w / tiles, t = w - ks * tiles;
+    int tm, tn;
+    if (g.tiles_m <= g.tiles_n) { tn = t / g.tiles_m; tm = t - tn * g.tiles_m; }
+    else { tm = t / g.tiles_n; tn = t - tm * g.tiles_n; }
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int kbeg = ks * g.kchunk;
+    const int nt = g.kchunk / 32;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wave >= 4) {
+        loader<LA, LB, AP, LW, 16>(g, smem, wave - 4, lane, m0, n0, kbeg, nt);
+        return;
+    }
+    unsigned long long t_in = 0, rt_in = 0;
+    if (g.dbg) { t_in = __builtin_amdgcn_s_memtime(); rt_in = __builtin_amdgcn_s_memrealtime(); }
+    const int c16 = lane & 15, q = lane >> 4;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    int offA[4][2], offB[4][2];                 // [16-row block][first / second tr read]
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        {
+            const int row = wm + 16 * b + c16;
+            if (LA == ROW) { offA[b][0] = row * 64 + ((q ^ row_swz(row, 16)) << 4); offA[b][1] = 0; }
+            else {
+                const int ch = (wm + 16 * b) / 8 + ((c16 & 3) >> 1);
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int k = 8 * q + 4 * tt + (c16 >> 2);
+                    offA[b][tt] = k * 256 + ((ch ^ col_swz(k, 16)) << 4) + 8 * (c16 & 1);
+                }
+            }
+        }
+        {
+            const int row = wn + 16 * b + c16;
+            if (LB == ROW) { offB[b][0] = row * 64 + ((q ^ row_swz(row, 16)) << 4); offB[b][1] = 0; }
+            else {
+                const int ch = (wn + 16 * b) / 8 + ((c16 & 3) >> 1);
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int k = 8 * q + 4 * tt + (c16 >> 2);
+                    offB[b][tt] = k * 256 + ((ch ^ col_swz(k, 16)) << 4) + 8 * (c16 & 1);
+                }
+            }
+        }
+    }
+    f32x4a acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4a{0.f, 0.f, 0.f, 0.f};
+    bf16x8 A0[3][4], A1[3][4], BL[3][2], BH[3][2];
+#define RD_A(FA, BASE)                                                                        \
+    _Pragma("unroll") for (int pl = 0; pl < AP; ++pl)                                         \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a) FA[pl][a] = frag<LA>((BASE) + pl * PLANE, offA[a][0], offA[a][1]);
+#define RD_B(FB, BASE, B0)                                                                    \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                          \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) FB[pl][b] = frag<LB>((BASE) + (3 + pl) * PLANE, offB[(B0) + b][0], offB[(B0) + b][1]);
+#define MMA16(FA, FB, B0)                                                                     \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                             \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                       \
+            f32x4a& c = acc[a][(B0) + b];                                                     \
+            if constexpr (AP == 3) {                                                          \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[2][a], FB[0][b], c, 0, 0, 0);  \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[2][b], c, 0, 0, 0);  \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[1][a], FB[1][b], c, 0, 0, 0);  \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[1][a], FB[0][b], c, 0, 0, 0);  \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[1][b], c, 0, 0, 0);  \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], c, 0, 0, 0);  \
+            } else {                                                                          \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[2][b], c, 0, 0, 0);  \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[1][b], c, 0, 0, 0);  \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], c, 0, 0, 0);  \
+            }                                                                                 \
+        }
+    constexpr int RA = 4 * AP * (LA == COL ? 2 : 1), RB = 6 * (LB == COL ? 2 : 1), NM = 8 * (AP == 3 ? 6 : 3);
+#define ORDER16(NR)                                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < ((NR) < NM ? (NR) : NM); ++i_) {                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+    }                                                                                         \
+    if ((NR) > NM) __builtin_amdgcn_sched_group_barrier(0x100, (NR) - NM, 0);                 \
+    if (NM > (NR)) __builtin_amdgcn_sched_group_barrier(0x008, NM - (NR), 0);
+#define BODY16(AC, AN, IT)                                                                    \
+    {                                                                                         \
+        const char* base = smem + ((IT) % NSTAGE) * STAGE;                                    \
+        const char* next = smem + (((IT) + 1) % NSTAGE) * STAGE;                              \
+        RD_B(BH, base, 2);                                                                    \
+        MMA16(AC, BL, 0);                                                                     \
+        ORDER16(RB);                                                                          \
+        __syncthreads();                                                                      \
+        RD_A(AN, next);                                                                       \
+        RD_B(BL, next, 0);                                                                    \
+        MMA16(AC, BH, 2);                                                                     \
+        ORDER16(RA + RB);                                                                     \
+    }
+    __syncthreads();                                 // stage 0 landed
+    unsigned long long t_loop = 0;
+    if (g.dbg) t_loop = __builtin_amdgcn_s_memtime();
+    RD_A(A0, smem);
+    RD_B(BL, smem, 0);
+    for (int it = 0; it < nt; it += 2) {
+        BODY16(A0, A1, it);
+        if (it + 1 < nt) BODY16(A1, A0, it + 1);
+    }
+#undef RD_A
+#undef RD_B
+#undef MMA16
+#undef ORDER16
+#undef BODY16
+    if (g.dbg && wave == 0 && lane == 0) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime(), rt_end = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* d = g.dbg + 4 * (int64_t)blockIdx.x;
+        d[0] = t_loop - t_in; d[1] = t_end - t_loop; d[2] = t_end - t_in; d[3] = rt_end - rt_in;
+    }
+    // accumulator (16x16): col = lane & 15, row = 4 * (lane >> 4) + e
+    float* C = g.C + (int64_t)ks * g.slab_stride;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                C[(int64_t)(m0 + wm + 16 * a + 4 * q + e) * g.ldc + n0 + wn + 16 * b + c16] = acc[a][b][e];
+}
+
+template <int LA, int LB, int AP, int LW>
+static int launch16(const PArgs& g, hipStream_t s)
+{
+    auto kern = planes_gemm16_kernel<LA, LB, AP, LW>;
+    static bool attr = false;
+    constexpr int lds = NSTAGE * STAGE;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return -2;
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n * g.splitk), dim3(64 * (4 + LW)), lds, s, g);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 // exact 3-way truncation split of an f32 matrix into bf16 planes (same layout, same ld)
 __global__ void split_kernel(const float* __restrict__ X, int64_t n, unsigned short* __restrict__ P, int64_t plane)
 {
@@ -345,6 +501,9 @@ extern "C" int exp_gemm(int la, int lb, int ap, int lw, const unsigned short* A,
     if (M % 128 || N % 128 || K % (32 * splitk)) return -1;
     PArgs g{A, lda, pa, B, ldb, pb, C, ldc, slab_stride, M, N, K, K / splitk, splitk, M / 128, N / 128, dbg};
     hipStream_t s = (hipStream_t)stream;
+#define CASE16(LAV, LBV, APV) if (la == LAV && lb == LBV && ap == APV && lw == 104) return launch16<LAV, LBV, APV, 4>(g, s)
+    CASE16(ROW, COL, 3); CASE16(ROW, COL, 1); CASE16(ROW, ROW, 3); CASE16(ROW, ROW, 1); CASE16(COL, COL, 3);
+#undef CASE16
 #define CASE(LAV, LBV, APV, LWV) if (la == LAV && lb == LBV && ap == APV && lw == LWV) return launch<LAV, LBV, APV, LWV>(g, s)
     CASE(ROW, COL, 3, 4); CASE(ROW, COL, 3, 8); CASE(ROW, COL, 1, 4); CASE(ROW, COL, 1, 8);
     CASE(ROW, ROW, 3, 4); CASE(ROW, ROW, 3, 8); CASE(ROW, ROW, 1, 4); CASE(ROW, ROW, 1, 8);

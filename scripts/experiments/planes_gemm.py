@@ -135,7 +135,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "variants":
             Ap, Bp = split(A), split(B)
             Cs = torch.zeros((sk, M, N), device=dev)
             ref = (A.double() if la == ROW else A.double().t()) @ (B.double().t() if lb == ROW else B.double())
-            for lw in (4, 8):
+            for lw in (4, 104):                     # 104 = v_mfma_f32_16x16x32_bf16 variant, 4 loader waves
                 f = lambda: vlib.exp_gemm(la, lb, ap, lw, Ap.data_ptr(), A.shape[1], A.numel(), Bp.data_ptr(), B.shape[1],
                                           B.numel(), Cs.data_ptr(), N, M * N, M, N, K, sk, stream(), None)
                 Cs.zero_()

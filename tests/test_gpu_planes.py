@@ -31,19 +31,26 @@ def split(eng, x):
 
 
 def test_split_is_exact_over_the_whole_exponent_range(hip_engine):
+    """x = p1 + p2 + p3 bit for bit for every |x| >= 2^-110 (exponents -110 ... 127, random 24-bit significands, both
+    signs) and for +-0.  Below 2^-110 the lowest of the 24 significand bits weighs less than 2^-133, the smallest bf16
+    subnormal, and is truncated: |x - (p1 + p2 + p3)| < 2^-133 (about 1e-40) for tiny normals and f32 subnormals --
+    an absolute error no sum of products can notice."""
     rs = np.random.RandomState(0)
     mant = rs.uniform(1, 2, (254, 64)).astype(np.float32)
     expo = np.arange(-126, 128, dtype=np.float32)[:, None]
     x = (mant * np.exp2(expo) * rs.choice([-1.0, 1.0], (254, 64))).astype(np.float32)
     denorm = (rs.randint(1, 1 << 23, (2, 64)).astype(np.uint32)).view(np.float32)        # f32 subnormals
-    x = np.concatenate([x, denorm, np.zeros((1, 64), np.float32), -np.zeros((1, 64), np.float32) * -1.0])
+    x = np.concatenate([x, denorm, np.zeros((1, 64), np.float32), -np.zeros((1, 64), np.float32)])
     xd = hip_engine.to_device(x)
     p1, p2, p3 = planes_to_f32(split(hip_engine, xd))
-    back = (p3 + p2) + p1                       # the residuals are exact f32 values: two exact additions
-    assert torch.equal(back.cpu(), torch.from_numpy(x)), "x != p1 + p2 + p3"
-    # every piece is a bf16 (low 16 bits clear by construction) and the pieces shrink by >= 2^-8 each
+    back = ((p3 + p2) + p1).cpu().numpy()       # the residuals are exact f32 values: two exact additions
+    exact_rows = np.concatenate([expo[:, 0] >= -110, [False, False, True, True]])
+    assert np.array_equal(back[exact_rows].view(np.uint32), x[exact_rows].view(np.uint32)), "x != p1 + p2 + p3"
+    err = np.abs(back.astype(np.float64) - x.astype(np.float64))
+    assert err[~exact_rows].max() < 2.0 ** -133
+    # the pieces shrink by at least 2^-7 each (bf16: 8 significant bits)
     a1, a2, a3 = [t.abs().cpu().numpy().astype(np.float64) for t in (p1, p2, p3)]
-    assert np.all(a2 <= a1 * 2.0 ** -7 + 1e-300) and np.all(a3 <= np.maximum(a2, a1 * 2.0 ** -8) * 2.0 ** -7 + 1e-300)
+    assert np.all(a2 <= a1 * 2.0 ** -7) and np.all(a3 <= a1 * 2.0 ** -15)
 
 
 def test_split_of_non_finite_values(hip_engine):
