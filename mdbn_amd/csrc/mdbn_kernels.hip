@@ -766,9 +766,25 @@ __global__ __launch_bounds__(64 * (4 + 2 * PW)) void gemm_bf16x6_kernel(GemmArgs
             X6_FRAGS(f1a, f1b, base, 1);
             X6_MMA(f0a, f0b);
             STAMP(1);
+            // Pin the F1 reads BEFORE the barrier: hipcc may sink LDS loads whose only use sits in a later basic
+            // block past s_barrier (an IntrNoMem intrinsic; the workgroup fences around it lower to waits only).
+            // That is what the "guarded reload" build did -- the F1 reads of slice `it` ended up after the barrier
+            // that lets the producers refill its buffer (root cause).  An empty asm that consumes the
+            // registers costs nothing and makes the position of the loads a data dependence.
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    if (pl < AP) asm volatile("" :: "v"(f1a[pl][a]));
+                    asm volatile("" :: "v"(f1b[pl][a]));
+                }
             __syncthreads();                         // (waits for F1: every read of this slice's buffer is done)
             STAMP(2);
+#ifdef X6_GUARD_RELOAD      // diagnostic build only: the guarded reload that gave wrong results (root cause)
+            if (it + 1 < nt) { X6_FRAGS(f0a, f0b, next, 0); }
+#else
             X6_FRAGS(f0a, f0b, next, 0);
+#endif
             X6_MMA(f1a, f1b);
             STAMP(3);
         }

@@ -234,6 +234,15 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
             PL_FRAGS(f1a, f1b, base, 1);
             PL_MMA(f0a, f0b);
             PL_ORDER();
+            // pin the F1 reads before the barrier (hipcc may sink LDS loads past s_barrier when their only use is in
+            // a later basic block: the root cause of the "guarded reload" miscompile)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    if (pl < AP) asm volatile("" :: "v"(f1a[pl][a]));
+                    asm volatile("" :: "v"(f1b[pl][a]));
+                }
             __syncthreads();                         // every read of stage `it` is done; stage it + 1 has landed
             PL_FRAGS(f0a, f0b, next, 0);
             PL_MMA(f1a, f1b);

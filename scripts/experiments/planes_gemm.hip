@@ -357,17 +357,23 @@ __global__ __launch_bounds__(64 * (4 + LW)) void planes_gemm16_kernel(PArgs g)
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4a{0.f, 0.f, 0.f, 0.f};
-    bf16x8 A0[3][4], A1[3][4], BL[3][2], BH[3][2];
-#define RD_A(FA, BASE)                                                                        \
+    // Four fragment register groups, one per operand half (two 16-row blocks x planes): 96 VGPRs.  The stage's 4 x 4
+    // tiles are visited quarter by quarter in a serpentine (lo,lo) (lo,hi) (hi,hi) (hi,lo) | (lo,hi) (lo,lo) (hi,lo) (hi,hi)
+    // so that consecutive quarters share one half, and every quarter prefetches exactly ONE half (this stage's, or
+    // after the mid-stage barrier the next stage's) under its 24 MFMAs.
+    bf16x8 Alo[3][2], Ahi[3][2], Blo[3][2], Bhi[3][2];
+#define RD_A(FA, BASE, HALF)                                                                  \
     _Pragma("unroll") for (int pl = 0; pl < AP; ++pl)                                         \
-        _Pragma("unroll") for (int a = 0; a < 4; ++a) FA[pl][a] = frag<LA>((BASE) + pl * PLANE, offA[a][0], offA[a][1]);
-#define RD_B(FB, BASE, B0)                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
+            FA[pl][i] = frag<LA>((BASE) + pl * PLANE, offA[2 * (HALF) + i][0], offA[2 * (HALF) + i][1]);
+#define RD_B(FB, BASE, HALF)                                                                  \
     _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                          \
-        _Pragma("unroll") for (int b = 0; b < 2; ++b) FB[pl][b] = frag<LB>((BASE) + (3 + pl) * PLANE, offB[(B0) + b][0], offB[(B0) + b][1]);
-#define MMA16(FA, FB, B0)                                                                     \
-    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                             \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
+            FB[pl][i] = frag<LB>((BASE) + (3 + pl) * PLANE, offB[2 * (HALF) + i][0], offB[2 * (HALF) + i][1]);
+#define MMQ(FA, FB, AH, BH)                                                                   \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                             \
         _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                       \
-            f32x4a& c = acc[a][(B0) + b];                                                     \
+            f32x4a& c = acc[2 * (AH) + a][2 * (BH) + b];                                      \
             if constexpr (AP == 3) {                                                          \
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[2][a], FB[0][b], c, 0, 0, 0);  \
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[2][b], c, 0, 0, 0);  \
@@ -381,41 +387,43 @@ __global__ __launch_bounds__(64 * (4 + LW)) void planes_gemm16_kernel(PArgs g)
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], c, 0, 0, 0);  \
             }                                                                                 \
         }
-    constexpr int RA = 4 * AP * (LA == COL ? 2 : 1), RB = 6 * (LB == COL ? 2 : 1), NM = 8 * (AP == 3 ? 6 : 3);
-#define ORDER16(NR)                                                                           \
+    constexpr int RA = 2 * AP * (LA == COL ? 2 : 1), RB = 6 * (LB == COL ? 2 : 1), NM = 4 * (AP == 3 ? 6 : 3);
+#define ORD(NR)                                                                               \
     _Pragma("unroll") for (int i_ = 0; i_ < ((NR) < NM ? (NR) : NM); ++i_) {                  \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
     }                                                                                         \
     if ((NR) > NM) __builtin_amdgcn_sched_group_barrier(0x100, (NR) - NM, 0);                 \
     if (NM > (NR)) __builtin_amdgcn_sched_group_barrier(0x008, NM - (NR), 0);
-#define BODY16(AC, AN, IT)                                                                    \
-    {                                                                                         \
-        const char* base = smem + ((IT) % NSTAGE) * STAGE;                                    \
-        const char* next = smem + (((IT) + 1) % NSTAGE) * STAGE;                              \
-        RD_B(BH, base, 2);                                                                    \
-        MMA16(AC, BL, 0);                                                                     \
-        ORDER16(RB);                                                                          \
-        __syncthreads();                                                                      \
-        RD_A(AN, next);                                                                       \
-        RD_B(BL, next, 0);                                                                    \
-        MMA16(AC, BH, 2);                                                                     \
-        ORDER16(RA + RB);                                                                     \
-    }
     __syncthreads();                                 // stage 0 landed
     unsigned long long t_loop = 0;
     if (g.dbg) t_loop = __builtin_amdgcn_s_memtime();
-    RD_A(A0, smem);
-    RD_B(BL, smem, 0);
+    RD_A(Alo, smem, 0);
+    RD_B(Blo, smem, 0);
     for (int it = 0; it < nt; it += 2) {
-        BODY16(A0, A1, it);
-        if (it + 1 < nt) BODY16(A1, A0, it + 1);
+        {   // even stage: holds (Alo, Blo)
+            const char* base = smem + (it % NSTAGE) * STAGE;
+            const char* next = smem + ((it + 1) % NSTAGE) * STAGE;
+            RD_B(Bhi, base, 1); MMQ(Alo, Blo, 0, 0); ORD(RB);
+            RD_A(Ahi, base, 1); MMQ(Alo, Bhi, 0, 1); ORD(RA);
+            __syncthreads();                         // every read of stage `it` is done; stage it + 1 has landed
+            RD_A(Alo, next, 0); MMQ(Ahi, Bhi, 1, 1); ORD(RA);
+            RD_B(Bhi, next, 1); MMQ(Ahi, Blo, 1, 0); ORD(RB);
+        }
+        if (it + 1 < nt) {   // odd stage: holds (Alo, Bhi)
+            const char* base = smem + ((it + 1) % NSTAGE) * STAGE;
+            const char* next = smem + ((it + 2) % NSTAGE) * STAGE;
+            RD_B(Blo, base, 0); MMQ(Alo, Bhi, 0, 1); ORD(RB);
+            RD_A(Ahi, base, 1); MMQ(Alo, Blo, 0, 0); ORD(RA);
+            __syncthreads();
+            RD_A(Alo, next, 0); MMQ(Ahi, Blo, 1, 0); ORD(RA);
+            RD_B(Blo, next, 0); MMQ(Ahi, Bhi, 1, 1); ORD(RB);
+        }
     }
 #undef RD_A
 #undef RD_B
-#undef MMA16
-#undef ORDER16
-#undef BODY16
+#undef MMQ
+#undef ORD
     if (g.dbg && wave == 0 && lane == 0) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime(), rt_end = __builtin_amdgcn_s_memrealtime();
         unsigned long long* d = g.dbg + 4 * (int64_t)blockIdx.x;
