@@ -17,6 +17,7 @@ using namespace mdbn;
 struct mdbn_ctx {
     int device;
     int num_cu;
+    int* counters = nullptr;   // arrival counters of the in-launch split-K reduction (mdbn_planes.hip), kept at zero
     void* comm = nullptr;      // ncclComm_t of mdbn_comm_init_rank (RCCL), or NULL
     int comm_ranks = 0;
     // side stream + events for mdbn_cd_train_step (memory-bound update work overlapped with the
@@ -196,6 +197,10 @@ static int g_opt_gemm_bf16x6 = 3;
 // mdbn_set_option("gemm_planes"): the CD step runs on pre-split bf16 planes (mdbn_planes.hip) when the caller
 // supplies the plane buffers and the shape is made of whole 128-row / 128-column tiles (default on)
 static int g_opt_gemm_planes = 1;
+// mdbn_set_option("inkernel_reduce"): split-K forward passes of the plane path sum their partial tiles inside the
+// GEMM launch (last-arriving block per tile) instead of a second, epilogue launch (default on; same bits)
+static int g_opt_inkernel_reduce = 1;
+constexpr int kMaxReduceTiles = 1024;
 
 // Turn an LDS-tiled plan into a bf16x6 plan (128x128 tiles, 32-deep slices) when that leaves enough
 // jobs to spread over the chip; `unsplit` = the caller needs splitk == 1 (fused statistics epilogue).
@@ -506,7 +511,7 @@ bool planes_eligible(const mdbn_cd_args* a, bool fused_update)
 
 // One forward pass on planes: A planes [rows, K] (ROW), W planes as COL (dir 0: propup) or ROW (dir 1: propdown);
 // `e` arrives with outputs / bias / rng / colsum set, this fills in the slab side and the cost partials.
-int run_affine_planes(const unsigned short* A, int64_t lda, int64_t pa, int ap, int dir, const unsigned short* Wp,
+int run_affine_planes(mdbn_ctx* ctx, const unsigned short* A, int64_t lda, int64_t pa, int ap, int dir, const unsigned short* Wp,
                       int64_t V, int64_t H, int64_t rows, EpiArgs e, bool want_cost, const Workspace& ws, hipStream_t s,
                       int* n_cost_out)
 {
@@ -519,7 +524,9 @@ int run_affine_planes(const unsigned short* A, int64_t lda, int64_t pa, int ap, 
     g.splitk = planes_splitk((int64_t)g.tiles_m * g.tiles_n, Kdim);
     g.kchunk = (int)(Kdim / g.splitk);
     const bool fuse = g_opt_fused_epilogue && g.splitk == 1;
-    const int nb = fuse ? g.tiles_m * g.tiles_n : epilogue_blocks(rows, e.ld);
+    const bool reduce_inside = !fuse && g.splitk > 1 && g_opt_inkernel_reduce && g.tiles_m * g.tiles_n <= kMaxReduceTiles &&
+                               (int64_t)g.splitk * rows * e.ld * 4 < ((int64_t)1 << 31);
+    const int nb = (fuse || reduce_inside) ? g.tiles_m * g.tiles_n : epilogue_blocks(rows, e.ld);
     e.rows = (int)rows; e.cols = (int)Ndim;
     e.cost_partials = nullptr;
     if (want_cost) {
@@ -530,6 +537,11 @@ int run_affine_planes(const unsigned short* A, int64_t lda, int64_t pa, int ap, 
     const int lb = dir == 0 ? LAY_MN : LAY_K;
     if (fuse) {
         g.fused = 1; g.epi = e;
+        HIP_OK(timed_gemm_planes(LAY_K, lb, g, s));
+    } else if (reduce_inside) {
+        REQUIRE((int64_t)g.splitk * rows * e.ld <= ws.slab_floats, "internal: plane GEMM slabs exceed the workspace");
+        g.fused = 3; g.C = ws.slabs; g.ldc = e.ld; g.slab_stride = rows * e.ld; g.counters = ctx->counters;
+        g.epi = e;
         HIP_OK(timed_gemm_planes(LAY_K, lb, g, s));
     } else {
         REQUIRE((int64_t)g.splitk * rows * e.ld <= ws.slab_floats, "internal: plane GEMM slabs exceed the workspace");
@@ -545,7 +557,6 @@ int run_affine_planes(const unsigned short* A, int64_t lda, int64_t pa, int ap, 
 // Bernoulli RBM, CD only).  upd != NULL: single-device step with the update fused into the statistics GEMM.
 int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const mdbn_update_args* upd, const Workspace& ws)
 {
-    (void)ctx;
     const int64_t B = a->B, V = a->V, H = a->H, ldv = V, ldh = H;
     PlaneBufs pb;
     {
@@ -571,7 +582,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
         e.ld = ldh; e.bias = a->hbias; e.mean = ph; e.sample = a->hs; e.mean_scale = 1.0f; e.gauss = 0;
         e.colsum = ws.colPpos; e.colsum_kind = 0; e.rng = key(0);
         e.mean_planes = pb.Pp; e.plane_stride = pb.pp; e.sample_plane = pb.hsp;
-        CHECK(run_affine_planes(pb.Xp, ldv, pb.px, 3, 0, Wp, V, H, B, e, false, ws, s, nullptr));
+        CHECK(run_affine_planes(ctx, pb.Xp, ldv, pb.px, 3, 0, Wp, V, H, B, e, false, ws, s, nullptr));
         if (a->trace_h) HIP_OK(hipMemcpyAsync(a->trace_h, a->hs, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
     }
     int n_cost = 0;
@@ -584,7 +595,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
             e.mean_planes = pb.Xp + B * ldv; e.plane_stride = pb.px;      // rows B..2B-1 of the X2 planes
             e.sample_plane = a->gauss ? nullptr : pb.vsp;
             if (last) { e.target = v0; e.ld_target = ldv; e.colsum = ws.colV; e.colsum_kind = 1; }
-            CHECK(run_affine_planes(pb.hsp, ldh, B * ldh, 1, 1, Wp, V, H, B, e, last, ws, s, last ? &n_cost : nullptr));
+            CHECK(run_affine_planes(ctx, pb.hsp, ldh, B * ldh, 1, 1, Wp, V, H, B, e, last, ws, s, last ? &n_cost : nullptr));
             if (a->trace_v && !a->gauss)
                 HIP_OK(hipMemcpyAsync(a->trace_v + (int64_t)(t - 1) * B * ldv, a->vs, sizeof(float) * B * ldv,
                                       hipMemcpyDeviceToDevice, s));
@@ -597,8 +608,8 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
             e.mean_planes = pb.Pp + B * ldh; e.plane_stride = pb.pp;       // rows B..2B-1 of the P2 planes: -nh_mean
             e.sample_plane = need_sample ? pb.hsp : nullptr;
             if (last) { e.colsum = ws.colPneg; e.colsum_kind = 0; }
-            if (a->gauss) CHECK(run_affine_planes(pb.Xp + B * ldv, ldv, pb.px, 3, 0, Wp, V, H, B, e, false, ws, s, nullptr));
-            else CHECK(run_affine_planes(pb.vsp, ldv, B * ldv, 1, 0, Wp, V, H, B, e, false, ws, s, nullptr));
+            if (a->gauss) CHECK(run_affine_planes(ctx, pb.Xp + B * ldv, ldv, pb.px, 3, 0, Wp, V, H, B, e, false, ws, s, nullptr));
+            else CHECK(run_affine_planes(ctx, pb.vsp, ldv, B * ldv, 1, 0, Wp, V, H, B, e, false, ws, s, nullptr));
             if (a->trace_h && need_sample)
                 HIP_OK(hipMemcpyAsync(a->trace_h + (int64_t)t * B * ldh, a->hs, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
         }
@@ -680,6 +691,11 @@ int mdbn_ctx_create(mdbn_ctx** out, int device)
     mdbn_ctx* c = new mdbn_ctx;
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
+    {   // context creation is the one place that allocates: 1024 tile counters, zeroed once (every launch leaves them zero)
+        HIP_OK(hipSetDevice(device));
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->counters), kMaxReduceTiles * sizeof(int)));
+        HIP_OK(hipMemset(c->counters, 0, kMaxReduceTiles * sizeof(int)));
+    }
     *out = c;
     return MDBN_OK;
 }
@@ -692,6 +708,7 @@ int mdbn_ctx_destroy(mdbn_ctx* ctx)
         if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
         if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
         if (ctx->side) (void)hipStreamDestroy(ctx->side);
+        if (ctx->counters) (void)hipFree(ctx->counters);
         if (ctx->comm) (void)mdbn_comm_destroy(ctx);
     }
     delete ctx;
@@ -748,6 +765,10 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     }
     if (strcmp(name, "gemm_bf16x6") == 0) {
         g_opt_gemm_bf16x6 = (int)value & 3;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "inkernel_reduce") == 0) {
+        g_opt_inkernel_reduce = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "gemm_planes") == 0) {

@@ -297,8 +297,10 @@ __device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, f
     if (e.colsum) e.colsum[(int64_t)(r0 >> 2) * e.ld + col] = csum;
 }
 
+// cost_slot: index of this tile's cost partial (default: the block index; a kernel whose reducer blocks are a
+// subset of the grid passes the tile index instead)
 template <int BM, int BN, int NT = 512>
-__device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, int m0, int n0)
+__device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, int m0, int n0, int cost_slot = -1)
 {
     constexpr int LDT = BN + 8;
     const int c = threadIdx.x & (BN - 1), rg0 = threadIdx.x / BN;
@@ -317,7 +319,7 @@ __device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, 
     }
     if (e.cost_partials) {
         const float tot = block_sum(cost, T + BM * LDT);
-        if (threadIdx.x == 0) e.cost_partials[blockIdx.x] = tot;
+        if (threadIdx.x == 0) e.cost_partials[cost_slot < 0 ? (int)blockIdx.x : cost_slot] = tot;
     }
 }
 

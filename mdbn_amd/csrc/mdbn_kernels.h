@@ -102,6 +102,10 @@ struct PlaneGemmArgs {
     int M, N, K, kchunk, splitk, tiles_m, tiles_n;
     int ap;                // planes of A: 3, or 1 when A holds 0/1 samples (three products instead of six)
     int fused;             // 0 | 1 activation epilogue (epi) | 2 parameter update (upd) + finalize units (fin)
+                           // | 3 split-K with the reduction INSIDE the launch: every block publishes its partial tile
+                           //   (write-through stores), the last block to arrive at a tile sums the partials in slab
+                           //   order and runs the activation epilogue (epi)
+    int* counters;         // fused == 3: one arrival counter per output tile, zero on entry, zero again on exit
     EpiArgs epi;
     UpdEpi upd;
     int fin_enabled;

@@ -118,7 +118,18 @@ __device__ __forceinline__ pbf16x8 pl_frag(const char* plane, int off0, int off1
 
 // FUSED: 0 = split-K slab / plain C store; 1 = activation + sampling epilogue on the parked tile (unsplit
 // forward pass); 2 = statistics GEMM: finalize units on the ramp-up, parameter update (+ W planes) on the
-// parked tile.  AP = planes of A (3, or 1 for 0/1 samples).
+// parked tile; 3 = split-K forward pass reduced INSIDE the launch (below).  AP = planes of A (3, or 1 for 0/1 samples).
+//
+// FUSED == 3, the in-launch split-K reduction (cdna_hip_programming.md section 5, "In-launch split-K reduction";
+// MI355X_MICROARCH.md, inter-workgroup visibility, first row of the sc1 table): every block parks its 128x128
+// partial tile in LDS and publishes it to its slab with 16-byte WRITE-THROUGH (sc1) stores; every storing wave
+// drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane takes a ticket from the
+// tile's arrival counter (agent-scope atomic add).  The block that draws ticket splitk-1 is the reducer: after a
+// barrier behind the returned add it reads all slabs of the tile with sc1 loads (L1 bypassed; never a plain load),
+// sums them in SLAB ORDER -- the same order as act_epilogue_kernel, so the result is bit-identical to the
+// two-launch path and independent of which block arrived last -- and runs the activation epilogue on the sum.
+// Nothing depends on dispatch order or XCD placement; no block ever waits for another (no spin, no deadlock).
+// The reducer zeroes the counter for the next launch (the context allocates the counters zeroed).
 template <int LA, int LB, int AP, int FUSED>
 __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemmArgs g)
 {
@@ -281,8 +292,55 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
     if constexpr (FUSED != 0) {     // all 8 waves work on the parked tile (every DMA has landed: the loaders drained vmcnt)
         __syncthreads();
         float* T = reinterpret_cast<float*>(smem);
-        if constexpr (FUSED == 1) fused_tile_epilogue<128, 128, 64 * (4 + PL_LW)>(g.epi, T, m0, n0);
-        else fused_update_epilogue<128, 128, 64 * (4 + PL_LW)>(g.upd, T, m0, n0);
+        constexpr int NT = 64 * (4 + PL_LW), LDT = 128 + 8;
+        if constexpr (FUSED == 1) fused_tile_epilogue<128, 128, NT>(g.epi, T, m0, n0);
+        else if constexpr (FUSED == 2) fused_update_epilogue<128, 128, NT>(g.upd, T, m0, n0);
+        else {
+            typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
+            // one descriptor for all slabs (< 4 GiB: checked by the host); offsets are bytes
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                g.C, 0, (int)((int64_t)g.splitk * g.slab_stride * 4), 0x00020000);
+            const int tile = t;
+            // 1. publish: rows of the parked tile -> slab ks, 16 bytes per lane, write-through
+#pragma unroll 4
+            for (int idx = threadIdx.x; idx < 128 * 32; idx += NT) {
+                const int row = idx >> 5, c4 = idx & 31;
+                const pu32x4 v = *reinterpret_cast<const pu32x4*>(T + row * LDT + 4 * c4);
+                const int off = (int)(((int64_t)ks * g.slab_stride + (int64_t)(m0 + row) * g.ldc + n0 + 4 * c4) * 4);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 16 /* sc1 */);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave drains its stores
+            __syncthreads();
+            int* flag = reinterpret_cast<int*>(T + 128 * LDT + 32);      // beyond the tile and block_sum's scratch
+            if (threadIdx.x == 0) {
+                const int ticket = __hip_atomic_fetch_add(g.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = ticket == g.splitk - 1;
+            }
+            __syncthreads();                                             // behind the returned add
+            if (!*flag) return;
+            // 2. the last arriver: sum the slabs in slab order (8 loads in flight per lane), sc1 loads only
+#pragma unroll 1
+            for (int idx = threadIdx.x; idx < 128 * 32; idx += NT) {
+                const int row = idx >> 5, c4 = idx & 31;
+                const int64_t base = (int64_t)(m0 + row) * g.ldc + n0 + 4 * c4;
+                pf32x4 a = {0.f, 0.f, 0.f, 0.f};
+                for (int s0 = 0; s0 < g.splitk; s0 += 8) {
+                    pu32x4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int sl = s0 + u < g.splitk ? s0 + u : g.splitk - 1;        // clamped: value unused
+                        v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((int64_t)sl * g.slab_stride + base) * 4), 0, 16);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (s0 + u < g.splitk) a += __builtin_bit_cast(pf32x4, v[u]);
+                }
+                *reinterpret_cast<pf32x4*>(T + row * LDT + 4 * c4) = a;
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(g.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            fused_tile_epilogue<128, 128, NT>(g.epi, T, m0, n0, tile);
+        }
     }
 }
 
@@ -304,12 +362,16 @@ static hipError_t launch_planes_t(const PlaneGemmArgs& g, hipStream_t s)
 hipError_t launch_gemm_planes(int la, int lb, const PlaneGemmArgs& g, hipStream_t s)
 {
     if (g.M % 128 || g.N % 128 || g.kchunk % 32 || g.kchunk * g.splitk != g.K || g.tiles_m != g.M / 128 ||
-        g.tiles_n != g.N / 128 || (g.lda & 7) || (g.ldb & 7) || (g.fused && g.splitk != 1) || (g.ap != 1 && g.ap != 3))
+        g.tiles_n != g.N / 128 || (g.lda & 7) || (g.ldb & 7) || ((g.fused == 1 || g.fused == 2) && g.splitk != 1) ||
+        (g.ap != 1 && g.ap != 3))
+        return hipErrorInvalidValue;
+    if (g.fused == 3 && (g.counters == nullptr || (int64_t)g.splitk * g.slab_stride * 4 >= (int64_t)1 << 31))
         return hipErrorInvalidValue;
 #define PL_CASE(LAV, LBV, APV, FV) \
     if (la == LAV && lb == LBV && g.ap == APV && g.fused == FV) return launch_planes_t<LAV, LBV, APV, FV>(g, s)
     // propup: x planes (ROW) x W planes (COL)
     PL_CASE(LAY_K, LAY_MN, 3, 0); PL_CASE(LAY_K, LAY_MN, 3, 1); PL_CASE(LAY_K, LAY_MN, 1, 0); PL_CASE(LAY_K, LAY_MN, 1, 1);
+    PL_CASE(LAY_K, LAY_MN, 3, 3); PL_CASE(LAY_K, LAY_MN, 1, 3); PL_CASE(LAY_K, LAY_K, 3, 3); PL_CASE(LAY_K, LAY_K, 1, 3);
     // propdown: h planes (ROW) x W planes (ROW)
     PL_CASE(LAY_K, LAY_K, 3, 0); PL_CASE(LAY_K, LAY_K, 3, 1); PL_CASE(LAY_K, LAY_K, 1, 0); PL_CASE(LAY_K, LAY_K, 1, 1);
     // statistics: [v0; nv]^T planes (COL) x [ph; -nh] planes (COL)

@@ -847,6 +847,44 @@ def test_bf16x6_split_is_exact(hip_engine):
 
 
 @pytest.mark.gpu
+def test_bf16x6_split_value_range_and_non_finite(hip_engine, planes=0):
+    """The whole f32 range through an identity multiply on the in-kernel split of gemm_bf16x6_kernel (the plane path's
+    split, the same truncation, is covered in test_gpu_planes.py): exponents -110 ... 127 come back BIT FOR BIT; below 2^-110 the lowest significand bits weigh less
+    than the smallest bf16 subnormal (2^-133) and are truncated -- error < 2^-132 absolute; a +-Inf or NaN operand
+    makes its output row/column NaN (Inf - Inf in the remainder), never a finite wrong number."""
+    import torch
+    eng = hip_engine
+    n, B = 1024, 512
+    eng.set_option("gemm_planes", planes)
+    try:
+        g = torch.Generator().manual_seed(5)
+        mant = 1.0 + torch.rand((B, n), generator=g)
+        expo = torch.randint(-110, 128, (B, n), generator=g).float()
+        vals = mant * torch.exp2(expo) * (torch.randint(0, 2, (B, n), generator=g).float() * 2 - 1)
+        tiny = (1.0 + torch.rand((B, n), generator=g)) * torch.exp2(torch.randint(-126, -110, (B, n), generator=g).float())
+        Wd = eng.alloc_matrix(n, n); Wd.copy_(torch.eye(n).to(eng.device))
+        zero = eng.alloc_vector(n)
+        for src, exact in ((vals, True), (tiny, False)):
+            h = eng.alloc_matrix(B, n); h.copy_(src.to(eng.device))
+            out = eng.propdown(h, Wd, zero, gauss=True)[0][:, :n]
+            if exact:
+                assert torch.equal(out, h)
+            else:
+                assert float((out.double() - h.double()).abs().max()) < 2.0 ** -132
+        bad = vals.clone().clamp(-1e3, 1e3)
+        bad[3, 7], bad[5, 9], bad[8, 11] = float("inf"), float("-inf"), float("nan")
+        h = eng.alloc_matrix(B, n); h.copy_(bad.to(eng.device))
+        out = eng.propdown(h, Wd, zero, gauss=True)[0][:, :n].cpu()
+        # identity weights: column j of the output only sees column j of h, times 0 elsewhere -- 0 * Inf = NaN spreads
+        # along the ROW of the non-finite entry, nowhere else
+        rows_bad = torch.isnan(out).any(dim=1) | torch.isinf(out).any(dim=1)
+        assert rows_bad.nonzero().flatten().tolist() == [3, 5, 8]
+        assert not torch.isfinite(out[3, 7]) and not torch.isfinite(out[5, 9]) and torch.isnan(out[8, 11])
+    finally:
+        eng.set_option("gemm_planes", 1)
+
+
+@pytest.mark.gpu
 def test_bf16x6_ragged_shapes_match_exact_kernel(hip_engine):
     """Random ragged shapes (edge tiles in both dimensions, K tails, K not a multiple of 4, split and
     unsplit K): the bf16x6 path against the exact-f32 kernel on both passes -- same results to the f32

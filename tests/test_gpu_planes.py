@@ -89,7 +89,10 @@ def test_plane_step_equals_f32_operand_step_bit_for_bit(hip_engine, gauss, V, H,
     a, _, _, _ = _run_steps(hip_engine, gauss, False, V, H, B, k)
     b, rbm, wp, valid = _run_steps(hip_engine, gauss, True, V, H, B, k)
     for key in a:
-        assert np.array_equal(a[key], b[key]), key
+        if key == "costs":       # the monitoring cost is summed from per-tile instead of per-epilogue-block partials
+            np.testing.assert_allclose(a[key], b[key], rtol=2e-6)
+        else:
+            assert np.array_equal(a[key], b[key]), key
     # the planes of W followed every update
     assert wp is not None and valid
     p1, p2, p3 = planes_to_f32(wp)
@@ -159,3 +162,27 @@ def test_plane_step_against_oracle_teacher_forced(hip_engine):
     assert np.abs(s_v - s_v_o).max() <= 1e-5 * max(1.0, np.abs(s_v_o).max())
     assert np.abs(sc.P2[:B].cpu().numpy() - ph).max() <= 2e-6
     assert flips <= 3
+
+
+@pytest.mark.parametrize("gauss,V,H,B,k", [(True, 4096, 1024, 512, 1), (False, 1024, 512, 512, 2), (True, 2048, 1024, 128, 1)])
+def test_in_launch_splitk_reduction_is_bitwise_and_repeatable(hip_engine, gauss, V, H, B, k):
+    """Split-K forward passes reduced inside the GEMM launch (last-arriving block per tile, write-through slabs,
+    agent-scope ticket) against the two-launch path (slabs + act_epilogue_kernel): identical parameters, speeds and
+    samples bit for bit -- the partials are summed in slab order whichever block arrives last -- and identical from
+    run to run (a race between publishing and reducing would show as run-to-run differences)."""
+    eng = hip_engine
+    runs = []
+    for inside in (1, 0, 1, 1):
+        eng.set_option("inkernel_reduce", inside)
+        try:
+            out, _, _, _ = _run_steps(eng, gauss, True, V, H, B, k, steps=12, seed=3)
+        finally:
+            eng.set_option("inkernel_reduce", 1)
+        runs.append(out)
+    for other in runs[1:]:
+        for key in runs[0]:
+            if key == "costs":
+                np.testing.assert_allclose(runs[0][key], other[key], rtol=2e-6)
+            else:
+                assert np.array_equal(runs[0][key], other[key]), key
+    assert np.array_equal(runs[0]["costs"], runs[2]["costs"]) and np.array_equal(runs[0]["costs"], runs[3]["costs"])
