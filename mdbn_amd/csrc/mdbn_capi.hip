@@ -198,8 +198,15 @@ static int g_opt_gemm_bf16x6 = 3;
 // supplies the plane buffers and the shape is made of whole 128-row / 128-column tiles (default on)
 static int g_opt_gemm_planes = 1;
 // mdbn_set_option("inkernel_reduce"): split-K forward passes of the plane path sum their partial tiles inside the
-// GEMM launch (last-arriving block per tile) instead of a second, epilogue launch (default on; same bits)
-static int g_opt_inkernel_reduce = 1;
+// GEMM launch (last-arriving block per tile) instead of a second, epilogue launch.  Same bits, but MEASURED SLOWER
+// and therefore off by default: at c2 the last arriver of a tile reads 128-512 KB of partials alone while the other
+// CUs idle (propup 54 us against 26 + 7.4 us for GEMM + epilogue launch, propdown 53 against 17.7 + 10.6; step
+// 216.8 against 160.2 us) -- the seam the guides say to cut at these slab sizes (MI355X_MICROARCH.md, splitk-seam).
+static int g_opt_inkernel_reduce = 0;
+// mdbn_set_option("planes_mfma"): MFMA shape of the plane GEMMs: 16 = v_mfma_f32_16x16x32_bf16 (default: the chip holds
+// a higher clock on it), 32 = v_mfma_f32_32x32x16_bf16 (the products and order of gemm_bf16x6_kernel: same bits as the
+// f32-operand path)
+static int g_opt_planes_mfma = 16;
 constexpr int kMaxReduceTiles = 1024;
 
 // Turn an LDS-tiled plan into a bf16x6 plan (128x128 tiles, 32-deep slices) when that leaves enough
@@ -454,8 +461,10 @@ int check_mat(const void* p, int64_t ld, int64_t cols, const char* name)
 
 
 // ---------------------------------------------------------------------------------- bf16 plane path
-hipError_t timed_gemm_planes(int la, int lb, const PlaneGemmArgs& g, hipStream_t s)
+hipError_t timed_gemm_planes(int la, int lb, const PlaneGemmArgs& g_in, hipStream_t s)
 {
+    PlaneGemmArgs g = g_in;
+    g.ms = g_opt_planes_mfma;
     if (!g_timing.enabled || g_timing.used >= 8192) return launch_gemm_planes(la, lb, g, s);
     if (g_timing.used == g_timing.pool.size()) {
         hipEvent_t a, b;
@@ -487,12 +496,11 @@ struct PlaneBufs {
 };
 inline int64_t planes_elems(int64_t B, int64_t ldv, int64_t ldh) { return 6 * B * ldv + 6 * B * ldh + B * ldh + B * ldv; }
 
-// split factor of a plane GEMM over K: about one job per CU, >= kMinSplitK of reduction per job, K / sk a multiple of 32
-int planes_splitk(int64_t tiles, int64_t K)
+// The plane GEMMs take over exactly the problems the bf16x6 plans cover (whole 128x128 tiles, 32-deep slices, the
+// same split factors): a plane step and an f32-operand step then sum in the same order and agree bit for bit.
+bool plane_plan(const Plan& p, int64_t M, int64_t N, int64_t K)
 {
-    int64_t sk = std::min(std::max<int64_t>(1, kTargetJobs / tiles), std::max<int64_t>(1, K / kMinSplitK));
-    while (sk > 1 && K % (32 * sk) != 0) --sk;
-    return (int)sk;
+    return p.x6 && !p.skinny && M % 128 == 0 && N % 128 == 0 && p.kchunk % 32 == 0 && (int64_t)p.kchunk * p.splitk == K;
 }
 
 bool planes_eligible(const mdbn_cd_args* a, bool fused_update)
@@ -502,11 +510,9 @@ bool planes_eligible(const mdbn_cd_args* a, bool fused_update)
     const int64_t B = a->B, V = a->V, H = a->H;
     if (B % 128 || V % 128 || H % 128 || a->ldv != V || a->ldh != H || B > 65535) return false;
     if (a->planes_bytes < 2 * planes_elems(B, V, H) || !aligned16(a->planes) || !aligned16(a->W_planes)) return false;
-    const int64_t t_up = (B / 128) * (H / 128), t_down = (B / 128) * (V / 128), t_st = (V / 128) * (H / 128);
-    if (t_up * planes_splitk(t_up, V) < g_opt_x6_min_jobs || t_down * planes_splitk(t_down, H) < g_opt_x6_min_jobs) return false;
-    if (t_st < g_opt_x6_min_jobs) return false;          // the statistics GEMM runs unsplit (fused update / plain S)
     (void)fused_update;
-    return true;
+    return plane_plan(plan_forward(B, H, V, H), B, H, V) && plane_plan(plan_forward(B, V, H, V), B, V, H) &&
+           plane_plan(plan_stats(V, H, 2 * B, H), V, H, 2 * B);
 }
 
 // One forward pass on planes: A planes [rows, K] (ROW), W planes as COL (dir 0: propup) or ROW (dir 1: propdown);
@@ -521,8 +527,10 @@ int run_affine_planes(mdbn_ctx* ctx, const unsigned short* A, int64_t lda, int64
     g.B = Wp; g.ldb = H; g.pb = V * H;
     g.M = (int)rows; g.N = (int)Ndim; g.K = (int)Kdim;
     g.tiles_m = (int)(rows / 128); g.tiles_n = (int)(Ndim / 128);
-    g.splitk = planes_splitk((int64_t)g.tiles_m * g.tiles_n, Kdim);
-    g.kchunk = (int)(Kdim / g.splitk);
+    {
+        const Plan p = plan_forward(rows, Ndim, Kdim, e.ld);        // eligibility checked that this is a whole-tile x6 plan
+        g.splitk = p.splitk; g.kchunk = p.kchunk;
+    }
     const bool fuse = g_opt_fused_epilogue && g.splitk == 1;
     const bool reduce_inside = !fuse && g.splitk > 1 && g_opt_inkernel_reduce && g.tiles_m * g.tiles_n <= kMaxReduceTiles &&
                                (int64_t)g.splitk * rows * e.ld * 4 < ((int64_t)1 << 31);
@@ -620,13 +628,14 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     float* s_v = s_h + ldh;
     float* cost = s_v + ldv;
     // S = [v0; nv]^T [ph; -nh]: one GEMM over the stacked batch dimension, both operands used transposed
+    const Plan sp = plan_stats(V, H, 2 * B, ldh);
     PlaneGemmArgs g{};
     g.A = pb.Xp; g.lda = ldv; g.pa = pb.px; g.ap = 3;
     g.B = pb.Pp; g.ldb = ldh; g.pb = pb.pp;
     g.M = (int)V; g.N = (int)H; g.K = (int)(2 * B);
-    g.tiles_m = (int)(V / 128); g.tiles_n = (int)(H / 128); g.splitk = 1; g.kchunk = g.K;
+    g.tiles_m = (int)(V / 128); g.tiles_n = (int)(H / 128); g.splitk = sp.splitk; g.kchunk = sp.kchunk;
     g.fin_enabled = 0;
-    const bool fuse_upd = upd != nullptr && g_opt_fused_update;
+    const bool fuse_upd = upd != nullptr && g_opt_fused_update && sp.splitk == 1;
     if (fuse_upd) {
         BiasUpd bu;
         bu.hb = upd->hbias; bu.hbs = upd->hbias_speed; bu.vb = upd->vbias; bu.vbs = upd->vbias_speed;
@@ -645,13 +654,23 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     }
     HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials, n_cost, s_h,
                                  s_v, cost, nullptr, s));
-    g.fused = 0; g.C = S; g.ldc = ldh; g.slab_stride = 0;
-    HIP_OK(timed_gemm_planes(LAY_MN, LAY_MN, g, s));
-    if (upd) {
-        mdbn_update_args u = *upd;
-        u.phase = 0;
-        HIP_OK(launch_update(u, s, nullptr, 1, 0, Wp));
+    g.fused = 0; g.ldc = ldh; g.slab_stride = V * ldh;
+    mdbn_update_args u;
+    if (upd) { u = *upd; u.phase = 0; }
+    if (sp.splitk == 1) {
+        g.C = S;
+        HIP_OK(timed_gemm_planes(LAY_MN, LAY_MN, g, s));
+    } else {
+        REQUIRE(sp.slab_floats(V, ldh) <= ws.slab_floats, "internal: statistic slabs exceed workspace");
+        g.C = ws.slabs;
+        HIP_OK(timed_gemm_planes(LAY_MN, LAY_MN, g, s));
+        if (upd && g_opt_fused_update) {     // the update sums the slabs itself (same order as sum_slabs_kernel)
+            HIP_OK(launch_update(u, s, ws.slabs, sp.splitk, g.slab_stride, Wp));
+            return MDBN_OK;
+        }
+        HIP_OK(launch_sum_slabs(ws.slabs, sp.splitk, g.slab_stride, V * ldh, S, s));
     }
+    if (upd) HIP_OK(launch_update(u, s, nullptr, 1, 0, Wp));
     return MDBN_OK;
 }
 
@@ -765,6 +784,11 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     }
     if (strcmp(name, "gemm_bf16x6") == 0) {
         g_opt_gemm_bf16x6 = (int)value & 3;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "planes_mfma") == 0) {
+        if (value != 16 && value != 32) return fail(MDBN_EINVAL, "planes_mfma must be 16 or 32");
+        g_opt_planes_mfma = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "inkernel_reduce") == 0) {

@@ -47,9 +47,22 @@ __device__ __forceinline__ void pl_glds16(const void* g, unsigned lds_off, char*
                                      (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
 }
 
+// LDS-image swizzles, per MFMA shape MS (32: v_mfma_f32_32x32x16_bf16, 16: v_mfma_f32_16x16x32_bf16), chosen so that the
+// fragment reads of that shape are bank-conflict free (derivations: DESIGN.md section 3):
+//   ROW image [128 rows][64 B]: 16-byte chunk c of row r lives at chunk c ^ pl_row_swz(r)
+//   COL image [32 k][256 B]   : 16-byte chunk c of k-row k lives at chunk c ^ pl_col_swz(k)
+template <int MS> __device__ __forceinline__ int pl_row_swz(int row)
+{
+    return MS == 32 ? ((row >> 2) & 3) : ((4 - ((row >> 2) & 3)) & 3);
+}
+template <int MS> __device__ __forceinline__ int pl_col_swz(int k)
+{
+    return MS == 32 ? ((k & 3) << 2) : (((k & 3) | (((k >> 3) & 1) << 2)) << 1);
+}
+
 // One loader wave's share of the staging: instructions q = w, w + LW, ... of the 8 * (AP + 3) per stage
 // (8 per plane: 1 KiB each).
-template <int LA, int LB, int AP>
+template <int LA, int LB, int AP, int MS>
 __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, int w, int lane, int m0, int n0, int kbeg, int nt)
 {
     constexpr int NQ = 8 * (AP + 3), PER = NQ / PL_LW;
@@ -68,12 +81,12 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
         dst[j] = (isA ? plane : 3 + plane) * PL_PLANE + sub * 1024;
         if (lay == LAY_K) {      // ROW: 16 rows x 64 B per instruction
             const int row = 16 * sub + (lane >> 2);
-            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            const int c = (lane & 3) ^ pl_row_swz<MS>(row);
             src[j] = reinterpret_cast<const char*>(base + (int64_t)(mn0 + row) * ld + kbeg + 8 * c);
             step[j] = 64;
         } else {                 // COL: 4 k-rows x 256 B per instruction
             const int k = 4 * sub + (lane >> 4);
-            const int ch = (lane & 15) ^ ((k & 3) << 2);
+            const int ch = (lane & 15) ^ pl_col_swz<MS>(k);
             src[j] = reinterpret_cast<const char*>(base + (int64_t)(kbeg + k) * ld + mn0 + 8 * ch);
             step[j] = 64 * ld;
         }
@@ -116,6 +129,118 @@ __device__ __forceinline__ pbf16x8 pl_frag(const char* plane, int off0, int off1
     }
 }
 
+// MFMA waves on v_mfma_f32_16x16x32_bf16: one MFMA spans the whole 32-deep stage, a wave owns 4 x 4 tiles of 16 x 16.
+// The chip is power-limited under this load (1.3-1.6 GHz with the 32x32x16 shape) and holds a higher clock on this shape
+// at equal cycles per FLOP (1.7 GHz: scripts/experiments/planes_gemm.py; MI355X_MICROARCH.md, DVFS give-back item 7).
+// Four fragment register groups, one per operand half (two 16-row blocks x planes, 96 VGPRs in all).  The stage's tiles
+// are visited quarter by quarter in a serpentine -- (lo,lo) (lo,hi) | (hi,hi) (hi,lo), next stage (lo,hi) (lo,lo) |
+// (hi,lo) (hi,hi) -- so that consecutive quarters share one half and every quarter prefetches exactly ONE half under its
+// MFMAs: this stage's in the first two quarters, the NEXT stage's after the mid-stage barrier `|`.
+typedef float pf32x4a __attribute__((ext_vector_type(4)));
+template <int LA, int LB, int AP>
+__device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int wm, int wn, pf32x4a (&acc)[4][4])
+{
+    const int c16 = lane & 15, q = lane >> 4;
+    int offA[4][2], offB[4][2];                 // [16-row block][first / second tr read]
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        {
+            const int row = wm + 16 * b + c16;
+            if (LA == LAY_K) { offA[b][0] = row * 64 + ((q ^ pl_row_swz<16>(row)) << 4); offA[b][1] = 0; }
+            else {
+                const int ch = (wm + 16 * b) / 8 + ((c16 & 3) >> 1);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int k = 8 * q + 4 * tt + (c16 >> 2);
+                    offA[b][tt] = k * 256 + ((ch ^ pl_col_swz<16>(k)) << 4) + 8 * (c16 & 1);
+                }
+            }
+        }
+        {
+            const int row = wn + 16 * b + c16;
+            if (LB == LAY_K) { offB[b][0] = row * 64 + ((q ^ pl_row_swz<16>(row)) << 4); offB[b][1] = 0; }
+            else {
+                const int ch = (wn + 16 * b) / 8 + ((c16 & 3) >> 1);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int k = 8 * q + 4 * tt + (c16 >> 2);
+                    offB[b][tt] = k * 256 + ((ch ^ pl_col_swz<16>(k)) << 4) + 8 * (c16 & 1);
+                }
+            }
+        }
+    }
+    pbf16x8 Alo[3][2], Ahi[3][2], Blo[3][2], Bhi[3][2];
+#define RD_A(FA, BASE, HALF)                                                                  \
+    _Pragma("unroll") for (int pl = 0; pl < AP; ++pl)                                         \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
+            FA[pl][i] = pl_frag<LA>((BASE) + pl * PL_PLANE, offA[2 * (HALF) + i][0], offA[2 * (HALF) + i][1]);
+#define RD_B(FB, BASE, HALF)                                                                  \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
+            FB[pl][i] = pl_frag<LB>((BASE) + (3 + pl) * PL_PLANE, offB[2 * (HALF) + i][0], offB[2 * (HALF) + i][1]);
+#define MMQ(FA, FB, AH, BH)                                                                   \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                             \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) {     /* smallest products first */     \
+            pf32x4a& c = acc[2 * (AH) + a][2 * (BH) + b];                                     \
+            if constexpr (AP == 3) {                                                          \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[2][a], FB[0][b], c, 0, 0, 0);  \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[2][b], c, 0, 0, 0);  \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[1][a], FB[1][b], c, 0, 0, 0);  \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[1][a], FB[0][b], c, 0, 0, 0);  \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[1][b], c, 0, 0, 0);  \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], c, 0, 0, 0);  \
+            } else {        /* A = a1 exactly: a1 b3 + a1 b2 + a1 b1 is the full product */   \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[2][b], c, 0, 0, 0);  \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[1][b], c, 0, 0, 0);  \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], c, 0, 0, 0);  \
+            }                                                                                 \
+        }
+    // issue order: the prefetched half's LDS reads one by one under this quarter's MFMAs
+    constexpr int RA = 2 * AP * (LA == LAY_MN ? 2 : 1), RB = 6 * (LB == LAY_MN ? 2 : 1), NM = 4 * (AP == 3 ? 6 : 3);
+#define ORD(NR)                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < ((NR) < NM ? (NR) : NM); ++i_) {                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+    }                                                                                         \
+    if ((NR) > NM) __builtin_amdgcn_sched_group_barrier(0x100, (NR) - NM, 0);                 \
+    if (NM > (NR)) __builtin_amdgcn_sched_group_barrier(0x008, NM - (NR), 0);
+    // every LDS read of a stage must have RETURNED before the barrier that frees its slot: pin the halves read in the
+    // first two quarters ahead of the barrier (hipcc may sink loads past s_barrier, DESIGN.md "guarded reload")
+#define PIN(FA, NPL)                                                                          \
+    _Pragma("unroll") for (int pl = 0; pl < (NPL); ++pl)                                      \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(FA[pl][i]));
+    __syncthreads();                                 // stage 0 landed
+    RD_A(Alo, smem, 0);
+    RD_B(Blo, smem, 0);
+    for (int it = 0; it < nt; it += 2) {
+        {   // even stage: enters holding (Alo, Blo)
+            const char* base = smem + (it % PL_NSTAGE) * PL_STAGE;
+            const char* next = smem + ((it + 1) % PL_NSTAGE) * PL_STAGE;
+            RD_B(Bhi, base, 1); MMQ(Alo, Blo, 0, 0); ORD(RB);
+            RD_A(Ahi, base, 1); MMQ(Alo, Bhi, 0, 1); ORD(RA);
+            PIN(Bhi, 3); PIN(Ahi, AP);
+            __syncthreads();                         // every read of stage `it` is done; stage it + 1 has landed
+            RD_A(Alo, next, 0); MMQ(Ahi, Bhi, 1, 1); ORD(RA);
+            RD_B(Bhi, next, 1); MMQ(Ahi, Blo, 1, 0); ORD(RB);
+        }
+        if (it + 1 < nt) {   // odd stage: enters holding (Alo, Bhi)
+            const char* base = smem + ((it + 1) % PL_NSTAGE) * PL_STAGE;
+            const char* next = smem + ((it + 2) % PL_NSTAGE) * PL_STAGE;
+            RD_B(Blo, base, 0); MMQ(Alo, Bhi, 0, 1); ORD(RB);
+            RD_A(Ahi, base, 1); MMQ(Alo, Blo, 0, 0); ORD(RA);
+            PIN(Blo, 3); PIN(Ahi, AP);
+            __syncthreads();
+            RD_A(Alo, next, 0); MMQ(Ahi, Blo, 1, 0); ORD(RA);
+            RD_B(Blo, next, 0); MMQ(Ahi, Bhi, 1, 1); ORD(RB);
+        }
+    }
+#undef RD_A
+#undef RD_B
+#undef MMQ
+#undef ORD
+#undef PIN
+}
+
 // FUSED: 0 = split-K slab / plain C store; 1 = activation + sampling epilogue on the parked tile (unsplit
 // forward pass); 2 = statistics GEMM: finalize units on the ramp-up, parameter update (+ W planes) on the
 // parked tile; 3 = split-K forward pass reduced INSIDE the launch (below).  AP = planes of A (3, or 1 for 0/1 samples).
@@ -130,7 +255,7 @@ __device__ __forceinline__ pbf16x8 pl_frag(const char* plane, int off0, int off1
 // two-launch path and independent of which block arrived last -- and runs the activation epilogue on the sum.
 // Nothing depends on dispatch order or XCD placement; no block ever waits for another (no spin, no deadlock).
 // The reducer zeroes the counter for the next launch (the context allocates the counters zeroed).
-template <int LA, int LB, int AP, int FUSED>
+template <int LA, int LB, int AP, int FUSED, int MS>
 __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemmArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -151,7 +276,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
     const int lane = threadIdx.x & 63;
 
     if (wave >= 4) {
-        pl_loader<LA, LB, AP>(g, smem, wave - 4, lane, m0, n0, kbeg, nt);
+        pl_loader<LA, LB, AP, MS>(g, smem, wave - 4, lane, m0, n0, kbeg, nt);
         if constexpr (FUSED == 0) return;
     } else {
         const int r = lane & 31, h = lane >> 5;
@@ -163,6 +288,37 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
                     finalize_unit(g.fin, unit, lane);
             }
         }
+        if constexpr (MS == 16) {
+            pf32x4a acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = pf32x4a{0.f, 0.f, 0.f, 0.f};
+            pl_consume16<LA, LB, AP>(smem, nt, lane, wm, wn, acc);
+            // accumulator (16x16): col = lane & 15, row = 4 * (lane >> 4) + e
+            const int c16 = lane & 15, q4 = lane >> 4;
+            if constexpr (FUSED != 0) {
+                float* T = reinterpret_cast<float*>(smem);
+                constexpr int LDT = 128 + 8;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            T[(wm + 16 * a + 4 * q4 + e) * LDT + wn + 16 * b + c16] = acc[a][b][e];
+            } else {
+                float* C = g.C + (int64_t)ks * g.slab_stride;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            C[(int64_t)(m0 + wm + 16 * a + 4 * q4 + e) * g.ldc + n0 + wn + 16 * b + c16] = acc[a][b][e];
+                return;
+            }
+        } else {
         // fragment byte offsets inside a plane image: [32-row block][k16 step][first / second tr read]
         int offA[2][2][2], offB[2][2][2];
 #pragma unroll
@@ -288,6 +444,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
                 }
             return;
         }
+            }
     }
     if constexpr (FUSED != 0) {     // all 8 waves work on the parked tile (every DMA has landed: the loaders drained vmcnt)
         __syncthreads();
@@ -344,10 +501,10 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
     }
 }
 
-template <int LA, int LB, int AP, int FUSED>
-static hipError_t launch_planes_t(const PlaneGemmArgs& g, hipStream_t s)
+template <int LA, int LB, int AP, int FUSED, int MS>
+static hipError_t launch_planes_m(const PlaneGemmArgs& g, hipStream_t s)
 {
-    auto kern = gemm_planes_kernel<LA, LB, AP, FUSED>;
+    auto kern = gemm_planes_kernel<LA, LB, AP, FUSED, MS>;
     static bool attr_set = false;
     constexpr int lds = PL_NSTAGE * PL_STAGE;        // 144 KB (the parked tile of the epilogues, 70 KB, reuses it)
     if (!attr_set) {
@@ -357,6 +514,12 @@ static hipError_t launch_planes_t(const PlaneGemmArgs& g, hipStream_t s)
     }
     hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n * g.splitk), dim3(64 * (4 + PL_LW)), lds, s, g);
     return hipGetLastError();
+}
+
+template <int LA, int LB, int AP, int FUSED>
+static hipError_t launch_planes_t(const PlaneGemmArgs& g, hipStream_t s)
+{
+    return g.ms == 32 ? launch_planes_m<LA, LB, AP, FUSED, 32>(g, s) : launch_planes_m<LA, LB, AP, FUSED, 16>(g, s);
 }
 
 hipError_t launch_gemm_planes(int la, int lb, const PlaneGemmArgs& g, hipStream_t s)

@@ -64,9 +64,10 @@ def test_split_of_non_finite_values(hip_engine):
     assert np.isnan(p2[0]) and np.isnan(p2[1]) and np.isnan(p2[2]) and p2[3] == 0.0 and p3[3] == 0.0
 
 
-def _run_steps(eng, gauss, planes, V, H, B, k, steps=3, seed=0):
+def _run_steps(eng, gauss, planes, V, H, B, k, steps=3, seed=0, mfma=16):
     import mdbn_amd
     eng.set_option("gemm_planes", int(planes))
+    eng.set_option("planes_mfma", mfma)
     rs = np.random.RandomState(seed)
     N = 4 * B
     data = rs.normal(size=(N, V)).astype(np.float32) if gauss else (rs.uniform(size=(N, V)) < 0.3).astype(np.float32)
@@ -80,14 +81,23 @@ def _run_steps(eng, gauss, planes, V, H, B, k, steps=3, seed=0):
                vbs=rbm.vbias_speed.get_value())
     wp, valid = eng.w_planes(rbm.W.tensor)
     eng.set_option("gemm_planes", 1)
+    eng.set_option("planes_mfma", 16)
     return out, rbm, wp, valid
 
 
 @pytest.mark.parametrize("gauss,V,H,B,k", [(True, 4096, 1024, 512, 1), (False, 1024, 512, 512, 1), (True, 1024, 768, 256, 3),
                                            (False, 2048, 1024, 384, 2)])
 def test_plane_step_equals_f32_operand_step_bit_for_bit(hip_engine, gauss, V, H, B, k):
+    """With the 32x32x16 MFMA shape the plane GEMMs issue the products of gemm_bf16x6_kernel in the same order and follow
+    the same split-K plans: every parameter, speed and sample equals the f32-operand step bit for bit.  The default
+    16x16x32 shape sums each 32-deep stage in one MFMA instead of two: same products, another fp32 summation order."""
     a, _, _, _ = _run_steps(hip_engine, gauss, False, V, H, B, k)
-    b, rbm, wp, valid = _run_steps(hip_engine, gauss, True, V, H, B, k)
+    b, rbm, wp, valid = _run_steps(hip_engine, gauss, True, V, H, B, k, mfma=32)
+    c, _, _, _ = _run_steps(hip_engine, gauss, True, V, H, B, k, mfma=16)
+    for key in ("W", "Ws", "hb", "vbs"):
+        scale = max(1e-3, np.abs(a[key]).max())
+        assert np.abs(c[key] - a[key]).max() <= 2e-5 * scale, key
+    np.testing.assert_allclose(c["costs"], a["costs"], rtol=1e-4)
     for key in a:
         if key == "costs":       # the monitoring cost is summed from per-tile instead of per-epilogue-block partials
             np.testing.assert_allclose(a[key], b[key], rtol=2e-6)
