@@ -79,6 +79,32 @@ def run_pcd(group_mode):
                 chain=chain.tensor.numpy().copy(), span=np.array([lo, hi]), bit=np.array([rbm.bit_i_idx]))
 
 
+def run_mdbn(group_mode):
+    """The c5 stacking (MDBN.train_bottom_layer x 2 modalities + a joint layer) with every layer's step function data
+    parallel: nothing in DBN.training / MDBN knows about ranks, the step functions shard each minibatch themselves."""
+    import mdbn_amd
+    from mdbn_amd import MDBN
+    from _oracle_engine import OracleEngine
+    mdbn_amd.set_engine(OracleEngine())
+    mdbn_amd.DBN.verbose = False
+    rs = np.random.RandomState(0)
+    rng = np.random.RandomState(123)
+    np.random.seed(7)                    # the shuffles (utils.py:62) must agree on every rank
+    outs, Ws = [], []
+    for width, sizes in ((20, [8, 4]), (12, [5])):
+        x = rs.normal(size=(24, width))
+        net, out_t, _ = MDBN.train_bottom_layer(x, None, batch_size=8, k=2, layers_sizes=sizes,
+                                                pretraining_epochs=[3] * len(sizes),
+                                                pretrain_lr=[0.005] + [0.1] * (len(sizes) - 1), rng=rng)
+        outs.append(out_t)
+        Ws.extend(p.get_value() for p in net.params)
+    joint = np.concatenate(outs, axis=1)
+    top = mdbn_amd.DBN(numpy_rng=rng, n_ins=joint.shape[1], gauss=False, hidden_layers_sizes=[6], n_outs=3)
+    top.training(mdbn_amd.shared(joint), batch_size=8, k=1, pretraining_epochs=[3, 3], pretrain_lr=[0.1, 0.1])
+    Ws.extend(p.get_value() for p in top.params)
+    return {"p%d" % i: w for i, w in enumerate(Ws)} | {"out": top.get_output(joint)}
+
+
 def run_interleaved(overlap, group_mode):
     """Two step functions of the SAME shape (two equal-sized modalities) called alternately: with the
     all-reduce of each deferred by one call, neither may see the other's pending statistics."""
@@ -116,6 +142,8 @@ def worker(rank, world, port, outdir, gauss, overlap):
     dist.init_from_env(backend="gloo")
     if gauss == 3:
         out = run_pcd(True)
+    elif gauss == 4:
+        out = run_mdbn(True)
     else:
         out = run_interleaved(overlap, True) if gauss == 2 else run_steps(gauss, overlap, True)
     np.savez(os.path.join(outdir, "rank%d_%d_%d.npz" % (rank, gauss, overlap)), **out)
@@ -127,8 +155,8 @@ def worker(rank, world, port, outdir, gauss, overlap):
 def dp_results():
     res = {}
     with tempfile.TemporaryDirectory() as d:
-        for gauss in (1, 0, 2, 3):          # 2 = two step functions interleaved, 3 = PCD (synchronous only)
-            for overlap in ((0,) if gauss == 3 else (0, 1)):
+        for gauss in (1, 0, 2, 3, 4):       # 2 = two step functions interleaved, 3 = PCD (synchronous only), 4 = MDBN stack
+            for overlap in ((0,) if gauss in (3, 4) else (0, 1)):
                 mp.spawn(worker, args=(2, free_port(), d, gauss, overlap), nprocs=2, join=True)
                 res[(gauss, overlap)] = [dict(np.load(os.path.join(d, "rank%d_%d_%d.npz" % (r, gauss, overlap))))
                                          for r in range(2)]
@@ -174,6 +202,16 @@ def test_pcd_under_data_parallelism(dp_results):
     for r in (r0, r1):
         lo, hi = r["span"]
         assert hi > lo and np.array_equal(r["chain"][lo:hi], single["chain"][lo:hi])
+
+
+def test_mdbn_stack_under_data_parallelism(dp_results):
+    """BASELINE configs[4]'s structure on two ranks: identical replicas, equal to the single-process run."""
+    sys.path.insert(0, HERE)
+    single = run_mdbn(False)
+    r0, r1 = dp_results[(4, 0)]
+    for k in single:
+        assert np.array_equal(r0[k], r1[k]), k
+        np.testing.assert_allclose(r0[k], single[k], rtol=2e-5, atol=1e-7, err_msg=k)      # float32 get_value round trips
 
 
 def test_shard_bounds():

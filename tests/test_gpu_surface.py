@@ -368,3 +368,36 @@ def test_rccl_communicator_through_the_c_abi(hip_engine):
     finally:
         _lib.check(eng.lib.mdbn_comm_destroy(eng.ctx), "mdbn_comm_destroy")
     assert eng.lib.mdbn_allreduce_stats(eng.ctx, None, C.c_void_p(x.data_ptr()), 4) != 0
+
+
+def test_config5_three_modality_mdbn_at_batch_512(shadow):
+    """BASELINE configs[4] at its stated batch size: GE 2048 -> 400 -> 40, miRNA 512 -> 40, SM 256 -> 200 -> 20 with
+    CD-5 on the Gaussian first layers, B = 512, concatenated 100 -> joint Bernoulli layer 128 -> 3; one numpy
+    RandomState threaded miRNA -> GE -> SM -> top as AMLsm2.py:38-62.  Every CD step on the device is replayed by the
+    float64 oracle along the device's chain (k = 5 included)."""
+    import mdbn_amd
+    from mdbn_amd import MDBN
+    mdbn_amd.DBN.verbose = False
+    rs = np.random.RandomState(0)
+    N, B = 1024, 512
+    ge = rs.normal(size=(N, 2048)).astype(np.float32)
+    me = rs.normal(size=(N, 512)).astype(np.float32)
+    sm = (rs.uniform(size=(N, 256)) < 0.02).astype(np.float32)
+    sm = ((sm - sm.mean(0)) / (sm.std(0) + 1e-3)).astype(np.float32)
+    rng = np.random.RandomState(123)
+    np.random.seed(3)
+    shadow.tie = 2e-5
+    outs, nets = [], []
+    for data, sizes, lr in ((me, [40], [0.002]), (ge, [400, 40], [0.001, 0.1]), (sm, [200, 20], [0.002, 0.1])):
+        net, out_t, _ = MDBN.train_bottom_layer(data, None, batch_size=B, k=5, layers_sizes=sizes,
+                                                pretraining_epochs=[3] * len(sizes), pretrain_lr=lr, rng=rng)
+        outs.append(out_t)
+        nets.append(net)
+    joint = np.concatenate(outs, axis=1)
+    assert joint.shape == (N, 100)
+    top = mdbn_amd.DBN(numpy_rng=rng, n_ins=100, gauss=False, hidden_layers_sizes=[128], n_outs=3, engine=shadow)
+    top.training(mdbn_amd.shared(joint, engine=shadow), batch_size=B, k=1, pretraining_epochs=[4, 4], pretrain_lr=[0.1, 0.1])
+    assert shadow.steps >= 2 * (3 + 6 + 6) and shadow.cost_err <= 2e-4, (shadow.steps, shadow.cost_err)
+    for net in nets + [top]:
+        for r in net.rbm_layers:
+            assert shadow.param_err(r) <= 5e-5
