@@ -151,7 +151,11 @@ int  mdbn_ctx_destroy(mdbn_ctx *ctx);
  *   register-streaming kernel (no LDS staging); "skinny_fused_max_k" (default 1024) largest K one
  *   block streams alone, "skinny_max_macs" (default 32 Mi) size limit above 64 rows.
  * "gemm_planes" (default 1): use the bf16 plane path of mdbn_cd_args when its buffers are given and the
- *   shape qualifies.
+ *   shape qualifies.  "planes_mfma" (default 16): its MFMA shape, 16 = v_mfma_f32_16x16x32_bf16, 32 =
+ *   v_mfma_f32_32x32x16_bf16 (bit-identical to the f32-operand path).  "inkernel_reduce" (default 0): sum the
+ *   split-K partials of its forward passes inside the GEMM launch (same bits; measured slower).
+ * "bf16_inputs" (default 0): REPORTING mode, not a parity path: the plane GEMMs use only the leading bf16 piece of
+ *   every operand (one product instead of six; probabilities off by ~4e-3).
  * "update_overlap": 1 = mdbn_cd_train_step overlaps part of the update with the statistics GEMM
  * on a side stream (default 0: measured slower, see csrc/mdbn_capi.hip). */
 int  mdbn_set_option(mdbn_ctx *ctx, const char *name, int64_t value);
@@ -164,7 +168,7 @@ int  mdbn_kernel_timing_read(mdbn_ctx *ctx, int64_t *n_launches, double *total_m
 /* Per recorded launch (up to `cap`): duration, algorithmic FLOPs 2*M*N*K, FLOPs issued on the matrix
  * pipe the kernel runs on (x6 / x3 for the split-operand bf16 kernels), and
  * kind = 1000*family (0 LDS-tiled, f32 operands; 1 register-streaming; 2 bf16 planes)
- *        + 100*pipe (0 exact-f32 MFMA, 1 bf16 six products, 2 bf16 three products)
+ *        + 100*pipe (0 exact-f32 MFMA, 1 bf16 six products, 2 bf16 three products, 3 bf16 one product)
  *        + 10*fused + 2*la + lb  ((la, lb): 1 = propup, 0 = propdown, 3 = statistics).
  * *n_launches receives the number recorded (may exceed cap). */
 int  mdbn_kernel_timing_detail(mdbn_ctx *ctx, int64_t cap, double *ms, double *alg_flop,

@@ -100,7 +100,8 @@ struct PlaneGemmArgs {
     const unsigned short* B; int64_t ldb, pb;   // planes [3][.][ldb]
     float* C; int64_t ldc, slab_stride;         // fused == 0: slabs [splitk][M][ldc] (or plain C)
     int M, N, K, kchunk, splitk, tiles_m, tiles_n;
-    int ap;                // planes of A: 3, or 1 when A holds 0/1 samples (three products instead of six)
+    int ap;                // planes of A: 3, or 1 when A holds 0/1 samples (three products instead of six);
+                           // 0 = bf16-input reporting mode: the leading plane of each operand, ONE product
     int ms;                // MFMA shape: 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16
     int fused;             // 0 | 1 activation epilogue (epi) | 2 parameter update (upd) + finalize units (fin)
                            // | 3 split-K with the reduction INSIDE the launch: every block publishes its partial tile

@@ -65,15 +65,17 @@ template <int MS> __device__ __forceinline__ int pl_col_swz(int k)
 template <int LA, int LB, int AP, int MS>
 __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, int w, int lane, int m0, int n0, int kbeg, int nt)
 {
-    constexpr int NQ = 8 * (AP + 3), PER = NQ / PL_LW;
+    // AP = planes of A (3 | 1); AP = 0 is the bf16-input REPORTING mode: one plane of each operand, one product
+    constexpr int NA = AP == 3 ? 3 : 1, NB = AP == 0 ? 1 : 3;
+    constexpr int NQ = 8 * (NA + NB), PER = NQ / PL_LW;
     const char* src[PER];
     unsigned dst[PER];
     int64_t step[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int q = w + j * PL_LW;
-        const bool isA = q < 8 * AP;
-        const int plane = isA ? q / 8 : (q - 8 * AP) / 8, sub = q & 7;
+        const bool isA = q < 8 * NA;
+        const int plane = isA ? q / 8 : (q - 8 * NA) / 8, sub = q & 7;
         const int lay = isA ? LA : LB;
         const unsigned short* base = isA ? g.A + plane * g.pa : g.B + plane * g.pb;
         const int64_t ld = isA ? g.lda : g.ldb;
@@ -169,13 +171,14 @@ __device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int w
             }
         }
     }
+    constexpr int NA = AP == 3 ? 3 : 1, NB = AP == 0 ? 1 : 3;      // AP = 0: bf16-input reporting mode (one product)
     pbf16x8 Alo[3][2], Ahi[3][2], Blo[3][2], Bhi[3][2];
 #define RD_A(FA, BASE, HALF)                                                                  \
-    _Pragma("unroll") for (int pl = 0; pl < AP; ++pl)                                         \
+    _Pragma("unroll") for (int pl = 0; pl < NA; ++pl)                                         \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
             FA[pl][i] = pl_frag<LA>((BASE) + pl * PL_PLANE, offA[2 * (HALF) + i][0], offA[2 * (HALF) + i][1]);
 #define RD_B(FB, BASE, HALF)                                                                  \
-    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                          \
+    _Pragma("unroll") for (int pl = 0; pl < NB; ++pl)                                         \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
             FB[pl][i] = pl_frag<LB>((BASE) + (3 + pl) * PL_PLANE, offB[2 * (HALF) + i][0], offB[2 * (HALF) + i][1]);
 #define MMQ(FA, FB, AH, BH)                                                                   \
@@ -189,14 +192,17 @@ __device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int w
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[1][a], FB[0][b], c, 0, 0, 0);  \
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[1][b], c, 0, 0, 0);  \
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], c, 0, 0, 0);  \
-            } else {        /* A = a1 exactly: a1 b3 + a1 b2 + a1 b1 is the full product */   \
+            } else if constexpr (AP == 1) {   /* A = a1 exactly: a1 b3 + a1 b2 + a1 b1 is the full product */ \
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[2][b], c, 0, 0, 0);  \
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[1][b], c, 0, 0, 0);  \
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], c, 0, 0, 0);  \
+            } else {        /* bf16 inputs: the leading pieces only */                        \
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], c, 0, 0, 0);  \
             }                                                                                 \
         }
     // issue order: the prefetched half's LDS reads one by one under this quarter's MFMAs
-    constexpr int RA = 2 * AP * (LA == LAY_MN ? 2 : 1), RB = 6 * (LB == LAY_MN ? 2 : 1), NM = 4 * (AP == 3 ? 6 : 3);
+    constexpr int RA = 2 * NA * (LA == LAY_MN ? 2 : 1), RB = 2 * NB * (LB == LAY_MN ? 2 : 1),
+                  NM = 4 * (AP == 3 ? 6 : (AP == 1 ? 3 : 1));
 #define ORD(NR)                                                                               \
     _Pragma("unroll") for (int i_ = 0; i_ < ((NR) < NM ? (NR) : NM); ++i_) {                  \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
@@ -218,7 +224,7 @@ __device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int w
             const char* next = smem + ((it + 1) % PL_NSTAGE) * PL_STAGE;
             RD_B(Bhi, base, 1); MMQ(Alo, Blo, 0, 0); ORD(RB);
             RD_A(Ahi, base, 1); MMQ(Alo, Bhi, 0, 1); ORD(RA);
-            PIN(Bhi, 3); PIN(Ahi, AP);
+            PIN(Bhi, NB); PIN(Ahi, NA);
             __syncthreads();                         // every read of stage `it` is done; stage it + 1 has landed
             RD_A(Alo, next, 0); MMQ(Ahi, Bhi, 1, 1); ORD(RA);
             RD_B(Bhi, next, 1); MMQ(Ahi, Blo, 1, 0); ORD(RB);
@@ -228,7 +234,7 @@ __device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int w
             const char* next = smem + ((it + 2) % PL_NSTAGE) * PL_STAGE;
             RD_B(Blo, base, 0); MMQ(Alo, Bhi, 0, 1); ORD(RB);
             RD_A(Ahi, base, 1); MMQ(Alo, Blo, 0, 0); ORD(RA);
-            PIN(Blo, 3); PIN(Ahi, AP);
+            PIN(Blo, NB); PIN(Ahi, NA);
             __syncthreads();
             RD_A(Alo, next, 0); MMQ(Ahi, Blo, 1, 0); ORD(RA);
             RD_B(Blo, next, 0); MMQ(Ahi, Bhi, 1, 1); ORD(RB);
@@ -519,14 +525,15 @@ static hipError_t launch_planes_m(const PlaneGemmArgs& g, hipStream_t s)
 template <int LA, int LB, int AP, int FUSED>
 static hipError_t launch_planes_t(const PlaneGemmArgs& g, hipStream_t s)
 {
-    return g.ms == 32 ? launch_planes_m<LA, LB, AP, FUSED, 32>(g, s) : launch_planes_m<LA, LB, AP, FUSED, 16>(g, s);
+    if constexpr (AP == 0) return launch_planes_m<LA, LB, 0, FUSED, 16>(g, s);        // reporting mode: 16x16x32 only
+    else return g.ms == 32 ? launch_planes_m<LA, LB, AP, FUSED, 32>(g, s) : launch_planes_m<LA, LB, AP, FUSED, 16>(g, s);
 }
 
 hipError_t launch_gemm_planes(int la, int lb, const PlaneGemmArgs& g, hipStream_t s)
 {
     if (g.M % 128 || g.N % 128 || g.kchunk % 32 || g.kchunk * g.splitk != g.K || g.tiles_m != g.M / 128 ||
         g.tiles_n != g.N / 128 || (g.lda & 7) || (g.ldb & 7) || ((g.fused == 1 || g.fused == 2) && g.splitk != 1) ||
-        (g.ap != 1 && g.ap != 3))
+        (g.ap != 0 && g.ap != 1 && g.ap != 3))
         return hipErrorInvalidValue;
     if (g.fused == 3 && (g.counters == nullptr || (int64_t)g.splitk * g.slab_stride * 4 >= (int64_t)1 << 31))
         return hipErrorInvalidValue;
@@ -539,6 +546,9 @@ hipError_t launch_gemm_planes(int la, int lb, const PlaneGemmArgs& g, hipStream_
     PL_CASE(LAY_K, LAY_K, 3, 0); PL_CASE(LAY_K, LAY_K, 3, 1); PL_CASE(LAY_K, LAY_K, 1, 0); PL_CASE(LAY_K, LAY_K, 1, 1);
     // statistics: [v0; nv]^T planes (COL) x [ph; -nh] planes (COL)
     PL_CASE(LAY_MN, LAY_MN, 3, 0); PL_CASE(LAY_MN, LAY_MN, 3, 2);
+    // bf16-input reporting mode (one product; never used for parity)
+    PL_CASE(LAY_K, LAY_MN, 0, 0); PL_CASE(LAY_K, LAY_MN, 0, 1); PL_CASE(LAY_K, LAY_K, 0, 0); PL_CASE(LAY_K, LAY_K, 0, 1);
+    PL_CASE(LAY_MN, LAY_MN, 0, 0); PL_CASE(LAY_MN, LAY_MN, 0, 2);
 #undef PL_CASE
     return hipErrorInvalidValue;
 }

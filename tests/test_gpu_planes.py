@@ -196,3 +196,34 @@ def test_in_launch_splitk_reduction_is_bitwise_and_repeatable(hip_engine, gauss,
             else:
                 assert np.array_equal(runs[0][key], other[key]), key
     assert np.array_equal(runs[0]["costs"], runs[2]["costs"]) and np.array_equal(runs[0]["costs"], runs[3]["costs"])
+
+
+def test_bf16_input_reporting_mode(hip_engine):
+    """mdbn_set_option("bf16_inputs", 1): one product on the leading bf16 pieces.  A reporting mode (BASELINE configs[1]
+    names "bf16/fp32"), not a parity path: probabilities within 1e-2 of the oracle, far outside the 2e-6 of the default
+    path -- and switching it off restores the f32-grade results exactly."""
+    from mdbn_amd import RngAddr
+    eng = hip_engine
+    V, H, B = 1024, 512, 256
+    rs = np.random.RandomState(4)
+    W = rbm_np.init_W(rs, V, H, np.float32)
+    hb, vb = rs.normal(0, 0.2, H).astype(np.float32), rs.normal(0, 0.2, V).astype(np.float32)
+    x = rs.normal(size=(B, V)).astype(np.float32)
+    dW, dhb, dvb, dx = [eng.to_device(a) for a in (W, hb, vb, x)]
+    st = rbm_np.RBMState(V, H, W=W, hbias=hb, vbias=vb, gauss=True)
+    _, ph = rbm_np.propup(st, x.astype(np.float64))
+    ref, _ = eng.cd_step(dx, None, dW, dhb, dvb, True, 1, RngAddr(2, 0, 0, 0, 0))
+    ref_stats = ref.clone()
+    sc = eng.last_scratch
+    good = sc.P2[:B].cpu().numpy().copy()
+    assert np.abs(good - ph).max() <= 2e-6
+    eng.set_option("bf16_inputs", 1)
+    try:
+        eng.cd_step(dx, None, dW, dhb, dvb, True, 1, RngAddr(2, 0, 0, 0, 0))
+        rough = eng.last_scratch.P2[:B].cpu().numpy().copy()
+    finally:
+        eng.set_option("bf16_inputs", 0)
+    err = np.abs(rough - ph).max()
+    assert 1e-5 < err <= 1e-2, err
+    again, _ = eng.cd_step(dx, None, dW, dhb, dvb, True, 1, RngAddr(2, 0, 0, 0, 0))
+    assert torch.equal(again, ref_stats) and np.array_equal(eng.last_scratch.P2[:B].cpu().numpy(), good)
