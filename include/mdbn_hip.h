@@ -58,7 +58,10 @@ typedef struct mdbn_cd_args {
     int32_t      add_noise;   /* GRBM only: 1 = error_free False (rbm.py:652-658)                */
     int32_t      sample_stats;/* 1 = negative visible statistics from nv_SAMPLE, not nv_mean: the
                                * chain_end of compute_symbolic_grad (rbm.py:339-342,378-390)      */
-    int32_t      reserved0;
+    int32_t      keep_f32;    /* plane path only: 1 = also store the float32 copies of ph_mean, -nh_mean (P2), nv_mean
+                               * (rows B.. of V2) and the chain samples (hs, vs) that only an inspecting caller reads;
+                               * 0 = planes only (v0 in V2[0..B) and the statistics are always written).  The
+                               * f32-operand path always writes them; trace_h / trace_v imply 1                      */
     int32_t      k;           /* Gibbs steps                                                     */
     int64_t      B, V, H;     /* local minibatch rows, n_visible, n_hidden                       */
     int64_t      ldv, ldh;    /* leading dims of [.,V] and [.,H] matrices (W uses ldh)           */

@@ -19,7 +19,7 @@ class Rng(C.Structure):
 class CdArgs(C.Structure):
     _fields_ = [("data", C.c_void_p), ("n_data", C.c_int64), ("indexes", C.c_void_p),
                 ("index_is_64", C.c_int32), ("gauss", C.c_int32), ("add_noise", C.c_int32),
-                ("sample_stats", C.c_int32), ("reserved0", C.c_int32), ("k", C.c_int32), ("B", C.c_int64), ("V", C.c_int64), ("H", C.c_int64),
+                ("sample_stats", C.c_int32), ("keep_f32", C.c_int32), ("k", C.c_int32), ("B", C.c_int64), ("V", C.c_int64), ("H", C.c_int64),
                 ("ldv", C.c_int64), ("ldh", C.c_int64),
                 ("W", C.c_void_p), ("hbias", C.c_void_p), ("vbias", C.c_void_p),
                 ("persistent", C.c_void_p),

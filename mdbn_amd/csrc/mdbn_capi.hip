@@ -581,6 +581,8 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     }
     unsigned short* Wp = reinterpret_cast<unsigned short*>(a->W_planes);
     if (!a->W_planes_valid) HIP_OK(launch_split_planes(a->W, V, ldh, Wp, V * ldh, s));
+    // float32 copies nobody on the path reads (the GEMMs take planes, the bias statistics their column partials)
+    const bool keep = a->keep_f32 != 0 || a->trace_h != nullptr || a->trace_v != nullptr;
 
     float* v0 = a->V2;
     float* nv = a->V2 + B * ldv;
@@ -592,7 +594,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     auto key = [&](uint32_t draw) { PhiloxKey k = make_key(a->rng, draw); return k; };
     {   // positive phase: ph_mean (+ planes), h0 sample (f32 for the taps, plane for the chain)   (rbm.py:303)
         EpiArgs e{};
-        e.ld = ldh; e.bias = a->hbias; e.mean = ph; e.sample = a->hs; e.mean_scale = 1.0f; e.gauss = 0;
+        e.ld = ldh; e.bias = a->hbias; e.mean = keep ? ph : nullptr; e.sample = keep ? a->hs : nullptr; e.mean_scale = 1.0f; e.gauss = 0;
         e.colsum = ws.colPpos; e.colsum_kind = 0; e.rng = key(0);
         e.mean_planes = pb.Pp; e.plane_stride = pb.pp; e.sample_plane = pb.hsp;
         CHECK(run_affine_planes(ctx, pb.Xp, ldv, pb.px, 3, 0, Wp, V, H, B, e, false, ws, s, nullptr));
@@ -603,8 +605,8 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
         const bool last = t == a->k;
         {   // v_t | h_{t-1}: the chain state is our own 0/1 sample: one plane, three products
             EpiArgs e{};
-            e.ld = ldv; e.bias = a->vbias; e.mean = nv; e.mean_scale = 1.0f; e.gauss = a->gauss;
-            e.sample = a->gauss ? nullptr : a->vs; e.rng = key((uint32_t)(2 * t - 1));
+            e.ld = ldv; e.bias = a->vbias; e.mean = keep ? nv : nullptr; e.mean_scale = 1.0f; e.gauss = a->gauss;
+            e.sample = (a->gauss || !keep) ? nullptr : a->vs; e.rng = key((uint32_t)(2 * t - 1));
             e.mean_planes = pb.Xp + B * ldv; e.plane_stride = pb.px;      // rows B..2B-1 of the X2 planes
             e.sample_plane = a->gauss ? nullptr : pb.vsp;
             if (last) { e.target = v0; e.ld_target = ldv; e.colsum = ws.colV; e.colsum_kind = 1; }
@@ -616,8 +618,8 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
         {   // h_t | v_t: from the mean for GRBM (rbm.py:669), from the 0/1 sample for RBM (rbm.py:246)
             const bool need_sample = !last;
             EpiArgs e{};
-            e.ld = ldh; e.bias = a->hbias; e.mean = nh; e.mean_scale = -1.0f; e.gauss = 0;
-            e.sample = need_sample ? a->hs : nullptr; e.rng = key((uint32_t)(2 * t));
+            e.ld = ldh; e.bias = a->hbias; e.mean = keep ? nh : nullptr; e.mean_scale = -1.0f; e.gauss = 0;
+            e.sample = (need_sample && keep) ? a->hs : nullptr; e.rng = key((uint32_t)(2 * t));
             e.mean_planes = pb.Pp + B * ldh; e.plane_stride = pb.pp;       // rows B..2B-1 of the P2 planes: -nh_mean
             e.sample_plane = need_sample ? pb.hsp : nullptr;
             if (last) { e.colsum = ws.colPneg; e.colsum_kind = 0; }

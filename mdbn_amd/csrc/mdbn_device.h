@@ -248,7 +248,7 @@ __device__ __forceinline__ void store_planes4(unsigned short* P, int64_t plane_s
 
 __device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, float x2, float x3, int r0, int col, bool live, float& cost)
 {
-    const bool need_u = e.sample != nullptr;
+    const bool need_u = e.sample != nullptr || e.sample_plane != nullptr;
     const bool need_z = need_u && e.gauss;
     uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
     if (need_u) {

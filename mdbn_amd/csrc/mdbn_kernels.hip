@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
 #pragma unroll
             for (int j = 0; j < CW; ++j) pre[r][j] += bias[j];
         uint32_t wa[CW][4], wb[CW][4];       // [col][row]
-        const bool need_u = e.sample != nullptr;
+        const bool need_u = e.sample != nullptr || e.sample_plane != nullptr;
         const bool need_z = need_u && e.gauss;
         if (need_u) {
             const uint64_t g0 = e.rng.row_offset + (uint64_t)r0;

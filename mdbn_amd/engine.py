@@ -142,6 +142,8 @@ class HipEngine(object):
         return t.detach().cpu().numpy()
 
     trace_chain = False         # True: every CD step also records the samples its Gibbs chain feeds onward
+    keep_f32 = False            # True: the plane path also stores the float32 copies of ph / nh / nv / samples in the
+                                # CD scratch (CDScratch.P2, V2[B:], hs, vs) for inspection; nothing on the path reads them
     check_indexes = False       # True: also range-check index lists that already live on the device (one sync)
 
     def index_tensor(self, indexes, n_rows=None):
@@ -365,6 +367,7 @@ class HipEngine(object):
         a.index_is_64 = int(idx is not None and idx.dtype == torch.int64)
         a.gauss, a.add_noise, a.k = int(bool(gauss)), int(bool(add_noise)), int(k)
         a.sample_stats = int(bool(sample_stats))
+        a.keep_f32 = int(bool(self.keep_f32))
         a.B, a.V, a.H = B, V, H
         a.ldv, a.ldh = ldv, ldh
         a.W, a.hbias, a.vbias = W.data_ptr(), hbias.data_ptr(), vbias.data_ptr()

@@ -25,7 +25,9 @@ def hip_engine(built_lib):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import mdbn_amd
-    return mdbn_amd.set_engine(mdbn_amd.HipEngine())
+    eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
+    eng.keep_f32 = True          # the parity tests inspect ph / nh / nv in the CD scratch (the product default skips those copies)
+    return eng
 
 
 @pytest.fixture()

@@ -73,9 +73,11 @@ def test_two_ranks_equal_one_process_on_device(built_lib, shape):
         r0, r1 = res[overlap]
         for k in single:
             assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
-            # two K-halves summed by the all-reduce instead of one K-long fp32 chain: rounding of order
-            # eps * sqrt(K) on values of the statistics' magnitude
-            tol = (2e-6 if shape == "small" else 5e-6) * max(1.0, np.abs(single[k]).max())
+            # two K-halves summed by the all-reduce instead of one K-long fp32 chain: rounding of order eps * sqrt(K).
+            # At the c2 size (6 steps x 1M Bernoulli draws) that rounding also flips the odd draw whose uniform lies
+            # within ~1e-7 of its probability -- about one per run is expected -- and a flipped hidden unit moves the
+            # statistics by x / B: a few 1e-6 on W.  (Replicas and overlapped-vs-synchronous stay BITWISE equal below.)
+            tol = (2e-6 if shape == "small" else 5e-5) * max(1.0, np.abs(single[k]).max())
             assert np.abs(r0[k] - single[k]).max() <= tol, (k, np.abs(r0[k] - single[k]).max())
     for k in single:                     # overlapped == synchronous, bit for bit
         assert np.array_equal(res[0][0][k], res[1][0][k]), k
