@@ -1267,16 +1267,26 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
             if (e.pre) VecIO<CW>::store(e.pre + off, pre[r]);
             if (e.mean) VecIO<CW>::store(e.mean + off, mean);
             if (e.sample) VecIO<CW>::store(e.sample + off, samp);
-            if (e.mean_planes || e.sample_plane) {
+            if (e.mean_planes || e.sample_plane) {      // CW bf16 values per plane and row: one packed store each
+                unsigned short q[4][CW];                 // [p1, p2, p3, sample][column]
 #pragma unroll
                 for (int j = 0; j < CW; ++j) {
-                    if (e.mean_planes) {
-                        unsigned short p1, p2, p3;
-                        split3(mean[j], p1, p2, p3);
-                        e.mean_planes[off + j] = p1; e.mean_planes[e.plane_stride + off + j] = p2;
-                        e.mean_planes[2 * e.plane_stride + off + j] = p3;
+                    split3(mean[j], q[0][j], q[1][j], q[2][j]);
+                    q[3][j] = (unsigned short)(__builtin_bit_cast(unsigned, samp[j]) >> 16);
+                }
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) {
+                    unsigned short* dst = pl < 3 ? (e.mean_planes ? e.mean_planes + pl * e.plane_stride + off : nullptr)
+                                                 : (e.sample_plane ? e.sample_plane + off : nullptr);
+                    if (!dst) continue;
+                    if constexpr (CW == 4) {
+                        uint2 w; w.x = q[pl][0] | ((unsigned)q[pl][1] << 16); w.y = q[pl][2] | ((unsigned)q[pl][3] << 16);
+                        *reinterpret_cast<uint2*>(dst) = w;
+                    } else if constexpr (CW == 2) {
+                        *reinterpret_cast<unsigned*>(dst) = q[pl][0] | ((unsigned)q[pl][1] << 16);
+                    } else {
+                        dst[0] = q[pl][0];
                     }
-                    if (e.sample_plane) e.sample_plane[off + j] = (unsigned short)(__builtin_bit_cast(unsigned, samp[j]) >> 16);
                 }
             }
         }

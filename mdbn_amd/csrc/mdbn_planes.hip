@@ -573,32 +573,46 @@ hipError_t launch_split_planes(const float* X, int64_t rows, int64_t ld, unsigne
     return hipGetLastError();
 }
 
-// minibatch gather (dbn.py:307) that also writes the rows' planes: dst f32 [n_idx][ld] + planes [3][.][ld]
+// minibatch gather (dbn.py:307) that also writes the rows' planes: dst f32 [n_idx][ld] + planes [3][.][ld].
+// A thread moves 8 columns (two float4 in, two float4 + three 16-byte plane stores out).
 __global__ __launch_bounds__(256) void gather_planes_kernel(const float* __restrict__ src, int64_t n_rows, int64_t ld_src,
-                                                            const void* __restrict__ idx, int idx64, int64_t ld4,
+                                                            const void* __restrict__ idx, int idx64, int64_t ld8,
                                                             float* __restrict__ dst, int64_t ld_dst,
                                                             unsigned short* __restrict__ P, int64_t plane_stride)
 {
     const int64_t r = blockIdx.y;
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ld4) return;
+    if (c >= ld8) return;
     int64_t s = r;
     if (idx) s = idx64 ? reinterpret_cast<const int64_t*>(idx)[r] : (int64_t)reinterpret_cast<const int32_t*>(idx)[r];
     if (s < 0) s += n_rows;
     s = s < 0 ? 0 : (s >= n_rows ? n_rows - 1 : s);
-    const float4 v = reinterpret_cast<const float4*>(src + s * ld_src)[c];
-    reinterpret_cast<float4*>(dst + r * ld_dst)[c] = v;
-    store_planes4(P, plane_stride, r * ld_dst + 4 * c, v);
+    const float4 v0 = reinterpret_cast<const float4*>(src + s * ld_src)[2 * c];
+    const float4 v1 = reinterpret_cast<const float4*>(src + s * ld_src)[2 * c + 1];
+    reinterpret_cast<float4*>(dst + r * ld_dst)[2 * c] = v0;
+    reinterpret_cast<float4*>(dst + r * ld_dst)[2 * c + 1] = v1;
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    unsigned short q[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3(x[j], q[0][j], q[1][j], q[2][j]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        uint4 w;
+        w.x = q[p][0] | ((unsigned)q[p][1] << 16); w.y = q[p][2] | ((unsigned)q[p][3] << 16);
+        w.z = q[p][4] | ((unsigned)q[p][5] << 16); w.w = q[p][6] | ((unsigned)q[p][7] << 16);
+        *reinterpret_cast<uint4*>(P + p * plane_stride + r * ld_dst + 8 * c) = w;
+    }
 }
 
 hipError_t launch_gather_planes(const float* src, int64_t n_rows, int64_t cols_ld, int64_t ld_src, const void* idx, int idx64,
                                 int64_t n_idx, float* dst, int64_t ld_dst, unsigned short* P, int64_t plane_stride, hipStream_t s)
 {
     if (n_idx <= 0) return hipSuccess;
-    if (n_idx > 65535) return hipErrorInvalidValue;
-    const int64_t ld4 = cols_ld >> 2;
-    hipLaunchKernelGGL(gather_planes_kernel, dim3((unsigned)((ld4 + 255) / 256), (unsigned)n_idx), dim3(256), 0, s, src, n_rows,
-                       ld_src, idx, idx64, ld4, dst, ld_dst, P, plane_stride);
+    if (n_idx > 65535 || (cols_ld & 7)) return hipErrorInvalidValue;         // the plane path has ld % 128 == 0
+    const int64_t ld8 = cols_ld >> 3;
+    const int threads = ld8 >= 256 ? 256 : 64;
+    hipLaunchKernelGGL(gather_planes_kernel, dim3((unsigned)((ld8 + threads - 1) / threads), (unsigned)n_idx), dim3(threads), 0, s,
+                       src, n_rows, ld_src, idx, idx64, ld8, dst, ld_dst, P, plane_stride);
     return hipGetLastError();
 }
 

@@ -189,7 +189,7 @@ def test_in_launch_splitk_reduction_is_bitwise_and_repeatable(hip_engine, gauss,
         try:
             out, _, _, _ = _run_steps(eng, gauss, True, V, H, B, k, steps=12, seed=3)
         finally:
-            eng.set_option("inkernel_reduce", 1)
+            eng.set_option("inkernel_reduce", 0)         # the library default (measured slower)
         runs.append(out)
     for other in runs[1:]:
         for key in runs[0]:
