@@ -12,8 +12,8 @@ class _Work:
 class FakeGroup:
     rank, world_size = 0, 2
     def shard(self, n): return 0, n                # this "rank" owns every row: per-rank work of a 512-row shard
-    def all_reduce_sum(self, t): return t
-    def all_reduce_sum_async(self, t): return _Work()
+    def all_reduce_sum(self, t, engine=None): return t
+    def all_reduce_sum_async(self, t, engine=None): return _Work()
 
 eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
 V, H, B, N = 4096, 1024, 512, 32768
