@@ -367,7 +367,8 @@ def main():
                   % (len(wins), args.steps),
         "windows_ms_per_step": [1e3 * w / args.steps for w in wins],
         "arithmetic": "f32 operands split exactly into 3 bf16 pieces; 6 piece products (3 when one operand holds 0/1 "
-                      "samples) on v_mfma_f32_32x32x16_bf16 with f32 accumulation (error vs float64 = rocBLAS sgemm's); "
+                      "samples) on v_mfma_f32_16x16x32_bf16 with f32 accumulation, operands pre-split into bf16 planes in "
+                      "HBM (error vs float64 = rocBLAS sgemm's); "
                       "exact_f32_mfma_* = the same step on v_mfma_f32_32x32x2_f32",
         "exact_f32_mfma_ms_per_step": exact_ms,
         "exact_f32_mfma_value": (B_global * K_GIBBS * 1e3 / exact_ms) if exact_ms else None,

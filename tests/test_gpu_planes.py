@@ -202,7 +202,7 @@ def test_in_launch_splitk_reduction_is_bitwise_and_repeatable(hip_engine, gauss,
 
 def test_bf16_input_reporting_mode(hip_engine):
     """mdbn_set_option("bf16_inputs", 1): one product on the leading bf16 pieces.  A reporting mode (BASELINE configs[1]
-    names "bf16/fp32"), not a parity path: probabilities within 1e-2 of the oracle, far outside the 2e-6 of the default
+    names "bf16/fp32"), not a parity path: probabilities within 3e-2 of the oracle, far outside the 2e-6 of the default
     path -- and switching it off restores the f32-grade results exactly."""
     from mdbn_amd import RngAddr
     eng = hip_engine
@@ -226,6 +226,6 @@ def test_bf16_input_reporting_mode(hip_engine):
     finally:
         eng.set_option("bf16_inputs", 0)
     err = np.abs(rough - ph).max()
-    assert 1e-5 < err <= 1e-2, err
+    assert 1e-5 < err <= 3e-2, err
     again, _ = eng.cd_step(dx, None, dW, dhb, dvb, True, 1, RngAddr(2, 0, 0, 0, 0))
     assert torch.equal(again, ref_stats) and np.array_equal(eng.last_scratch.P2[:B].cpu().numpy(), good)
