@@ -174,7 +174,7 @@ def kernel_breakdown(detail):
     rows = {}
     for kind, v in sorted(groups.items()):
         p = (kind // 100) % 10
-        family = {0: "", 1: "_streaming", 2: "_planes"}.get(kind // 1000, "_%d" % (kind // 1000))
+        family = {0: "", 1: "_streaming", 2: "_planes", 3: "_planes_balanced"}.get(kind // 1000, "_%d" % (kind // 1000))
         name = KIND_NAMES.get(kind % 10, "gemm%d" % (kind % 10)) + family
         t = sum(x[0] for x in v) * 1e-3
         alg, pipe = sum(x[1] for x in v), sum(x[2] for x in v)
@@ -183,7 +183,9 @@ def kernel_breakdown(detail):
         rows[key] = {"launches": len(v), "avg_us": 1e6 * t / len(v),
                      "pipe": ("bf16 MFMA, %d product(s) per algorithmic product" % {1: 6, 2: 3, 3: 1}[p]) if p else "f32 MFMA",
                      "kernel": {0: "gemm_bf16x6_kernel / gemm_splitk_kernel (f32 operands in HBM)", 1: "skinny_gemm_kernel",
-                                2: "gemm_planes_kernel (pre-split bf16 planes, LDS-DMA)"}.get(kind // 1000, "?"),
+                                2: "gemm_planes_kernel (pre-split bf16 planes, LDS-DMA)",
+                                3: "gemm_planes_bal_kernel (the same on CUs - comm_cus workgroups, equal stage ranges)"
+                                }.get(kind // 1000, "?"),
                      "issued_tflops": pipe / t / 1e12, "pipe_peak_tflops": peak, "frac_of_pipe": pipe / t / 1e12 / peak,
                      "algorithmic_f32_tflops": alg / t / 1e12, "fused_epilogue": (kind // 10) % 10}
     return rows

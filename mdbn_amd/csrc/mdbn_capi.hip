@@ -212,6 +212,13 @@ static int g_opt_planes_mfma = 16;
 // Probabilities then carry ~4e-3 of error: never used for a parity claim, off by default.
 static int g_opt_bf16_inputs = 0;
 constexpr int kMaxReduceTiles = 1024;
+// mdbn_set_option("comm_cus"): CUs left to a collective that runs beside the step (data-parallel mode).  > 0: the plane
+// GEMMs of mdbn_cd_step are launched BALANCED on (CUs - comm_cus) workgroups (mdbn_planes.hip, "BALANCED launches"):
+// a collective's kernel takes whole CUs, and a one-workgroup-per-CU grid on fewer CUs needs a second round (measured:
+// 163 -> 219 us per step with 8 CUs taken, scripts/dp_contention_probe.py).  0 (default): one workgroup per CU.
+static int g_opt_comm_cus = 0;
+static int g_opt_bal_blocks = 0;       // "bal_blocks" (tests): the number of workgroups itself, whatever the device has
+constexpr int kMaxBalBlocks = 256;
 
 // Turn an LDS-tiled plan into a bf16x6 plan (128x128 tiles, 32-deep slices) when that leaves enough
 // jobs to spread over the chip; `unsplit` = the caller needs splitk == 1 (fused statistics epilogue).
@@ -327,6 +334,14 @@ WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
     {
         const Plan st2 = plan_stats(V, H, 2 * B, ldh);        // under the current options (bf16x6 splits differently)
         if (st2.splitk > 1) s.slab = std::max(s.slab, st2.slab_floats(V, ldh));
+    }
+    if (B % 128 == 0 && V % 128 == 0 && H % 128 == 0) {
+        // balanced launches (comm_cus > 0): a tile has at most P / tiles + 2 segments, P <= kMaxBalBlocks; the in-place
+        // statistics GEMM parks 64 KB per workgroup
+        const int64_t tu = (B / 128) * (H / 128), td = (B / 128) * (V / 128);
+        s.slab = std::max(s.slab, (kMaxBalBlocks / tu + 2) * B * ldh);
+        s.slab = std::max(s.slab, (kMaxBalBlocks / td + 2) * B * ldv);
+        s.slab = std::max<int64_t>(s.slab, (int64_t)kMaxBalBlocks * 2 * 16384);
     }
     s.slab = std::max<int64_t>(s.slab, 4 * std::max(ldv, ldh) * 8);
     s.cost = std::max<int64_t>(256, (((B + 3) / 4) * std::max(ldv, ldh) + 255) / 256) + 64;   // worst case: one column per thread
@@ -470,7 +485,8 @@ hipError_t timed_gemm_planes(int la, int lb, const PlaneGemmArgs& g_in, hipStrea
     PlaneGemmArgs g = g_in;
     g.ms = g_opt_planes_mfma;
     if (g_opt_bf16_inputs) g.ap = 0;
-    if (!g_timing.enabled || g_timing.used >= 8192) return launch_gemm_planes(la, lb, g, s);
+    auto launch = [&]() { return g.bal ? launch_gemm_planes_bal(la, lb, g, s) : launch_gemm_planes(la, lb, g, s); };
+    if (!g_timing.enabled || g_timing.used >= 8192) return launch();
     if (g_timing.used == g_timing.pool.size()) {
         hipEvent_t a, b;
         hipError_t e = hipEventCreate(&a);
@@ -482,14 +498,14 @@ hipError_t timed_gemm_planes(int la, int lb, const PlaneGemmArgs& g_in, hipStrea
     {
         const double alg = 2.0 * (double)g.M * (double)g.N * (double)g.K;
         const int pipe = g.ap == 3 ? 1 : (g.ap == 1 ? 2 : 3);           // 3: one product (bf16-input reporting mode)
-        GemmTiming::Meta m{2000 + 100 * pipe + 10 * g.fused + 2 * la + lb, alg, alg * (pipe == 1 ? 6.0 : pipe == 2 ? 3.0 : 1.0)};
+        GemmTiming::Meta m{(g.bal ? 3000 : 2000) + 100 * pipe + 10 * g.fused + 2 * la + lb, alg, alg * (pipe == 1 ? 6.0 : pipe == 2 ? 3.0 : 1.0)};
         if (g_timing.meta.size() <= g_timing.used) g_timing.meta.resize(g_timing.used + 1);
         g_timing.meta[g_timing.used] = m;
     }
     auto& ev = g_timing.pool[g_timing.used++];
     hipError_t e = hipEventRecord(ev.first, s);
     if (e != hipSuccess) return e;
-    e = launch_gemm_planes(la, lb, g, s);
+    e = launch();
     if (e != hipSuccess) return e;
     return hipEventRecord(ev.second, s);
 }
@@ -520,6 +536,25 @@ bool planes_eligible(const mdbn_cd_args* a, bool fused_update)
            plane_plan(plan_stats(V, H, 2 * B, H), V, H, 2 * B);
 }
 
+// Workgroups of a balanced launch over `units` stage units (0: launch one workgroup per tile job as usual).  Balanced
+// launches exist for the 16x16x32 shape only, need >= 4 stages per workgroup to keep the LDS ring busy, and the in-place
+// variant parks through a workspace sized for kMaxBalBlocks workgroups.
+int bal_blocks(const mdbn_ctx* ctx, int64_t tiles, int64_t stages)
+{
+    if ((g_opt_comm_cus <= 0 && g_opt_bal_blocks <= 0) || g_opt_planes_mfma != 16) return 0;
+    int P = g_opt_bal_blocks > 0 ? g_opt_bal_blocks : std::min(ctx->num_cu - g_opt_comm_cus, kMaxBalBlocks);
+    if (P < 1) return 0;
+    // Fewer tiles than workgroups (forward passes): every tile is shared.  When P is not a multiple of the tile count the
+    // shares begin at stages scattered all over the reduction index, the workgroups stop sweeping it in step and the
+    // operand stages stop being shared in L2 (measured at c2: propup 31 -> 40 us at P = 216, 31 again at P = 192).  An
+    // equal number of workgroups per tile keeps them in step; take it unless it costs more than a quarter in stages.
+    if (tiles < P && P % tiles != 0 && g_opt_bal_blocks <= 0) {
+        const int aligned = (int)(tiles * (P / tiles));
+        if (4ll * P <= 5ll * aligned) P = aligned;          // stages per workgroup grow by P / aligned <= 1.25
+    }
+    return tiles * stages >= 4 * (int64_t)P ? P : 0;
+}
+
 // One forward pass on planes: A planes [rows, K] (ROW), W planes as COL (dir 0: propup) or ROW (dir 1: propdown);
 // `e` arrives with outputs / bias / rng / colsum set, this fills in the slab side and the cost partials.
 int run_affine_planes(mdbn_ctx* ctx, const unsigned short* A, int64_t lda, int64_t pa, int ap, int dir, const unsigned short* Wp,
@@ -536,8 +571,16 @@ int run_affine_planes(mdbn_ctx* ctx, const unsigned short* A, int64_t lda, int64
         const Plan p = plan_forward(rows, Ndim, Kdim, e.ld);        // eligibility checked that this is a whole-tile x6 plan
         g.splitk = p.splitk; g.kchunk = p.kchunk;
     }
-    const bool fuse = g_opt_fused_epilogue && g.splitk == 1;
-    const bool reduce_inside = !fuse && g.splitk > 1 && g_opt_inkernel_reduce && g.tiles_m * g.tiles_n <= kMaxReduceTiles &&
+    // data-parallel mode: P workgroups share tiles x stages evenly; a tile's segments land in slabs, the epilogue launch
+    // sums the slabs each tile has
+    int bal = bal_blocks(ctx, (int64_t)g.tiles_m * g.tiles_n, Kdim / 32), bal_slabs = 0;
+    if (bal) {
+        bal_slabs = bal_max_segments(g.tiles_m * g.tiles_n, (int)(Kdim / 32), bal);
+        if ((int64_t)bal_slabs * rows * e.ld > ws.slab_floats) bal = 0;        // a workspace sized before the option was set
+        if ((int64_t)bal_slabs * rows * e.ld * 4 >= (int64_t)1 << 31) bal = 0;  // 32-bit buffer offsets
+    }
+    const bool fuse = !bal && g_opt_fused_epilogue && g.splitk == 1;
+    const bool reduce_inside = !bal && !fuse && g.splitk > 1 && g_opt_inkernel_reduce && g.tiles_m * g.tiles_n <= kMaxReduceTiles &&
                                (int64_t)g.splitk * rows * e.ld * 4 < ((int64_t)1 << 31);
     const int nb = (fuse || reduce_inside) ? g.tiles_m * g.tiles_n : epilogue_blocks(rows, e.ld);
     e.rows = (int)rows; e.cols = (int)Ndim;
@@ -548,7 +591,14 @@ int run_affine_planes(mdbn_ctx* ctx, const unsigned short* A, int64_t lda, int64
         if (n_cost_out) *n_cost_out = nb;
     }
     const int lb = dir == 0 ? LAY_MN : LAY_K;
-    if (fuse) {
+    if (bal) {
+        g.bal = bal; g.fused = 0; g.C = ws.slabs; g.ldc = e.ld; g.slab_stride = rows * e.ld;
+        g.splitk = 1; g.kchunk = (int)Kdim; g.c_bytes = (int64_t)bal_slabs * rows * e.ld * 4;
+        e.slabs = ws.slabs; e.slab_stride = g.slab_stride; e.nsplit = bal_slabs;
+        e.bal_P = bal; e.bal_S = (int)(Kdim / 32); e.bal_tiles_m = g.tiles_m; e.bal_tiles_n = g.tiles_n;
+        HIP_OK(timed_gemm_planes(LAY_K, lb, g, s));
+        HIP_OK(launch_act_epilogue(e, s));
+    } else if (fuse) {
         g.fused = 1; g.epi = e;
         HIP_OK(timed_gemm_planes(LAY_K, lb, g, s));
     } else if (reduce_inside) {
@@ -642,7 +692,11 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     g.M = (int)V; g.N = (int)H; g.K = (int)(2 * B);
     g.tiles_m = (int)(V / 128); g.tiles_n = (int)(H / 128); g.splitk = sp.splitk; g.kchunk = sp.kchunk;
     g.fin_enabled = 0;
-    const bool fuse_upd = upd != nullptr && g_opt_fused_update && sp.splitk == 1;
+    // data-parallel mode: the statistics land in place from a balanced launch (partials of shared tiles go through
+    // scratch carved from the slab region, which the forward passes no longer need)
+    int bal = sp.splitk == 1 ? bal_blocks(ctx, (int64_t)g.tiles_m * g.tiles_n, 2 * B / 32) : 0;
+    if (bal && ((int64_t)bal * 2 * 16384 > ws.slab_floats || V * ldh * 4 >= (int64_t)1 << 31)) bal = 0;
+    const bool fuse_upd = !bal && upd != nullptr && g_opt_fused_update && sp.splitk == 1;
     if (fuse_upd) {
         BiasUpd bu;
         bu.hb = upd->hbias; bu.hbs = upd->hbias_speed; bu.vb = upd->vbias; bu.vbs = upd->vbias_speed;
@@ -664,7 +718,11 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     g.fused = 0; g.ldc = ldh; g.slab_stride = V * ldh;
     mdbn_update_args u;
     if (upd) { u = *upd; u.phase = 0; }
-    if (sp.splitk == 1) {
+    if (bal) {
+        g.C = S; g.bal = bal; g.fused = 4; g.kchunk = (int)(2 * B); g.c_bytes = V * ldh * 4;
+        g.scratch = ws.slabs;
+        HIP_OK(timed_gemm_planes(LAY_MN, LAY_MN, g, s));
+    } else if (sp.splitk == 1) {
         g.C = S;
         HIP_OK(timed_gemm_planes(LAY_MN, LAY_MN, g, s));
     } else {
@@ -804,6 +862,16 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     }
     if (strcmp(name, "inkernel_reduce") == 0) {
         g_opt_inkernel_reduce = value != 0;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "bal_blocks") == 0) {
+        if (value < 0 || value > kMaxBalBlocks) return fail(MDBN_EINVAL, "bal_blocks must be in [0, %d]", kMaxBalBlocks);
+        g_opt_bal_blocks = (int)value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "comm_cus") == 0) {
+        if (value < 0 || value > 192) return fail(MDBN_EINVAL, "comm_cus must be in [0, 192]");
+        g_opt_comm_cus = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "gemm_planes") == 0) {

@@ -32,6 +32,9 @@ struct EpiArgs {
     unsigned short* mean_planes;   // nullable
     int64_t plane_stride;          // elements between planes
     unsigned short* sample_plane;  // nullable (Bernoulli samples only)
+    // slabs written by a balanced GEMM (launch_gemm_planes_bal): a 128x128 tile has as many slabs as workgroups shared
+    // its stages; bal_P = 0: every element has `nsplit` slabs
+    int bal_P, bal_S, bal_tiles_m, bal_tiles_n;
 };
 
 // parameter update applied by the statistics GEMM to its own output tile (fused == 2)
@@ -108,13 +111,39 @@ struct PlaneGemmArgs {
                            //   (write-through stores), the last block to arrive at a tile sums the partials in slab
                            //   order and runs the activation epilogue (epi)
     int* counters;         // fused == 3: one arrival counter per output tile, zero on entry, zero again on exit
+    // balanced launches (launch_gemm_planes_bal): `bal` workgroups share tiles x (K / 32) stages evenly;
+    // fused = 0: slabs, one per piece of a tile; fused = 4: result in place, pieces of shared tiles through `scratch`
+    int bal;
+    float* scratch;        // fused == 4: 128 KB per workgroup
+    int64_t c_bytes;       // balanced: bytes addressable from C (all slabs; < 2 GiB)
     EpiArgs epi;
     UpdEpi upd;
     int fin_enabled;
     FinArgs fin;
 };
 
+// balanced launches (mdbn_planes.hip): U units in (tile, stage) order, workgroup w of P takes [w U / P, (w + 1) U / P)
+__host__ __device__ inline int bal_first_unit(int w, int P, int64_t U) { return (int)(((int64_t)w * U) / P); }
+__host__ __device__ inline int bal_block_of(int64_t u, int P, int64_t U) { return (int)(((u + 1) * P - 1) / U); }   // owner of unit u
+// workgroups that take part in the remainder (the tiles beyond (tiles / P) P): each of them gets at least one stage
+__host__ __device__ inline int bal_rem_blocks(int tiles, int S, int P)
+{
+    const int64_t Ur = (int64_t)(tiles - (tiles / P) * P) * S;
+    return Ur < P ? (int)Ur : P;
+}
+// slabs of tile t written by a balanced launch of P workgroups over tiles x S stages: whole tiles have one, a
+// remainder tile one per workgroup that shared its stages
+__host__ __device__ inline int bal_tile_slabs(int t, int tiles, int S, int P)
+{
+    const int Tf = (tiles / P) * P;
+    if (t < Tf) return 1;
+    const int64_t Ur = (int64_t)(tiles - Tf) * S, u0 = (int64_t)(t - Tf) * S;
+    const int Pr = bal_rem_blocks(tiles, S, P);
+    return bal_block_of(u0 + S - 1, Pr, Ur) - bal_block_of(u0, Pr, Ur) + 1;
+}
 hipError_t launch_gemm_planes(int la, int lb, const PlaneGemmArgs& g, hipStream_t s);
+hipError_t launch_gemm_planes_bal(int la, int lb, const PlaneGemmArgs& g, hipStream_t s);
+int bal_max_segments(int tiles, int stages, int P);     // slabs a balanced fused == 0 launch needs
 hipError_t launch_split_planes(const float* X, int64_t rows, int64_t ld, unsigned short* P, int64_t plane_stride, hipStream_t s);
 hipError_t launch_gather_planes(const float* src, int64_t n_rows, int64_t cols_ld, int64_t ld_src, const void* idx, int idx64,
                                 int64_t n_idx, float* dst, int64_t ld_dst, unsigned short* P, int64_t plane_stride, hipStream_t s);

@@ -1194,7 +1194,13 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
             // any split count: 16 / CW slabs x 4 rows of loads in flight per round (a load-add-load-add
             // chain costs one memory latency per slab: 76 us at 36 slabs), summed in slab order
             constexpr int SB = 16 / CW;               // slabs per round: 64 loaded floats per thread in flight
-            for (int s0 = 0; s0 < e.nsplit; s0 += SB) {
+            int nsplit = e.nsplit;
+            if (e.bal_P) {      // slabs of a balanced GEMM: this 128x128 tile has one per workgroup that shared its stages
+                const int tm = r0 >> 7, tn = c0 >> 7;
+                const int t = e.bal_tiles_m <= e.bal_tiles_n ? tn * e.bal_tiles_m + tm : tm * e.bal_tiles_n + tn;
+                nsplit = bal_tile_slabs(t, e.bal_tiles_m * e.bal_tiles_n, e.bal_S, e.bal_P);
+            }
+            for (int s0 = 0; s0 < nsplit; s0 += SB) {
                 float v[4][SB][CW];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -1202,7 +1208,7 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
                     for (int u = 0; u < SB; ++u) {
 #pragma unroll
                         for (int j = 0; j < CW; ++j) v[r][u][j] = 0.f;
-                        if (r0 + r < e.rows && s0 + u < e.nsplit)
+                        if (r0 + r < e.rows && s0 + u < nsplit)
                             VecIO<CW>::load(base + (int64_t)r * e.ld + (int64_t)(s0 + u) * e.slab_stride, v[r][u]);
                     }
 #pragma unroll
@@ -1332,7 +1338,7 @@ static void launch_act_epilogue_cw(const EpiArgs& e, hipStream_t s)
     const int64_t n = ((int64_t)(e.rows + 3) / 4) * (e.ld / CW);
     const int t = epilogue_threads(e.rows, e.ld);
     const dim3 grid((unsigned)((n + t - 1) / t)), block(t);
-    switch (e.nsplit) {
+    switch (e.bal_P ? 0 : e.nsplit) {
         case 1: hipLaunchKernelGGL((act_epilogue_kernel<1, CW>), grid, block, 0, s, e); break;
         case 2: hipLaunchKernelGGL((act_epilogue_kernel<2, CW>), grid, block, 0, s, e); break;
         case 4: hipLaunchKernelGGL((act_epilogue_kernel<4, CW>), grid, block, 0, s, e); break;

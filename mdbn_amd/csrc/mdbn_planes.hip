@@ -139,11 +139,12 @@ __device__ __forceinline__ pbf16x8 pl_frag(const char* plane, int off0, int off1
 // (hi,lo) (hi,hi) -- so that consecutive quarters share one half and every quarter prefetches exactly ONE half under its
 // MFMAs: this stage's in the first two quarters, the NEXT stage's after the mid-stage barrier `|`.
 typedef float pf32x4a __attribute__((ext_vector_type(4)));
-template <int LA, int LB, int AP>
-__device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int wm, int wn, pf32x4a (&acc)[4][4])
+
+// fragment byte offsets inside a plane image for the 16x16x32 shape: [16-row block][first / second tr read]
+template <int LA, int LB>
+__device__ __forceinline__ void pl_offsets16(int lane, int wm, int wn, int (&offA)[4][2], int (&offB)[4][2])
 {
     const int c16 = lane & 15, q = lane >> 4;
-    int offA[4][2], offB[4][2];                 // [16-row block][first / second tr read]
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         {
@@ -171,8 +172,10 @@ __device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int w
             }
         }
     }
-    constexpr int NA = AP == 3 ? 3 : 1, NB = AP == 0 ? 1 : 3;      // AP = 0: bf16-input reporting mode (one product)
-    pbf16x8 Alo[3][2], Ahi[3][2], Blo[3][2], Bhi[3][2];
+}
+
+// Building blocks of the 16x16x32 consumers (pl_consume16, pl_consume16_bal); they expect offA / offB / acc and the
+// constants NA, NB, RA, RB, NM in scope.
 #define RD_A(FA, BASE, HALF)                                                                  \
     _Pragma("unroll") for (int pl = 0; pl < NA; ++pl)                                         \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
@@ -200,9 +203,7 @@ __device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int w
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], c, 0, 0, 0);  \
             }                                                                                 \
         }
-    // issue order: the prefetched half's LDS reads one by one under this quarter's MFMAs
-    constexpr int RA = 2 * NA * (LA == LAY_MN ? 2 : 1), RB = 2 * NB * (LB == LAY_MN ? 2 : 1),
-                  NM = 4 * (AP == 3 ? 6 : (AP == 1 ? 3 : 1));
+// issue order: the prefetched half's LDS reads one by one under this quarter's MFMAs
 #define ORD(NR)                                                                               \
     _Pragma("unroll") for (int i_ = 0; i_ < ((NR) < NM ? (NR) : NM); ++i_) {                  \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
@@ -210,41 +211,58 @@ __device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int w
     }                                                                                         \
     if ((NR) > NM) __builtin_amdgcn_sched_group_barrier(0x100, (NR) - NM, 0);                 \
     if (NM > (NR)) __builtin_amdgcn_sched_group_barrier(0x008, NM - (NR), 0);
-    // every LDS read of a stage must have RETURNED before the barrier that frees its slot: pin the halves read in the
-    // first two quarters ahead of the barrier (hipcc may sink loads past s_barrier, DESIGN.md "guarded reload")
+// every LDS read of a stage must have RETURNED before the barrier that frees its slot: pin the halves read in the
+// first two quarters ahead of the barrier (hipcc may sink loads past s_barrier, DESIGN.md "guarded reload")
 #define PIN(FA, NPL)                                                                          \
     _Pragma("unroll") for (int pl = 0; pl < (NPL); ++pl)                                      \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(FA[pl][i]));
+// The two stage bodies of the serpentine.  EVEN enters holding (Alo, Blo) of its stage and leaves holding (Alo, Bhi) of
+// the next; ODD enters holding (Alo, Bhi) and leaves holding (Alo, Blo).
+#define PL_STAGE_EVEN(BASE, NEXT, BARRIER)                                                    \
+    do {                                                                                      \
+        RD_B(Bhi, BASE, 1); MMQ(Alo, Blo, 0, 0); ORD(RB);                                     \
+        RD_A(Ahi, BASE, 1); MMQ(Alo, Bhi, 0, 1); ORD(RA);                                     \
+        PIN(Bhi, NB); PIN(Ahi, NA);                                                           \
+        BARRIER;                     /* every read of this stage is done; the next has landed */ \
+        RD_A(Alo, NEXT, 0); MMQ(Ahi, Bhi, 1, 1); ORD(RA);                                     \
+        RD_B(Bhi, NEXT, 1); MMQ(Ahi, Blo, 1, 0); ORD(RB);                                     \
+    } while (0)
+#define PL_STAGE_ODD(BASE, NEXT, BARRIER)                                                     \
+    do {                                                                                      \
+        RD_B(Blo, BASE, 0); MMQ(Alo, Bhi, 0, 1); ORD(RB);                                     \
+        RD_A(Ahi, BASE, 1); MMQ(Alo, Blo, 0, 0); ORD(RA);                                     \
+        PIN(Blo, NB); PIN(Ahi, NA);                                                           \
+        BARRIER;                                                                              \
+        RD_A(Alo, NEXT, 0); MMQ(Ahi, Blo, 1, 0); ORD(RA);                                     \
+        RD_B(Blo, NEXT, 0); MMQ(Ahi, Bhi, 1, 1); ORD(RB);                                     \
+    } while (0)
+#define PL_CONSUME_CONSTS()                                                                   \
+    constexpr int NA = AP == 3 ? 3 : 1, NB = AP == 0 ? 1 : 3;      /* AP = 0: bf16-input reporting mode */ \
+    constexpr int RA = 2 * NA * (LA == LAY_MN ? 2 : 1), RB = 2 * NB * (LB == LAY_MN ? 2 : 1), \
+                  NM = 4 * (AP == 3 ? 6 : (AP == 1 ? 3 : 1));
+
+template <int LA, int LB, int AP>
+__device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int wm, int wn, pf32x4a (&acc)[4][4])
+{
+    int offA[4][2], offB[4][2];
+    pl_offsets16<LA, LB>(lane, wm, wn, offA, offB);
+    PL_CONSUME_CONSTS();
+    pbf16x8 Alo[3][2], Ahi[3][2], Blo[3][2], Bhi[3][2];
     __syncthreads();                                 // stage 0 landed
     RD_A(Alo, smem, 0);
     RD_B(Blo, smem, 0);
     for (int it = 0; it < nt; it += 2) {
-        {   // even stage: enters holding (Alo, Blo)
+        {   // even stage
             const char* base = smem + (it % PL_NSTAGE) * PL_STAGE;
             const char* next = smem + ((it + 1) % PL_NSTAGE) * PL_STAGE;
-            RD_B(Bhi, base, 1); MMQ(Alo, Blo, 0, 0); ORD(RB);
-            RD_A(Ahi, base, 1); MMQ(Alo, Bhi, 0, 1); ORD(RA);
-            PIN(Bhi, NB); PIN(Ahi, NA);
-            __syncthreads();                         // every read of stage `it` is done; stage it + 1 has landed
-            RD_A(Alo, next, 0); MMQ(Ahi, Bhi, 1, 1); ORD(RA);
-            RD_B(Bhi, next, 1); MMQ(Ahi, Blo, 1, 0); ORD(RB);
+            PL_STAGE_EVEN(base, next, __syncthreads());
         }
-        if (it + 1 < nt) {   // odd stage: enters holding (Alo, Bhi)
+        if (it + 1 < nt) {   // odd stage
             const char* base = smem + ((it + 1) % PL_NSTAGE) * PL_STAGE;
             const char* next = smem + ((it + 2) % PL_NSTAGE) * PL_STAGE;
-            RD_B(Blo, base, 0); MMQ(Alo, Bhi, 0, 1); ORD(RB);
-            RD_A(Ahi, base, 1); MMQ(Alo, Blo, 0, 0); ORD(RA);
-            PIN(Blo, NB); PIN(Ahi, NA);
-            __syncthreads();
-            RD_A(Alo, next, 0); MMQ(Ahi, Blo, 1, 0); ORD(RA);
-            RD_B(Blo, next, 0); MMQ(Ahi, Bhi, 1, 1); ORD(RB);
+            PL_STAGE_ODD(base, next, __syncthreads());
         }
     }
-#undef RD_A
-#undef RD_B
-#undef MMQ
-#undef ORD
-#undef PIN
 }
 
 // FUSED: 0 = split-K slab / plain C store; 1 = activation + sampling epilogue on the parked tile (unsplit
@@ -552,6 +570,340 @@ hipError_t launch_gemm_planes(int la, int lb, const PlaneGemmArgs& g, hipStream_
 #undef PL_CASE
     return hipErrorInvalidValue;
 }
+
+// ==================================================================================
+// BALANCED launches: the same GEMM on ANY number of workgroups (data-parallel mode).
+//
+// A collective's kernel that runs beside the step takes whole CUs (RCCL's gfx950 all-reduce kernel: 248-256 VGPRs per
+// wave, 37.6 KB LDS, 512 threads -- it cannot share a CU with a 144-KB GEMM block), and a 256-workgroup grid on 255 CUs
+// runs in two rounds: measured with a stand-in kernel of that footprint, the c2 data-parallel step goes from 168 to
+// 220 us as soon as EIGHT CUs are taken (scripts/dp_contention_probe.py, profiles/r02i_*).  So in data-parallel mode
+// the GEMMs are launched on P = CUs - comm_cus workgroups and the work is cut evenly:
+//   * F = tiles / P WHOLE tiles per workgroup ([w F, (w + 1) F)), swept from stage 0 by every workgroup in step;
+//   * the stages of the R = tiles - F P tiles left over, in (tile, stage) order, cut into equal contiguous shares
+//     ("stream-K" on the remainder only; a share is shorter than one tile, so at most two pieces).  With fewer tiles
+//     than workgroups (the forward passes at c2) everything is remainder.
+// The LDS ring and the loader waves run straight through the seams between segments; the MFMA waves flush their
+// accumulators at each.  A shared tile's pieces are combined OUTSIDE the launch, by a kernel that follows it:
+//   FIX = 0 (forward passes): every piece goes to its own slab, slab index = position of the workgroup among those
+//           that share the tile; the activation epilogue launch sums the slabs a tile HAS (bal_tile_slabs), in order.
+//   FIX = 1 (statistics GEMM, result wanted in place): whole tiles are stored where they belong; pieces of shared
+//           tiles are parked in scratch (64 KB per workgroup, in accumulator-register layout: 1 KiB per store
+//           instruction) and bal_fixup_kernel adds the pieces of each shared tile in workgroup order.
+// No workgroup ever waits for another: an earlier version let a tile's owner collect the parked pieces inside the
+// launch behind per-wave flags; the owner's serial, latency-bound collection (4 round trips to memory per piece) cost
+// more than the extra launch (statistics GEMM 63-76 us against 52 + 4), and a spin-wait is a liability beside a
+// collective that takes CUs away.
+// Determinism: the cut depends only on (tiles, stages, P); pieces are added in a fixed order.
+// A piece that does not reach its tile's last stage is computed FIRST, the piece that does LAST: every workgroup then
+// starts at stage 0 of some tile, and the workgroups sweep the reduction index nearly in step -- that keeps the
+// operand stages shared in L2 (ranges starting at scattered stages cost up to 60 %: statistics GEMM 63 -> 102 us).
+// ==================================================================================
+struct BalRange {
+    int F, Tf;                    // whole tiles per workgroup; first remainder tile
+    int tA, sA, tB, eB, nrem;     // remainder units [tA * S + sA, tB * S + eB) in remainder-tile space, eB in 1..S; pieces
+    int pre, nseg, nt;            // remainder pieces processed BEFORE the whole tiles; segments; stages in all
+};
+__host__ __device__ inline BalRange bal_range(int w, int P, int tiles, int S)
+{
+    BalRange r;
+    r.F = tiles / P; r.Tf = r.F * P;
+    const int64_t Ur = (int64_t)(tiles - r.Tf) * S;
+    const int Pr = bal_rem_blocks(tiles, S, P);
+    const int u0 = w < Pr ? bal_first_unit(w, Pr, Ur) : 0, u1 = w < Pr ? bal_first_unit(w + 1, Pr, Ur) : 0;
+    r.tA = r.sA = r.tB = r.eB = r.nrem = r.pre = 0;
+    if (u1 > u0) {
+        r.tA = u0 / S; r.sA = u0 - r.tA * S;
+        r.tB = (u1 - 1) / S; r.eB = u1 - r.tB * S;
+        r.nrem = r.tB - r.tA + 1;
+        r.pre = r.nrem == 2 ? 1 : (r.eB != S ? 1 : 0);
+    }
+    r.nseg = r.F + r.nrem;
+    r.nt = r.F * S + (u1 - u0);
+    return r;
+}
+// segment k of a workgroup in processing order: (tile, first stage, end stage)
+__host__ __device__ inline void bal_segment(const BalRange& r, int w, int k, int S, int& tile, int& s0, int& s1)
+{
+    if (k < r.pre) {                              // the piece that does not reach its tile's end
+        if (r.nrem == 2) { tile = r.Tf + r.tB; s0 = 0; s1 = r.eB; }
+        else { tile = r.Tf + r.tA; s0 = r.sA; s1 = r.eB; }
+    } else if (k < r.pre + r.F) {
+        tile = w * r.F + (k - r.pre); s0 = 0; s1 = S;
+    } else {                                      // the piece that ends its tile
+        tile = r.Tf + r.tA; s0 = r.sA; s1 = S;
+    }
+}
+
+template <int LA, int LB, int AP>
+__device__ __forceinline__ void pl_loader_bal(const PlaneGemmArgs& g, char* smem, int w, int lane, int wg, const BalRange& r, int nt, int S)
+{
+    constexpr int NA = AP == 3 ? 3 : 1, NB = AP == 0 ? 1 : 3;
+    constexpr int NQ = 8 * (NA + NB), PER = NQ / PL_LW, PERA = 8 * NA / PL_LW;     // j < PERA: an A instruction
+    const char* base[PER];        // tile (0, 0), stage 0
+    const char* src[PER];
+    unsigned dst[PER];
+    int64_t step[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int q = w + j * PL_LW;
+        const bool isA = j < PERA;
+        const int plane = isA ? q / 8 : (q - 8 * NA) / 8, sub = q & 7;
+        const int lay = isA ? LA : LB;
+        const unsigned short* b0 = isA ? g.A + plane * g.pa : g.B + plane * g.pb;
+        const int64_t ld = isA ? g.lda : g.ldb;
+        dst[j] = (isA ? plane : 3 + plane) * PL_PLANE + sub * 1024;
+        if (lay == LAY_K) {
+            const int row = 16 * sub + (lane >> 2);
+            const int c = (lane & 3) ^ pl_row_swz<16>(row);
+            base[j] = reinterpret_cast<const char*>(b0 + (int64_t)row * ld + 8 * c);
+            step[j] = 64;
+        } else {
+            const int k = 4 * sub + (lane >> 4);
+            const int ch = (lane & 15) ^ pl_col_swz<16>(k);
+            base[j] = reinterpret_cast<const char*>(b0 + (int64_t)k * ld + 8 * ch);
+            step[j] = 64 * ld;
+        }
+    }
+    int seg = 0, left = 0;
+    auto next_segment = [&]() {       // point src[] at the first stage of segment `seg`
+        int t, s0, s1;
+        bal_segment(r, wg, seg, S, t, s0, s1);
+        ++seg; left = s1 - s0;
+        int tm, tn;
+        if (g.tiles_m <= g.tiles_n) { tn = t / g.tiles_m; tm = t - tn * g.tiles_m; }
+        else { tm = t / g.tiles_n; tn = t - tm * g.tiles_n; }
+        const int64_t offA = LA == LAY_K ? (int64_t)tm * 128 * g.lda * 2 : (int64_t)tm * 256;
+        const int64_t offB = LB == LAY_K ? (int64_t)tn * 128 * g.ldb * 2 : (int64_t)tn * 256;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) src[j] = base[j] + (j < PERA ? offA : offB) + (int64_t)s0 * step[j];
+    };
+    next_segment();
+#define PL_ISSUE(T)                                                                           \
+    do {                                                                                      \
+        const unsigned so = ((T) % PL_NSTAGE) * PL_STAGE;                                     \
+        _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                     \
+            pl_glds16(src[j], so + dst[j], smem);                                             \
+            src[j] += step[j];                                                                \
+        }                                                                                     \
+        if (--left == 0 && seg < r.nseg) next_segment();                                      \
+    } while (0)
+    PL_ISSUE(0);
+    if (nt > 1) { PL_ISSUE(1); }
+    if (nt > 2) { PL_ISSUE(2); }
+    if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER) : "memory");
+    else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // stage 0 landed
+    for (int it = 0; it < nt; ++it) {
+        if (it + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // every read of stage `it` is done: its slot is free
+        if (it + 3 < nt) { PL_ISSUE(it + 3); }
+    }
+#undef PL_ISSUE
+}
+
+typedef unsigned int pu32x4b __attribute__((ext_vector_type(4)));
+
+// __syncthreads() fences: it waits for EVERY outstanding memory operation of the wave, stores flushed at a seam
+// included.  The stage barrier only has to order LDS traffic: the fragment reads of the stage have returned (PIN), so
+// wait for LDS and meet.
+#define PL_RAW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int LA, int LB, int AP, int FIX>
+__global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_bal_kernel(PlaneGemmArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int P = gridDim.x;
+    const int w = blockIdx.x;
+    const int S = g.K / 32, tiles = g.tiles_m * g.tiles_n;
+    const BalRange r = bal_range(w, P, tiles, S);
+    const int nt = r.nt;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (nt <= 0) return;                             // more workgroups than stages (the host never launches that)
+    if (wave >= 4) {
+        pl_loader_bal<LA, LB, AP>(g, smem, wave - 4, lane, w, r, nt, S);
+        return;
+    }
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    int offA[4][2], offB[4][2];
+    pl_offsets16<LA, LB>(lane, wm, wn, offA, offB);
+    PL_CONSUME_CONSTS();
+    pbf16x8 Alo[3][2], Ahi[3][2], Blo[3][2], Bhi[3][2];
+    pf32x4a acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = pf32x4a{0.f, 0.f, 0.f, 0.f};
+    const int c16 = lane & 15, q4 = lane >> 4;
+    // buffer descriptors: the matrix side (slabs, or the result in place) and the scratch of the in-place variant;
+    // per-lane offsets are 32-bit, the (a, b, e) part of an offset is scalar
+    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)g.c_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(g.scratch, 0, FIX ? 2 * P * 65536 : 0, 0x00020000);
+    const int ldc4 = (int)g.ldc * 4;
+    const int lane_off = (wm + 4 * q4) * ldc4 + (wn + c16) * 4;
+
+    int it = 0, seg = 0, left, t_cur, s_beg, s_end;
+    bal_segment(r, w, seg, S, t_cur, s_beg, s_end);
+    left = s_end - s_beg;
+    // the segment [s_beg, s_end) of tile t_cur is complete: flush the accumulators
+    auto flush = [&]() __attribute__((always_inline)) {
+        int tm, tn;
+        if (g.tiles_m <= g.tiles_n) { tn = t_cur / g.tiles_m; tm = t_cur - tn * g.tiles_m; }
+        else { tm = t_cur / g.tiles_n; tn = t_cur - tm * g.tiles_n; }
+        const bool shared = s_beg != 0 || s_end != S;
+        int base_off = tm * 128 * ldc4 + tn * 512;                           // bytes; < 2^31 (host check)
+        if (FIX == 0 && t_cur >= r.Tf) {
+            const int Pr = bal_rem_blocks(tiles, S, P);
+            const int64_t Ur = (int64_t)(tiles - r.Tf) * S;
+            base_off += (w - bal_block_of((int64_t)(t_cur - r.Tf) * S, Pr, Ur)) * (int)(g.slab_stride * 4);
+        }
+        if (FIX != 0 && shared) {
+            // a piece of a shared tile: parked in register layout, slot 2 w + (0: the piece that ends its tile, 1: the
+            // other one), [wave][a][b][lane] x 16 bytes
+            const int slot = 2 * w + (s_end != S ? 1 : 0);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4b, acc[a][b]), srsrc, lane * 16,
+                                                           ((slot * 4 + wave) * 16 + a * 4 + b) * 1024, 0);
+        } else {
+            // accumulator (16x16): col = lane & 15, row = 4 * (lane >> 4) + e
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float val = acc[a][b][e];      // (a bit_cast of the vector-element lvalue itself reads element 0)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), crsrc, lane_off,
+                                                              base_off + (16 * a + e) * ldc4 + 64 * b, 0);
+                    }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = pf32x4a{0.f, 0.f, 0.f, 0.f};
+        if (++seg < r.nseg) {
+            bal_segment(r, w, seg, S, t_cur, s_beg, s_end);
+            left = s_end - s_beg;
+        }
+    };
+
+    __syncthreads();                                 // stage 0 landed
+    RD_A(Alo, smem, 0);
+    RD_B(Blo, smem, 0);
+    while (it < nt) {
+        {
+            const char* base = smem + (it % PL_NSTAGE) * PL_STAGE;
+            const char* next = smem + ((it + 1) % PL_NSTAGE) * PL_STAGE;
+            PL_STAGE_EVEN(base, next, PL_RAW_BARRIER());
+            ++it;
+            if (--left == 0) flush();
+        }
+        if (it < nt) {
+            const char* base = smem + (it % PL_NSTAGE) * PL_STAGE;
+            const char* next = smem + ((it + 1) % PL_NSTAGE) * PL_STAGE;
+            PL_STAGE_ODD(base, next, PL_RAW_BARRIER());
+            ++it;
+            if (--left == 0) flush();
+        }
+    }
+}
+
+// Shared tiles of an in-place balanced launch: C tile = sum of the parked pieces in workgroup order.  One workgroup
+// per (shared tile, 16-row band a of each wave's quadrant): thread = (wave, lane) of the GEMM's MFMA waves, so the
+// scratch is read in the layout it was written in (16 bytes per lane, 1 KiB per wave-instruction).
+__global__ __launch_bounds__(256) void bal_fixup_kernel(const float* __restrict__ scratch, float* __restrict__ C, int64_t ldc,
+                                                       int tiles_m, int tiles_n, int S, int P)
+{
+    const int tiles = tiles_m * tiles_n, Tf = (tiles / P) * P;
+    const int t = Tf + (int)blockIdx.x / 4, a = (int)blockIdx.x & 3;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int Pr = bal_rem_blocks(tiles, S, P);
+    const int64_t Ur = (int64_t)(tiles - Tf) * S, u0 = (int64_t)(t - Tf) * S;
+    const int wfirst = bal_block_of(u0, Pr, Ur), wlast = bal_block_of(u0 + S - 1, Pr, Ur);
+    if (wfirst == wlast) return;                     // one workgroup computed the whole tile and stored it itself
+    pf32x4a acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = pf32x4a{0.f, 0.f, 0.f, 0.f};
+    for (int w = wfirst; w <= wlast; ++w) {
+        // the piece of workgroup w on this tile: the one that ends the tile only for the last sharer
+        const int slot = 2 * w + (w == wlast ? 0 : 1);
+        const pf32x4a* p = reinterpret_cast<const pf32x4a*>(scratch) + (((int64_t)slot * 4 + wave) * 16 + a * 4) * 64 + lane;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] += p[b * 64];
+    }
+    int tm, tn;
+    if (tiles_m <= tiles_n) { tn = t / tiles_m; tm = t - tn * tiles_m; }
+    else { tm = t / tiles_n; tn = t - tm * tiles_n; }
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, c16 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            C[(int64_t)(tm * 128 + wm + 16 * a + 4 * q4 + e) * ldc + tn * 128 + wn + 16 * b + c16] = acc[b][e];
+}
+
+template <int LA, int LB, int AP, int FIX>
+static hipError_t launch_planes_bal_t(const PlaneGemmArgs& g, hipStream_t s)
+{
+    auto kern = gemm_planes_bal_kernel<LA, LB, AP, FIX>;
+    static bool attr_set = false;
+    constexpr int lds = PL_NSTAGE * PL_STAGE;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.bal), dim3(64 * (4 + PL_LW)), lds, s, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !FIX) return e;
+    const int tiles = g.tiles_m * g.tiles_n, rem = tiles - (tiles / g.bal) * g.bal;
+    if (rem > 0)
+        hipLaunchKernelGGL(bal_fixup_kernel, dim3(4 * rem), dim3(256), 0, s, g.scratch, g.C, g.ldc, g.tiles_m, g.tiles_n, g.K / 32, g.bal);
+    return hipGetLastError();
+}
+
+int bal_max_segments(int tiles, int S, int P)
+{
+    int mx = 1;
+    for (int t = (tiles / P) * P; t < tiles; ++t) mx = std::max(mx, bal_tile_slabs(t, tiles, S, P));
+    return mx;
+}
+
+// g.bal = number of workgroups; g.fused = 0 (slabs, one per piece of a tile) or 4 (in place: shared tiles through
+// g.scratch, 128 KB per workgroup, and bal_fixup_kernel)
+hipError_t launch_gemm_planes_bal(int la, int lb, const PlaneGemmArgs& g, hipStream_t s)
+{
+    const int64_t U = (int64_t)g.tiles_m * g.tiles_n * (g.K / 32);
+    if (g.M % 128 || g.N % 128 || g.K % 32 || g.tiles_m != g.M / 128 || g.tiles_n != g.N / 128 || (g.lda & 7) || (g.ldb & 7) ||
+        g.bal < 1 || g.bal > U / 4 || (g.fused != 0 && g.fused != 4) || (g.ap != 0 && g.ap != 1 && g.ap != 3))
+        return hipErrorInvalidValue;
+    if (g.fused == 4 && (g.scratch == nullptr || (int64_t)g.bal * 2 * 65536 >= (int64_t)1 << 31)) return hipErrorInvalidValue;
+    if (g.c_bytes <= 0 || g.c_bytes >= (int64_t)1 << 31) return hipErrorInvalidValue;
+#define PL_CASE(LAV, LBV, APV)                                                                \
+    if (la == LAV && lb == LBV && g.ap == APV)                                                \
+        return g.fused == 4 ? launch_planes_bal_t<LAV, LBV, APV, 1>(g, s) : launch_planes_bal_t<LAV, LBV, APV, 0>(g, s)
+    PL_CASE(LAY_K, LAY_MN, 3); PL_CASE(LAY_K, LAY_MN, 1); PL_CASE(LAY_K, LAY_K, 3); PL_CASE(LAY_K, LAY_K, 1);
+    PL_CASE(LAY_MN, LAY_MN, 3);
+    PL_CASE(LAY_K, LAY_MN, 0); PL_CASE(LAY_K, LAY_K, 0); PL_CASE(LAY_MN, LAY_MN, 0);
+#undef PL_CASE
+    return hipErrorInvalidValue;
+}
+
+#undef RD_A
+#undef RD_B
+#undef MMQ
+#undef ORD
+#undef PIN
+#undef PL_STAGE_EVEN
+#undef PL_STAGE_ODD
+#undef PL_RAW_BARRIER
+#undef PL_CONSUME_CONSTS
 
 // ----------------------------------------------------------------------------------
 // f32 matrix -> three bf16 planes (same shape, same ld): W once per externally written W, and any tensor a

@@ -1,0 +1,39 @@
+// Stand-in for a collective's kernel on a ONE-GPU box: R workgroups with the footprint of RCCL's gfx950 all-reduce
+// kernel (librccl.so 7.2.0, ncclDevKernel_Generic: 248-256 VGPRs, 37,664 B LDS, up to 512 threads per workgroup --
+// read from the code object's notes) that hold their CUs for a given time while streaming a
+// buffer.  It moves no data between GPUs and proves nothing about xGMI; it shows what the step pays when a kernel of
+// that shape runs beside it.  scripts/dp_contention_probe.py drives it.  Not part of the product library.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+__global__ __launch_bounds__(512) void occupier_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4,
+                                                      int64_t ticks)     // 100 MHz wall-clock ticks
+{
+    __shared__ volatile float lds[37664 / 4];
+    asm volatile("v_mov_b32 v250, 0" ::: "v250");                        // the register footprint: 256 VGPRs per wave
+    lds[threadIdx.x] = 0.f;
+    const int64_t t0 = wall_clock64();
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // every wave leaves when the time is up: the loop is bounded by the clock, not by the data
+    while (wall_clock64() - t0 < ticks) {
+        const float4 v = src[i % n4];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        dst[i % n4] = acc;
+        i += stride;
+        // ~32 bytes per thread per microsecond: 32 x 512 threads move ~0.5 TB/s, about what an 8-rank ring all-reduce of
+        // the 16.8 MB statistics buffer reads and writes locally in 120 us
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (acc.x == 12345.678f) dst[0] = make_float4(lds[(threadIdx.x * 7) % (37664 / 4)], 0.f, 0.f, 0.f);   // keep both alive
+}
+
+extern "C" int occupier_launch(void* stream, int blocks, int threads, const void* src, void* dst, long long n_bytes,
+                               double microseconds)
+{
+    if (blocks <= 0) return 0;
+    hipLaunchKernelGGL(occupier_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst,
+                       (int64_t)(n_bytes / 16), (int64_t)(microseconds * 100.0));
+    return (int)hipGetLastError();
+}

@@ -25,3 +25,14 @@ for rnd in range(5):
         res[v].append((time.perf_counter() - t0) * 1e4)
 for v in values:
     print("%s=%d: median %.1f us/step (min %.1f)" % (opt, v, np.median(res[v]), min(res[v])))
+# per-GEMM averages (HIP events around each launch) under every value
+for v in values:
+    eng.set_option(opt, v)
+    run(5); eng.synchronize()
+    eng.kernel_timing(True); run(50); eng.synchronize()
+    groups = {}
+    for ms, alg, pipe, kind in eng.kernel_timing_detail():
+        groups.setdefault(kind, []).append(ms)
+    eng.kernel_timing(False)
+    print("%s=%d GEMM launches: %s" % (opt, v, ", ".join("kind %d: %.1f us x%d" % (k, 1e3 * np.mean(t), len(t) // 50)
+                                                          for k, t in sorted(groups.items()))))

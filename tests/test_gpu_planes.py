@@ -200,6 +200,36 @@ def test_in_launch_splitk_reduction_is_bitwise_and_repeatable(hip_engine, gauss,
     assert np.array_equal(runs[0]["costs"], runs[2]["costs"]) and np.array_equal(runs[0]["costs"], runs[3]["costs"])
 
 
+@pytest.mark.parametrize("gauss,V,H,B,k,comm_cus", [(True, 4096, 1024, 512, 1, 32), (True, 4096, 1024, 512, 1, 1),
+                                                    (False, 1024, 512, 512, 2, 192), (True, 2048, 1024, 384, 1, 100)])
+def test_balanced_launches_match_and_repeat(hip_engine, gauss, V, H, B, k, comm_cus):
+    """mdbn_set_option("comm_cus", n): the plane GEMMs run on (CUs - n) workgroups that share tiles x stages evenly
+    (data-parallel mode: the CUs left over belong to the collective).  A tile's stages are then summed in another
+    grouping -- forward passes through per-segment slabs, the statistics GEMM through parked partials and per-wave
+    flags -- so the step agrees with the one-workgroup-per-tile step to fp32 summation order, and with ITSELF bit for
+    bit from run to run (a race in the flag protocol would show as run-to-run differences)."""
+    eng = hip_engine
+    ref, _, _, _ = _run_steps(eng, gauss, True, V, H, B, k, steps=3, seed=2)
+    runs = []
+    for _ in range(3):
+        eng.set_option("comm_cus", comm_cus)
+        try:
+            out, rbm, wp, valid = _run_steps(eng, gauss, True, V, H, B, k, steps=3, seed=2)
+        finally:
+            eng.set_option("comm_cus", 0)
+        runs.append(out)
+    for key in ("W", "Ws", "hb", "vbs"):
+        scale = max(1e-3, np.abs(ref[key]).max())
+        assert np.isfinite(runs[0][key]).all(), key
+        assert np.abs(runs[0][key] - ref[key]).max() <= 2e-5 * scale, key
+    np.testing.assert_allclose(runs[0]["costs"], ref["costs"], rtol=1e-4)
+    for other in runs[1:]:
+        for key in runs[0]:
+            assert np.array_equal(runs[0][key], other[key]), key
+    p1, p2, p3 = planes_to_f32(wp)             # the planes of W followed the (unfused) update
+    assert valid and torch.equal((p3 + p2) + p1, rbm.W.tensor._base if rbm.W.tensor._base is not None else rbm.W.tensor)
+
+
 def test_bf16_input_reporting_mode(hip_engine):
     """mdbn_set_option("bf16_inputs", 1): one product on the leading bf16 pieces.  A reporting mode (BASELINE configs[1]
     names "bf16/fp32"), not a parity path: probabilities within 3e-2 of the oracle, far outside the 2e-6 of the default
