@@ -390,6 +390,7 @@ def main():
                         "per_rank_ms_per_step": rank_ms, "allreduce_alone_us": allreduce_us,
                         "allreduce_bytes": 4 * (V * H + H + V + 4) if world > 1 else 0,
                         "overlap": bool(getattr(step_fn, "overlap", False)),
+                        "comm_cus": int(getattr(step_fn, "comm_cus", 0)),
                         "collective": step_fn.group.collective if getattr(step_fn, "group", None) is not None else None},
         # achieved = FLOPs ISSUED on the matrix pipe the GEMM kernels execute on (six / three bf16 products per
         # algorithmic f32 product), summed over the step's GEMM launches, / their summed HIP-event durations;

@@ -96,7 +96,10 @@ typedef struct mdbn_cd_args {
     int32_t      W_planes_valid; /* 1: W_planes already hold the split of the current W; 0: split W first.
                                * mdbn_cd_train_step / mdbn_apply_update (with its W_planes set) keep them in
                                * step with W, so a caller passes 0 only after writing W itself            */
-    int32_t      reserved1;
+    int32_t      comm_cus;       /* data-parallel mode: CUs left to a collective that runs beside this step; > 0: the plane
+                               * GEMMs are launched balanced on (CUs - comm_cus) workgroups instead of one workgroup
+                               * per CU (a collective's kernel takes whole CUs, and a full grid on fewer CUs needs a
+                               * second round).  0: one workgroup per CU.  mdbn_set_option("comm_cus") overrides 0.  */
 } mdbn_cd_args;
 
 /* Parameter update of src/rbm.py:347-365 from (all-reduced) statistics. */

@@ -27,7 +27,7 @@ class CdArgs(C.Structure):
                 ("stats", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
                 ("rng", Rng), ("trace_h", C.c_void_p), ("trace_v", C.c_void_p),
                 ("planes", C.c_void_p), ("planes_bytes", C.c_int64), ("W_planes", C.c_void_p),
-                ("W_planes_valid", C.c_int32), ("reserved1", C.c_int32)]
+                ("W_planes_valid", C.c_int32), ("comm_cus", C.c_int32)]
 
 
 class UpdateArgs(C.Structure):

@@ -539,10 +539,11 @@ bool planes_eligible(const mdbn_cd_args* a, bool fused_update)
 // Workgroups of a balanced launch over `units` stage units (0: launch one workgroup per tile job as usual).  Balanced
 // launches exist for the 16x16x32 shape only, need >= 4 stages per workgroup to keep the LDS ring busy, and the in-place
 // variant parks through a workspace sized for kMaxBalBlocks workgroups.
-int bal_blocks(const mdbn_ctx* ctx, int64_t tiles, int64_t stages)
+int bal_blocks(const mdbn_ctx* ctx, int comm_cus, int64_t tiles, int64_t stages)
 {
-    if ((g_opt_comm_cus <= 0 && g_opt_bal_blocks <= 0) || g_opt_planes_mfma != 16) return 0;
-    int P = g_opt_bal_blocks > 0 ? g_opt_bal_blocks : std::min(ctx->num_cu - g_opt_comm_cus, kMaxBalBlocks);
+    if (comm_cus <= 0) comm_cus = g_opt_comm_cus;
+    if ((comm_cus <= 0 && g_opt_bal_blocks <= 0) || g_opt_planes_mfma != 16) return 0;
+    int P = g_opt_bal_blocks > 0 ? g_opt_bal_blocks : std::min(ctx->num_cu - comm_cus, kMaxBalBlocks);
     if (P < 1) return 0;
     // Fewer tiles than workgroups (forward passes): every tile is shared.  When P is not a multiple of the tile count the
     // shares begin at stages scattered all over the reduction index, the workgroups stop sweeping it in step and the
@@ -557,9 +558,9 @@ int bal_blocks(const mdbn_ctx* ctx, int64_t tiles, int64_t stages)
 
 // One forward pass on planes: A planes [rows, K] (ROW), W planes as COL (dir 0: propup) or ROW (dir 1: propdown);
 // `e` arrives with outputs / bias / rng / colsum set, this fills in the slab side and the cost partials.
-int run_affine_planes(mdbn_ctx* ctx, const unsigned short* A, int64_t lda, int64_t pa, int ap, int dir, const unsigned short* Wp,
-                      int64_t V, int64_t H, int64_t rows, EpiArgs e, bool want_cost, const Workspace& ws, hipStream_t s,
-                      int* n_cost_out)
+int run_affine_planes(mdbn_ctx* ctx, int comm_cus, const unsigned short* A, int64_t lda, int64_t pa, int ap, int dir,
+                      const unsigned short* Wp, int64_t V, int64_t H, int64_t rows, EpiArgs e, bool want_cost, const Workspace& ws,
+                      hipStream_t s, int* n_cost_out)
 {
     const int64_t Kdim = dir == 0 ? V : H, Ndim = dir == 0 ? H : V;
     PlaneGemmArgs g{};
@@ -573,7 +574,7 @@ int run_affine_planes(mdbn_ctx* ctx, const unsigned short* A, int64_t lda, int64
     }
     // data-parallel mode: P workgroups share tiles x stages evenly; a tile's segments land in slabs, the epilogue launch
     // sums the slabs each tile has
-    int bal = bal_blocks(ctx, (int64_t)g.tiles_m * g.tiles_n, Kdim / 32), bal_slabs = 0;
+    int bal = bal_blocks(ctx, comm_cus, (int64_t)g.tiles_m * g.tiles_n, Kdim / 32), bal_slabs = 0;
     if (bal) {
         bal_slabs = bal_max_segments(g.tiles_m * g.tiles_n, (int)(Kdim / 32), bal);
         if ((int64_t)bal_slabs * rows * e.ld > ws.slab_floats) bal = 0;        // a workspace sized before the option was set
@@ -593,9 +594,19 @@ int run_affine_planes(mdbn_ctx* ctx, const unsigned short* A, int64_t lda, int64
     const int lb = dir == 0 ? LAY_MN : LAY_K;
     if (bal) {
         g.bal = bal; g.fused = 0; g.C = ws.slabs; g.ldc = e.ld; g.slab_stride = rows * e.ld;
+        // the shares of one tile have no operand stage in common; tiles in one row / column of tiles do.  With many more
+        // workgroups than tiles deal a tile's shares over the XCDs, otherwise keep neighbouring tiles on one XCD
+        // (c2 data-parallel step at P = 224: 190.9 us with this rule, 194.6 all dealt, 193.8 all grouped)
+        g.xcd_group = bal >= 4 * g.tiles_m * g.tiles_n ? 0 : 1;
         g.splitk = 1; g.kchunk = (int)Kdim; g.c_bytes = (int64_t)bal_slabs * rows * e.ld * 4;
         e.slabs = ws.slabs; e.slab_stride = g.slab_stride; e.nsplit = bal_slabs;
         e.bal_P = bal; e.bal_S = (int)(Kdim / 32); e.bal_tiles_m = g.tiles_m; e.bal_tiles_n = g.tiles_n;
+        {   // every tile with the same number of slabs: the epilogue needs no per-tile count (and has unrolled variants)
+            const int tiles = g.tiles_m * g.tiles_n;
+            bool uniform = true;
+            for (int t = 0; t < tiles && uniform; ++t) uniform = bal_tile_slabs(t, tiles, e.bal_S, bal) == bal_slabs;
+            if (uniform) e.bal_P = 0;
+        }
         HIP_OK(timed_gemm_planes(LAY_K, lb, g, s));
         HIP_OK(launch_act_epilogue(e, s));
     } else if (fuse) {
@@ -647,7 +658,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
         e.ld = ldh; e.bias = a->hbias; e.mean = keep ? ph : nullptr; e.sample = keep ? a->hs : nullptr; e.mean_scale = 1.0f; e.gauss = 0;
         e.colsum = ws.colPpos; e.colsum_kind = 0; e.rng = key(0);
         e.mean_planes = pb.Pp; e.plane_stride = pb.pp; e.sample_plane = pb.hsp;
-        CHECK(run_affine_planes(ctx, pb.Xp, ldv, pb.px, 3, 0, Wp, V, H, B, e, false, ws, s, nullptr));
+        CHECK(run_affine_planes(ctx, a->comm_cus, pb.Xp, ldv, pb.px, 3, 0, Wp, V, H, B, e, false, ws, s, nullptr));
         if (a->trace_h) HIP_OK(hipMemcpyAsync(a->trace_h, a->hs, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
     }
     int n_cost = 0;
@@ -660,7 +671,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
             e.mean_planes = pb.Xp + B * ldv; e.plane_stride = pb.px;      // rows B..2B-1 of the X2 planes
             e.sample_plane = a->gauss ? nullptr : pb.vsp;
             if (last) { e.target = v0; e.ld_target = ldv; e.colsum = ws.colV; e.colsum_kind = 1; }
-            CHECK(run_affine_planes(ctx, pb.hsp, ldh, B * ldh, 1, 1, Wp, V, H, B, e, last, ws, s, last ? &n_cost : nullptr));
+            CHECK(run_affine_planes(ctx, a->comm_cus, pb.hsp, ldh, B * ldh, 1, 1, Wp, V, H, B, e, last, ws, s, last ? &n_cost : nullptr));
             if (a->trace_v && !a->gauss)
                 HIP_OK(hipMemcpyAsync(a->trace_v + (int64_t)(t - 1) * B * ldv, a->vs, sizeof(float) * B * ldv,
                                       hipMemcpyDeviceToDevice, s));
@@ -673,8 +684,8 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
             e.mean_planes = pb.Pp + B * ldh; e.plane_stride = pb.pp;       // rows B..2B-1 of the P2 planes: -nh_mean
             e.sample_plane = need_sample ? pb.hsp : nullptr;
             if (last) { e.colsum = ws.colPneg; e.colsum_kind = 0; }
-            if (a->gauss) CHECK(run_affine_planes(ctx, pb.Xp + B * ldv, ldv, pb.px, 3, 0, Wp, V, H, B, e, false, ws, s, nullptr));
-            else CHECK(run_affine_planes(ctx, pb.vsp, ldv, B * ldv, 1, 0, Wp, V, H, B, e, false, ws, s, nullptr));
+            if (a->gauss) CHECK(run_affine_planes(ctx, a->comm_cus, pb.Xp + B * ldv, ldv, pb.px, 3, 0, Wp, V, H, B, e, false, ws, s, nullptr));
+            else CHECK(run_affine_planes(ctx, a->comm_cus, pb.vsp, ldv, B * ldv, 1, 0, Wp, V, H, B, e, false, ws, s, nullptr));
             if (a->trace_h && need_sample)
                 HIP_OK(hipMemcpyAsync(a->trace_h + (int64_t)t * B * ldh, a->hs, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
         }
@@ -694,7 +705,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     g.fin_enabled = 0;
     // data-parallel mode: the statistics land in place from a balanced launch (partials of shared tiles go through
     // scratch carved from the slab region, which the forward passes no longer need)
-    int bal = sp.splitk == 1 ? bal_blocks(ctx, (int64_t)g.tiles_m * g.tiles_n, 2 * B / 32) : 0;
+    int bal = sp.splitk == 1 ? bal_blocks(ctx, a->comm_cus, (int64_t)g.tiles_m * g.tiles_n, 2 * B / 32) : 0;
     if (bal && ((int64_t)bal * 2 * 16384 > ws.slab_floats || V * ldh * 4 >= (int64_t)1 << 31)) bal = 0;
     const bool fuse_upd = !bal && upd != nullptr && g_opt_fused_update && sp.splitk == 1;
     if (fuse_upd) {
@@ -719,6 +730,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     mdbn_update_args u;
     if (upd) { u = *upd; u.phase = 0; }
     if (bal) {
+        g.xcd_group = 1;
         g.C = S; g.bal = bal; g.fused = 4; g.kchunk = (int)(2 * B); g.c_bytes = V * ldh * 4;
         g.scratch = ws.slabs;
         HIP_OK(timed_gemm_planes(LAY_MN, LAY_MN, g, s));
@@ -1240,6 +1252,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
     REQUIRE(ctx != nullptr && a != nullptr, "NULL argument");
     const int64_t B = a->B, V = a->V, H = a->H, ldv = a->ldv, ldh = a->ldh;
     REQUIRE(B > 0 && V > 0 && H > 0 && a->k >= 1, "bad shape / k");
+    REQUIRE(a->comm_cus >= 0 && a->comm_cus <= 192, "comm_cus must be in [0, 192]");
     REQUIRE(ldv >= V && ldh >= H && ldv % 4 == 0 && ldh % 4 == 0, "leading dims must be multiples of 4, >= V / H");
     CHECK(check_mat(a->data, ldv, V, "data"));
     CHECK(check_mat(a->W, ldh, H, "W"));

@@ -114,6 +114,7 @@ struct PlaneGemmArgs {
     // balanced launches (launch_gemm_planes_bal): `bal` workgroups share tiles x (K / 32) stages evenly;
     // fused = 0: slabs, one per piece of a tile; fused = 4: result in place, pieces of shared tiles through `scratch`
     int bal;
+    int xcd_group;         // balanced: 1 = consecutive workgroups on one XCD, 0 = dealt over the XCDs
     float* scratch;        // fused == 4: 128 KB per workgroup
     int64_t c_bytes;       // balanced: bytes addressable from C (all slabs; < 2 GiB)
     EpiArgs epi;

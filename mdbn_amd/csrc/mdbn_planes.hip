@@ -236,6 +236,13 @@ __device__ __forceinline__ void pl_offsets16(int lane, int wm, int wn, int (&off
         RD_A(Alo, NEXT, 0); MMQ(Ahi, Blo, 1, 0); ORD(RA);                                     \
         RD_B(Blo, NEXT, 0); MMQ(Ahi, Bhi, 1, 1); ORD(RB);                                     \
     } while (0)
+// __syncthreads() fences: it waits for EVERY outstanding memory operation of the wave (stores flushed at a seam of a
+// balanced launch included).  The stage barrier only has to order LDS traffic: the fragment reads of the stage have
+// returned (PIN), so wait for LDS and meet.
+#define PL_RAW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifndef PL_MAIN_BARRIER
+#define PL_MAIN_BARRIER() __syncthreads()
+#endif
 #define PL_CONSUME_CONSTS()                                                                   \
     constexpr int NA = AP == 3 ? 3 : 1, NB = AP == 0 ? 1 : 3;      /* AP = 0: bf16-input reporting mode */ \
     constexpr int RA = 2 * NA * (LA == LAY_MN ? 2 : 1), RB = 2 * NB * (LB == LAY_MN ? 2 : 1), \
@@ -255,12 +262,12 @@ __device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int w
         {   // even stage
             const char* base = smem + (it % PL_NSTAGE) * PL_STAGE;
             const char* next = smem + ((it + 1) % PL_NSTAGE) * PL_STAGE;
-            PL_STAGE_EVEN(base, next, __syncthreads());
+            PL_STAGE_EVEN(base, next, PL_MAIN_BARRIER());
         }
         if (it + 1 < nt) {   // odd stage
             const char* base = smem + ((it + 1) % PL_NSTAGE) * PL_STAGE;
             const char* next = smem + ((it + 2) % PL_NSTAGE) * PL_STAGE;
-            PL_STAGE_ODD(base, next, __syncthreads());
+            PL_STAGE_ODD(base, next, PL_MAIN_BARRIER());
         }
     }
 }
@@ -706,17 +713,17 @@ __device__ __forceinline__ void pl_loader_bal(const PlaneGemmArgs& g, char* smem
 
 typedef unsigned int pu32x4b __attribute__((ext_vector_type(4)));
 
-// __syncthreads() fences: it waits for EVERY outstanding memory operation of the wave, stores flushed at a seam
-// included.  The stage barrier only has to order LDS traffic: the fragment reads of the stage have returned (PIN), so
-// wait for LDS and meet.
-#define PL_RAW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
 template <int LA, int LB, int AP, int FIX>
 __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_bal_kernel(PlaneGemmArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int P = gridDim.x;
-    const int w = blockIdx.x;
+    // Hardware ids are dealt round-robin over the 8 XCDs, each with its own L2.  xcd_group = 1: consecutive logical
+    // workgroups (neighbouring tiles: shared operand tiles) sit on the same XCD (propdown at c2: 25.7 -> 21.0 us);
+    // xcd_group = 0: consecutive workgroups (the shares of ONE tile, which have no operand stage in common) are dealt
+    // over the XCDs, so that an XCD sees one slice of the reduction index of every tile (propup at c2: 30.6 -> 27.1 us)
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3, qq = P >> 3, rem = P & 7;
+    const int w = g.xcd_group ? (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + slot : bid;
     const int S = g.K / 32, tiles = g.tiles_m * g.tiles_n;
     const BalRange r = bal_range(w, P, tiles, S);
     const int nt = r.nt;

@@ -87,6 +87,15 @@ class Group(object):
         return td.all_reduce(tensor, op=td.ReduceOp.SUM, group=self.pg, async_op=True)
 
 
+DEFAULT_COMM_CUS = 32
+
+
+def comm_cus():
+    """CUs an overlapped data-parallel step leaves to the collective (``MDBN_COMM_CUS``, default 32 of 256: the
+    step's GEMMs then run on 224 workgroups, a multiple of the tile counts at the c2 shape)."""
+    return max(0, min(192, int(os.environ.get("MDBN_COMM_CUS", DEFAULT_COMM_CUS))))
+
+
 def shard_bounds(n, rank, world_size):
     base, rem = divmod(int(n), int(world_size))
     lo = rank * base + min(rank, rem)
@@ -112,6 +121,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if comm_cus() > 0:
+            # one RCCL channel = one workgroup = one CU: keep the collective within the CUs the step leaves it
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", str(comm_cus()))
         if backend is None:
             # MDBN_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals (RCCL needs
             # one GPU per rank); the default on GPUs is nccl = RCCL over xGMI

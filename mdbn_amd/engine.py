@@ -347,7 +347,7 @@ class HipEngine(object):
 
     # ------------------------------------------------------------------ CD-k
     def _cd_args(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent, add_noise, stats_slot,
-                 sample_stats=False, stats=None):
+                 sample_stats=False, stats=None, comm_cus=0):
         data = self.as_matrix(data)
         V, H = W.shape
         assert data.shape[1] == V, "data has %d columns, RBM has %d visibles" % (data.shape[1], V)
@@ -381,6 +381,7 @@ class HipEngine(object):
             wp, valid = self.w_planes(W, create=True)
             a.planes, a.planes_bytes = sc.planes.data_ptr(), sc.planes.numel() * 2
             a.W_planes, a.W_planes_valid = wp.data_ptr(), int(valid)
+        a.comm_cus = int(comm_cus)
         if self.trace_chain:
             if sc.trace_h is None or sc.trace_h.shape[0] != k + 1:
                 sc.trace_h = torch.zeros((k + 1, B, ldh), dtype=torch.float32, device=self.device)
@@ -390,12 +391,13 @@ class HipEngine(object):
         return a, stats, sc, (data, idx, ws)        # keep the tensors alive until enqueued
 
     def cd_step(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent=None, add_noise=False,
-                stats_slot=0, sample_stats=False, stats=None):
+                stats_slot=0, sample_stats=False, stats=None, comm_cus=0):
         """gather + positive phase + k Gibbs steps + statistics (rbm.py:303-345,374).
         Returns (stats, scratch): the packed [S | s_h | s_v | cost_sum] buffer and the
-        CDScratch holding ph_mean / nv_mean / nh_mean for inspection."""
+        CDScratch holding ph_mean / nv_mean / nh_mean for inspection.  ``comm_cus`` > 0 (data-parallel
+        mode): CUs left to the collective that runs beside this step (mdbn_cd_args.comm_cus)."""
         a, stats, sc, _keep = self._cd_args(data, indexes, W, hbias, vbias, gauss, k, rng, persistent,
-                                            add_noise, stats_slot, sample_stats, stats)
+                                            add_noise, stats_slot, sample_stats, stats, comm_cus)
         _lib.check(self.lib.mdbn_cd_step(self.ctx, self._stream(), C.byref(a)), "mdbn_cd_step")
         if a.W_planes:
             self._w_planes_written(W)            # (split on entry if they were stale)

@@ -113,13 +113,16 @@ class StepFunction(object):
         # nan_guard: check cost and parameters for NaN / Inf after every call (synchronises; what the
         # reference's commented-out NanGuardMode would do, rbm.py:542-543, dbn.py:311)
         self.nan_guard = bool(getattr(self.engine, "nan_guard", False))
+        self.comm_cus = 0
         if self.group is not None and self.group.world_size > 1 and hasattr(self.engine, "set_option"):
-            # RCCL's all-reduce kernels run beside the next step's GEMMs.  A GEMM block with two MFMA
-            # waves per SIMD fills the CU's register file (3 x 168 VGPRs per SIMD), so a collective
-            # block could only get a CU of its own and the 256-job GEMMs would need a second round;
-            # with one MFMA wave per SIMD (2 x 152) the two kinds of block can share a CU.  Costs
-            # ~2.5% of the GEMMs; to be re-measured on a multi-GPU node.
-            self.engine.set_option("gemm_cw", 1)
+            # The collective's kernels run beside the next step's GEMMs and take whole CUs (RCCL's gfx950 all-reduce
+            # kernel: 248-256 VGPRs per wave, 37.6 KB LDS -- nothing of ours fits next to it), and a one-workgroup-per-
+            # CU GEMM grid on fewer CUs needs a second round: measured 163 -> 219 us per step with EIGHT CUs taken.
+            # So an overlapped data-parallel step leaves `comm_cus` CUs to the collective and launches its GEMMs
+            # balanced on the rest (mdbn_planes.hip, "BALANCED launches").  MDBN_COMM_CUS
+            # overrides; dist.init_from_env caps RCCL's channels (= workgroups) at the same number.
+            self.comm_cus = _dist.comm_cus() if self.overlap else 0      # handed to every cd_step call
+            self.engine.set_option("gemm_cw", 1)        # exact-f32 fallback kernels: one MFMA wave per SIMD
         if self.overlap:
             for arr in self.rbm.params_speed:
                 arr._sync_hook = self.flush
@@ -207,9 +210,10 @@ class StepFunction(object):
                                                            rbm.W.tensor.stride(0))
         stats = self._stats_slots[slot]
         if hi > lo:
+            extra = {"comm_cus": self.comm_cus} if self.comm_cus else {}
             eng.cd_step(data, idx, rbm.W.tensor, rbm.hbias.tensor, rbm.vbias.tensor, rbm.gauss, p.k,
                         RngAddr(rbm.theano_rng.seed, rbm.stream_id, step, 0, lo),
-                        persistent=persistent, sample_stats=p.symbolic_grad, stats=stats)
+                        persistent=persistent, sample_stats=p.symbolic_grad, stats=stats, **extra)
         else:                                  # this rank holds no row of a short minibatch
             stats.zero_()
 

@@ -3,7 +3,7 @@
     python scripts/build_variants.py "-DX6_SCHED=0" "-DX6_SCHED=1" ..."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = [os.path.join(ROOT, "mdbn_amd", "csrc", f) for f in ("mdbn_kernels.hip", "mdbn_capi.hip")]
+src = [os.path.join(ROOT, "mdbn_amd", "csrc", f) for f in ("mdbn_kernels.hip", "mdbn_planes.hip", "mdbn_capi.hip")]
 out = os.path.join(ROOT, "gpurun_out"); os.makedirs(out, exist_ok=True)
 for i, flags in enumerate(sys.argv[1:]):
     so = os.path.join(out, "libmdbn_var%d.so" % i)
@@ -31,6 +31,12 @@ run(30); eng.synchronize()
 ts = []
 for r in range(5):
     t0 = time.perf_counter(); c = run(100); eng.synchronize(); ts.append((time.perf_counter() - t0) * 1e4)
-print("%%-30s median %%.1f us/step   cost %%.6f" %% (%r, np.median(ts), float(c)), flush=True)
+eng.kernel_timing(True); run(50); eng.synchronize()
+groups = {}
+for ms, alg, pipe, kind in eng.kernel_timing_detail():
+    groups.setdefault(kind, []).append(ms)
+eng.kernel_timing(False)
+print("%%-40s median %%.1f us/step   cost %%.6f   %%s" %% (%r, np.median(ts), float(c),
+      ", ".join("kind %%d: %%.1f us" %% (k, 1e3 * np.mean(t)) for k, t in sorted(groups.items()))), flush=True)
 ''' % (ROOT, so, flags)
     subprocess.check_call([sys.executable, "-c", prog])

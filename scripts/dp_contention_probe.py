@@ -79,26 +79,30 @@ def run(fn, n):
         fn(indexes=perm[mb * B:(mb + 1) * B], momentum=0.0)
 
 
+host_us = [0.0]
+
+
 def median_us(fn):
     run(fn, 20); eng.synchronize()
-    out = []
+    out, host = [], []
     for _ in range(5):
-        t0 = time.perf_counter(); run(fn, 100); eng.synchronize()
+        t0 = time.perf_counter(); run(fn, 100)
+        host.append((time.perf_counter() - t0) * 1e4)      # time to ENQUEUE 100 steps (the queue is far from full)
+        eng.synchronize()
         out.append((time.perf_counter() - t0) * 1e4)
+    host_us[0] = float(np.median(host))
     return float(np.median(out))
 
 
 single = make(None)
-print("single-device fused step                         %.1f us/step" % median_us(single), flush=True)
+print("single-device fused step                         %.1f us/step  (host enqueue %.1f)" % (median_us(single), host_us[0]), flush=True)
 for reserve in [int(x) for x in args.reserve.split(",")]:
-    try:
-        eng.set_option("comm_cus", reserve)
-    except Exception as e:
-        if reserve:
-            print("comm_cus not available:", e); continue
+    os.environ["MDBN_COMM_CUS"] = str(reserve)       # read by StepFunction, handed to every mdbn_cd_step call
     dp = make(grp)
+    assert dp.comm_cus == reserve
     for blocks in [int(x) for x in args.blocks.split(",")]:
         grp.blocks = blocks
-        print("DP path, comm_cus=%-3d occupier %3d x %d thr, %3.0f us  %.1f us/step"
-              % (reserve, blocks, args.threads, args.us, median_us(dp)), flush=True)
+        t = median_us(dp)
+        print("DP path, comm_cus=%-3d occupier %3d x %d thr, %3.0f us  %.1f us/step  (host enqueue %.1f)"
+              % (reserve, blocks, args.threads, args.us, t, host_us[0]), flush=True)
     dp.flush()

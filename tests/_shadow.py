@@ -74,7 +74,7 @@ class ShadowEngine(mdbn_amd.HipEngine):
 
     # -- PCD / data-parallel path: statistics, then the update
     def cd_step(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent=None, add_noise=False,
-                stats_slot=0, sample_stats=False, stats=None):
+                stats_slot=0, sample_stats=False, stats=None, comm_cus=0):     # comm_cus: a launch-geometry hint
         st = self._state(W, hbias, vbias, gauss)
         v0 = self._rows(data, indexes)
         chain0 = None if persistent is None else persistent.cpu().numpy().astype(np.float64)
