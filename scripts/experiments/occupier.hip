@@ -37,3 +37,28 @@ extern "C" int occupier_launch(void* stream, int blocks, int threads, const void
                        (int64_t)(n_bytes / 16), (int64_t)(microseconds * 100.0));
     return (int)hipGetLastError();
 }
+
+// Fork / join with the library's own events, to price the cross-stream dependency itself:
+//   flags = hipEventDisableTiming (0x2), optionally | hipEventReleaseToDevice (0x40000000) / hipEventDisableSystemFence (0x20000000)
+static hipEvent_t g_fork = nullptr, g_join[2] = {nullptr, nullptr};
+extern "C" int occupier_events(unsigned flags)
+{
+    for (hipEvent_t* e : {&g_fork, &g_join[0], &g_join[1]}) {
+        if (*e) (void)hipEventDestroy(*e);
+        hipError_t rc = hipEventCreateWithFlags(e, flags);
+        if (rc != hipSuccess) return (int)rc;
+    }
+    return 0;
+}
+extern "C" int occupier_fork(void* compute, void* side, int slot, int blocks, int threads, const void* src, void* dst, long long n_bytes,
+                             double microseconds)
+{
+    hipError_t rc = hipEventRecord(g_fork, (hipStream_t)compute);
+    if (rc != hipSuccess) return (int)rc;
+    rc = hipStreamWaitEvent((hipStream_t)side, g_fork, 0);
+    if (rc != hipSuccess) return (int)rc;
+    int r = occupier_launch(side, blocks, threads, src, dst, n_bytes, microseconds);
+    if (r) return r;
+    return (int)hipEventRecord(g_join[slot & 1], (hipStream_t)side);
+}
+extern "C" int occupier_join(void* compute, int slot) { return (int)hipStreamWaitEvent((hipStream_t)compute, g_join[slot & 1], 0); }

@@ -47,14 +47,15 @@ def run_steps(group_mode, overlap, shape="small"):
                 hbs=rbm.hbias_speed.get_value(), costs=np.array(costs))
 
 
-def worker(rank, world, port, outdir, overlap, shape):
+def worker(rank, world, port, outdir, overlap, shape, comm_cus=0):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
-                      WORLD_SIZE=str(world), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      WORLD_SIZE=str(world), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      MDBN_COMM_CUS=str(comm_cus))
     from mdbn_amd import dist
     dist.init_from_env(backend="gloo")
     out = run_steps(True, overlap, shape)
-    np.savez(os.path.join(outdir, "rank%d_%d.npz" % (rank, overlap)), **out)
+    np.savez(os.path.join(outdir, "rank%d_%d.npz" % (rank, overlap + (2 if comm_cus else 0))), **out)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -66,10 +67,12 @@ def test_two_ranks_equal_one_process_on_device(built_lib, shape):
     single = run_steps(False, False, shape)
     with tempfile.TemporaryDirectory() as d:
         res = {}
-        for overlap in (0, 1):
-            mp.spawn(worker, args=(2, free_port(), d, overlap, shape), nprocs=2, join=True)
-            res[overlap] = [dict(np.load(os.path.join(d, "rank%d_%d.npz" % (r, overlap)))) for r in range(2)]
-    for overlap in (0, 1):
+        # 0: synchronous; 1: overlapped; 3: overlapped with 32 CUs left to the collective (the default of a real
+        # data-parallel job: the plane GEMMs then run balanced on 224 workgroups, another summation grouping)
+        for mode, (overlap, cus) in {0: (0, 0), 1: (1, 0), 3: (1, 32)}.items():
+            mp.spawn(worker, args=(2, free_port(), d, overlap, shape, cus), nprocs=2, join=True)
+            res[mode] = [dict(np.load(os.path.join(d, "rank%d_%d.npz" % (r, mode)))) for r in range(2)]
+    for overlap in (0, 1, 3):
         r0, r1 = res[overlap]
         for k in single:
             assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
@@ -91,7 +94,7 @@ def test_two_ranks_equal_one_process_on_device(built_lib, shape):
             scale = max(float(np.abs(single[k]).max()), 1e-30)
             assert np.sqrt((diff * diff).mean()) <= 1e-2 * scale, (k, np.sqrt((diff * diff).mean()), scale)
             assert np.abs(diff).max() <= 0.3 * scale, (k, np.abs(diff).max(), scale)
-    for k in single:                     # overlapped == synchronous, bit for bit
+    for k in single:                     # overlapped == synchronous, bit for bit (same launch geometry)
         assert np.array_equal(res[0][0][k], res[1][0][k]), k
 
 
