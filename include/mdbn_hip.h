@@ -60,7 +60,7 @@ typedef struct mdbn_cd_args {
                                * chain_end of compute_symbolic_grad (rbm.py:339-342,378-390)      */
     int32_t      keep_f32;    /* plane path only: 1 = also store the float32 copies of ph_mean, -nh_mean (P2), nv_mean
                                * (rows B.. of V2) and the chain samples (hs, vs) that only an inspecting caller reads;
-                               * 0 = planes only (v0 in V2[0..B) and the statistics are always written).  The
+                               * 0 = planes only (the statistics are always written; V2 / P2 / hs / vs are then scratch without defined content).  The
                                * f32-operand path always writes them; trace_h / trace_v imply 1                      */
     int32_t      k;           /* Gibbs steps                                                     */
     int64_t      B, V, H;     /* local minibatch rows, n_visible, n_hidden                       */

@@ -650,7 +650,10 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     float* ph = a->P2;
     float* nh = a->P2 + B * ldh;
     // x = train_set_x[indexes] (dbn.py:307), as f32 (cost target, bias statistics) and as planes
-    HIP_OK(launch_gather_planes(a->data, a->n_data, ldv, ldv, a->indexes, a->index_is_64, B, v0, ldv, pb.Xp, pb.px, s));
+    // (without `keep` the float32 copy of v0 is not made either: its one reader, the reconstruction-cost / bias-statistics
+    // target of the last visible pass, reads the dataset rows through the index instead)
+    HIP_OK(launch_gather_planes(a->data, a->n_data, ldv, ldv, a->indexes, a->index_is_64, B, keep ? v0 : nullptr, ldv, pb.Xp,
+                                pb.px, s));
 
     auto key = [&](uint32_t draw) { PhiloxKey k = make_key(a->rng, draw); return k; };
     {   // positive phase: ph_mean (+ planes), h0 sample (f32 for the taps, plane for the chain)   (rbm.py:303)
@@ -670,7 +673,14 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
             e.sample = (a->gauss || !keep) ? nullptr : a->vs; e.rng = key((uint32_t)(2 * t - 1));
             e.mean_planes = pb.Xp + B * ldv; e.plane_stride = pb.px;      // rows B..2B-1 of the X2 planes
             e.sample_plane = a->gauss ? nullptr : pb.vsp;
-            if (last) { e.target = v0; e.ld_target = ldv; e.colsum = ws.colV; e.colsum_kind = 1; }
+            if (last) {
+                e.colsum = ws.colV; e.colsum_kind = 1;
+                if (keep) { e.target = v0; e.ld_target = ldv; }
+                else {
+                    e.target = a->data; e.ld_target = ldv; e.target_rows = a->n_data;
+                    e.target_idx = a->indexes; e.target_idx64 = a->index_is_64;       // NULL: rows 0..B-1 of the data
+                }
+            }
             CHECK(run_affine_planes(ctx, a->comm_cus, pb.hsp, ldh, B * ldh, 1, 1, Wp, V, H, B, e, last, ws, s, last ? &n_cost : nullptr));
             if (a->trace_v && !a->gauss)
                 HIP_OK(hipMemcpyAsync(a->trace_v + (int64_t)(t - 1) * B * ldv, a->vs, sizeof(float) * B * ldv,

@@ -157,6 +157,16 @@ __device__ __forceinline__ void finalize_unit(const FinArgs& f, int unit, int la
 // each).  |error| of sigmoid <= ~1e-7 absolute: the exponent's argument rounding |x|*6e-8 is
 // multiplied by sigmoid' = p(1-p) <= 1/4.  The libm-grade expf/division these replace made
 // the epilogue VALU-bound (14 us per call at B*H = 512K elements).
+// row of EpiArgs.target that output row `row` is compared with (identity, or through the minibatch index)
+__device__ __forceinline__ int64_t epi_target_row(const EpiArgs& e, int64_t row)
+{
+    if (!e.target_idx) return row;
+    int64_t s = e.target_idx64 ? reinterpret_cast<const int64_t*>(e.target_idx)[row]
+                               : (int64_t)reinterpret_cast<const int32_t*>(e.target_idx)[row];
+    if (s < 0) s += e.target_rows;
+    return s < 0 ? 0 : (s >= e.target_rows ? e.target_rows - 1 : s);
+}
+
 __device__ __forceinline__ float sigmoidf_(float x)
 {
     return __frcp_rn(1.0f + __expf(-x));
@@ -276,7 +286,7 @@ __device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, f
             }
             float tg = 0.f;
             if (e.target && live) {
-                tg = e.target[(int64_t)row * e.ld_target + col];
+                tg = e.target[epi_target_row(e, row) * e.ld_target + col];
                 if (e.gauss) { const float d = sigmoidf_(xj) - tg; cost += d * d; }
                 else cost += tg * softplusf_(-xj) + (1.0f - tg) * softplusf_(xj);
             }

@@ -23,6 +23,11 @@ struct EpiArgs {
     int gauss;             // 0: sigmoid + Bernoulli ; 1: linear + N(0,1)
     const float* target;   // nullable: reconstruction-cost target (v0)
     int64_t ld_target;
+    // target rows through a minibatch index (plane path without the float32 copy of v0: the target is the dataset
+    // itself): row r of the output reads row target_idx[r] (numpy-style negative values, clamped like the gather)
+    const void* target_idx;     // nullable: int32 / int64 [rows]
+    int target_idx64;
+    int64_t target_rows;        // rows of the matrix `target` points into
     float* cost_partials;  // nullable: one float per block
     float* colsum;         // nullable: [ceil(rows/4)][ld] partial column sums over each 4-row group
     int colsum_kind;       // 0: sum of stored (scaled) mean ; 1: sum of (target - mean) ; 2: sum of (target - sample)

@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
             float mean[CW], samp[CW], tgt[CW];
 #pragma unroll
             for (int j = 0; j < CW; ++j) tgt[j] = 0.f;
-            if (e.target) VecIO<CW>::load(e.target + (int64_t)(r0 + r) * e.ld_target + c0, tgt);
+            if (e.target) VecIO<CW>::load(e.target + epi_target_row(e, r0 + r) * e.ld_target + c0, tgt);
 #pragma unroll
             for (int j = 0; j < CW; ++j) {
                 const bool live = c0 + j < e.cols;

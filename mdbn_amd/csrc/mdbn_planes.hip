@@ -932,7 +932,7 @@ hipError_t launch_split_planes(const float* X, int64_t rows, int64_t ld, unsigne
     return hipGetLastError();
 }
 
-// minibatch gather (dbn.py:307) that also writes the rows' planes: dst f32 [n_idx][ld] + planes [3][.][ld].
+// minibatch gather (dbn.py:307) that also writes the rows' planes: dst f32 [n_idx][ld] (nullable) + planes [3][.][ld].
 // A thread moves 8 columns (two float4 in, two float4 + three 16-byte plane stores out).
 __global__ __launch_bounds__(256) void gather_planes_kernel(const float* __restrict__ src, int64_t n_rows, int64_t ld_src,
                                                             const void* __restrict__ idx, int idx64, int64_t ld8,
@@ -948,8 +948,10 @@ __global__ __launch_bounds__(256) void gather_planes_kernel(const float* __restr
     s = s < 0 ? 0 : (s >= n_rows ? n_rows - 1 : s);
     const float4 v0 = reinterpret_cast<const float4*>(src + s * ld_src)[2 * c];
     const float4 v1 = reinterpret_cast<const float4*>(src + s * ld_src)[2 * c + 1];
-    reinterpret_cast<float4*>(dst + r * ld_dst)[2 * c] = v0;
-    reinterpret_cast<float4*>(dst + r * ld_dst)[2 * c + 1] = v1;
+    if (dst) {                                    // the float32 copy is optional (mdbn_cd_args.keep_f32)
+        reinterpret_cast<float4*>(dst + r * ld_dst)[2 * c] = v0;
+        reinterpret_cast<float4*>(dst + r * ld_dst)[2 * c + 1] = v1;
+    }
     const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
     unsigned short q[3][8];
 #pragma unroll
