@@ -734,8 +734,16 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
         HIP_OK(timed_gemm_planes(LAY_MN, LAY_MN, g, s));
         return MDBN_OK;
     }
-    HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials, n_cost, s_h,
-                                 s_v, cost, nullptr, s));
+    // bias statistics + cost total: inside the statistics GEMM (its MFMA waves run the units while the first stages are
+    // in flight) when that GEMM is one launch, a launch of its own (~6 us of dependent tiny kernel) otherwise
+    if (sp.splitk == 1 && g_opt_fused_finalize) {
+        g.fin_enabled = 1;
+        g.fin = make_fin_args(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials, n_cost, s_h, s_v,
+                              cost, nullptr);
+    } else {
+        HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials, n_cost, s_h,
+                                     s_v, cost, nullptr, s));
+    }
     g.fused = 0; g.ldc = ldh; g.slab_stride = V * ldh;
     mdbn_update_args u;
     if (upd) { u = *upd; u.phase = 0; }

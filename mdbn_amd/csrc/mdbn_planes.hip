@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
     } else {
         const int r = lane & 31, h = lane >> 5;
         const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-        if constexpr (FUSED == 2) {
+        if constexpr ((FUSED == 2 || FUSED == 0) && LA == LAY_MN && LB == LAY_MN) {
             if (g.fin_enabled) {        // statistics GEMM: finalize units while the first stages are in flight
                 const int nu = fin_units(g.fin);
                 for (int unit = wave * (int)gridDim.x + (int)blockIdx.x; unit <= nu; unit += 4 * (int)gridDim.x)
@@ -735,6 +735,13 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_bal_kernel(Plane
         return;
     }
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    if constexpr (LA == LAY_MN && LB == LAY_MN) {
+        if (g.fin_enabled) {            // statistics GEMM: finalize units while the first stages are in flight
+            const int nu = fin_units(g.fin);
+            for (int unit = wave * (int)gridDim.x + (int)blockIdx.x; unit <= nu; unit += 4 * (int)gridDim.x)
+                finalize_unit(g.fin, unit, lane);
+        }
+    }
     int offA[4][2], offB[4][2];
     pl_offsets16<LA, LB>(lane, wm, wn, offA, offB);
     PL_CONSUME_CONSTS();
