@@ -344,7 +344,7 @@ WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
         s.slab = std::max<int64_t>(s.slab, (int64_t)kMaxBalBlocks * 2 * 16384);
     }
     s.slab = std::max<int64_t>(s.slab, 4 * std::max(ldv, ldh) * 8);
-    s.cost = std::max<int64_t>(256, (((B + 3) / 4) * std::max(ldv, ldh) + 255) / 256) + 64;   // worst case: one column per thread
+    s.cost = std::max<int64_t>(256, (((B + 3) / 4) * std::max(ldv, ldh) + 63) / 64) + 64;   // worst case: one column per thread, 64-thread blocks
     // fused epilogues write one partial per block: 128 x 64 tiles, or 32-column strips (skinny)
     s.cost = std::max<int64_t>(s.cost, ((B + 127) / 128) * ((std::max(ldv, ldh) + 63) / 64) + 64);
     s.cost = std::max<int64_t>(s.cost, ((B + 63) / 64) * ((std::max(ldv, ldh) + 31) / 32) + 64);
@@ -839,6 +839,11 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "gemm_bk") == 0) {
         REQUIRE(value == 0 || value == 32 || value == 64, "gemm_bk must be 0 (auto), 32 or 64");
         g_opt_gemm_bk = (int)value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "epilogue_threads") == 0) {
+        if (value != 0 && value != 64 && value != 128 && value != 256) return fail(MDBN_EINVAL, "epilogue_threads must be 0, 64, 128 or 256");
+        set_epilogue_threads((int)value);
         return MDBN_OK;
     }
     if (strcmp(name, "epilogue_cw") == 0) {

@@ -158,6 +158,7 @@ hipError_t launch_gather_planes(const float* src, int64_t n_rows, int64_t cols_l
 int epilogue_blocks(int64_t rows, int64_t ld);
 int epilogue_cw(int64_t rows, int64_t ld);
 void set_epilogue_cw(int cw);
+void set_epilogue_threads(int t);
 inline int row_groups(int64_t B) { return (int)((B + 3) / 4); }
 
 hipError_t launch_gemm(int la, int lb, const GemmArgs& g, hipStream_t s);

@@ -1319,8 +1319,11 @@ int epilogue_cw(int64_t rows, int64_t ld)
 
 // threads per block: a small output (a 20-row minibatch) is spread over 64-thread blocks -- with
 // 256-thread blocks 4 CUs would read all the split-K slabs (12 us for 37 slabs of 20 x 400)
+static int g_epilogue_threads = 0;     // 0 = auto; 64 | 128 | 256 (mdbn_set_option "epilogue_threads")
+void set_epilogue_threads(int t) { g_epilogue_threads = t; }
 static int epilogue_threads(int64_t rows, int64_t ld)
 {
+    if (g_epilogue_threads) return g_epilogue_threads;
     const int64_t n = ((rows + 3) / 4) * (ld / epilogue_cw(rows, ld));
     return n <= 64 * 256 ? 64 : 256;
 }

@@ -201,7 +201,9 @@ def test_in_launch_splitk_reduction_is_bitwise_and_repeatable(hip_engine, gauss,
 
 
 @pytest.mark.parametrize("gauss,V,H,B,k,comm_cus", [(True, 4096, 1024, 512, 1, 32), (True, 4096, 1024, 512, 1, 1),
-                                                    (False, 1024, 512, 512, 2, 192), (True, 2048, 1024, 384, 1, 100)])
+                                                    (False, 1024, 512, 512, 2, 192), (True, 2048, 1024, 384, 1, 100),
+                                                    # forward passes with MORE tiles than workgroups: whole tiles + shared rest
+                                                    (False, 1024, 2048, 2048, 1, 32), (True, 2048, 2048, 1152, 1, 57)])
 def test_balanced_launches_match_and_repeat(hip_engine, gauss, V, H, B, k, comm_cus):
     """mdbn_set_option("comm_cus", n): the plane GEMMs run on (CUs - n) workgroups that share tiles x stages evenly
     (data-parallel mode: the CUs left over belong to the collective).  A tile's stages are then summed in another
