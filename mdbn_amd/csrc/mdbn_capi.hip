@@ -211,6 +211,11 @@ static int g_opt_planes_mfma = 16;
 // leading bf16 piece of every operand (inputs truncated to bf16, f32 accumulation, one product instead of six).
 // Probabilities then carry ~4e-3 of error: never used for a parity claim, off by default.
 static int g_opt_bf16_inputs = 0;
+// mdbn_set_option("planes_min_work"): the plane path serves a whole-tile shape only from B * V * H >= this on (and V * H
+// >= 2^21): below, the launches of a step are so short that writing every tensor twice (f32 + planes) costs more than the
+// cheaper GEMMs gain (c4's second layer 1024 -> 256 at B = 512: 69.2 us on the f32-operand kernels, 77.3 on planes;
+// 2048 -> 1024: 122.9 vs 118.9; c2: 158.7 vs 150).  0: every whole-tile shape (tests).
+static int64_t g_opt_planes_min_work = (int64_t)1 << 30;
 constexpr int kMaxReduceTiles = 1024;
 // mdbn_set_option("comm_cus"): CUs left to a collective that runs beside the step (data-parallel mode).  > 0: the plane
 // GEMMs of mdbn_cd_step are launched BALANCED on (CUs - comm_cus) workgroups (mdbn_planes.hip, "BALANCED launches"):
@@ -530,6 +535,7 @@ bool planes_eligible(const mdbn_cd_args* a, bool fused_update)
     if (a->persistent || a->sample_stats || (a->gauss && a->add_noise)) return false;
     const int64_t B = a->B, V = a->V, H = a->H;
     if (B % 128 || V % 128 || H % 128 || a->ldv != V || a->ldh != H || B > 65535) return false;
+    if (g_opt_planes_min_work > 0 && (B * V * H < g_opt_planes_min_work || V * H < ((int64_t)1 << 21))) return false;
     if (a->planes_bytes < 2 * planes_elems(B, V, H) || !aligned16(a->planes) || !aligned16(a->W_planes)) return false;
     (void)fused_update;
     return plane_plan(plan_forward(B, H, V, H), B, H, V) && plane_plan(plan_forward(B, V, H, V), B, V, H) &&
@@ -884,6 +890,11 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     }
     if (strcmp(name, "gemm_bf16x6") == 0) {
         g_opt_gemm_bf16x6 = (int)value & 3;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "planes_min_work") == 0) {
+        if (value < 0) return fail(MDBN_EINVAL, "planes_min_work must be >= 0");
+        g_opt_planes_min_work = value;
         return MDBN_OK;
     }
     if (strcmp(name, "bf16_inputs") == 0) {

@@ -214,10 +214,24 @@ class HipEngine(object):
         return C.c_void_p(t.data_ptr()) if t is not None else None
 
     # ------------------------------------------------------------------ bf16 planes of W
-    @staticmethod
-    def plane_shape(B, V, H, ldv, ldh):
-        """Shapes the plane path of the library takes (include/mdbn_hip.h): whole 128-row / column tiles."""
-        return B > 0 and B % 128 == 0 and V % 128 == 0 and H % 128 == 0 and ldv == V and ldh == H and B <= 65535
+    # The plane path pays for itself on big layers only (measured, scripts/step_ab.py gemm_planes 0 1 with
+    # MDBN_AB_SHAPE: 4096->1024 at B = 512 158.7 -> 150 us, 2048->1024 122.9 -> 118.9; but 1024->256 69.2 -> 77.3,
+    # 1024->512 at B = 256 68.1 -> 74.9, 2048->512 at B = 128 72.0 -> 80.6, 1024->1024 at B = 1024 112.0 -> 114.0):
+    # B * V * H >= planes_min_work and V * H >= 2^21.  Mirrors mdbn_set_option("planes_min_work"); tests set 0.
+    planes_min_work = 1 << 30
+
+    def plane_shape(self, B, V, H, ldv, ldh):
+        """Shapes the plane path of the library takes (include/mdbn_hip.h): whole 128-row / column tiles, big enough."""
+        if not (B > 0 and B % 128 == 0 and V % 128 == 0 and H % 128 == 0 and ldv == V and ldh == H and B <= 65535):
+            return False
+        m = int(self.planes_min_work)
+        return m <= 0 or (B * V * H >= m and V * H >= (1 << 21))
+
+    def set_planes_min_work(self, work):
+        """Smallest B * V * H the plane path serves (0: every whole-tile shape)."""
+        self.planes_min_work = int(work)
+        self.set_option("planes_min_work", int(work))
+        self._scratch.clear()            # the plane scratch of a shape exists only when the shape is served
 
     def w_planes(self, W, create=False):
         """(planes, valid) for a weight matrix: the [3, V, ldh] bf16 planes the library keeps in step with W, and

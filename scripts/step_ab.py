@@ -4,11 +4,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, mdbn_amd
 opt, values = sys.argv[1], [int(v) for v in sys.argv[2:]]
 eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
-V, H, B, N = 4096, 1024, 512, 32768
+# MDBN_AB_SHAPE="V,H,B,k,gauss" selects another layer (default: the c2 headline shape)
+V, H, B, K, GAUSS = [int(x) for x in os.environ.get("MDBN_AB_SHAPE", "4096,1024,512,1,1").split(",")]
+N = 32768
 g = torch.Generator(device="cpu").manual_seed(0)
-data = mdbn_amd.shared(torch.randn((N, V), generator=g).to(eng.device))
-rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123))
-_, up = rbm.get_cost_updates(lr=0.001, k=1, lambda_2=0.1, batch_size=B)
+if GAUSS:
+    data = mdbn_amd.shared(torch.randn((N, V), generator=g).to(eng.device))
+    rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123))
+    _, up = rbm.get_cost_updates(lr=0.001, k=K, lambda_2=0.1, batch_size=B)
+else:
+    data = mdbn_amd.shared((torch.rand((N, V), generator=g) < 0.3).float().to(eng.device))
+    rbm = mdbn_amd.RBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123))
+    _, up = rbm.get_cost_updates(lr=0.05, k=K, weightcost=2e-4, batch_size=B)
 fn = mdbn_amd.function(up, data)
 perm = torch.from_numpy(np.random.RandomState(1).permutation(N)).to(eng.device)
 def run(n):

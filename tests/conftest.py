@@ -27,6 +27,7 @@ def hip_engine(built_lib):
     import mdbn_amd
     eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
     eng.keep_f32 = True          # the parity tests inspect ph / nh / nv in the CD scratch (the product default skips those copies)
+    eng.set_planes_min_work(0)   # the plane path at every whole-tile shape (the product default keeps small layers off it)
     return eng
 
 
