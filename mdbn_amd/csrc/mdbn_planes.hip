@@ -940,35 +940,51 @@ hipError_t launch_split_planes(const float* X, int64_t rows, int64_t ld, unsigne
 }
 
 // minibatch gather (dbn.py:307) that also writes the rows' planes: dst f32 [n_idx][ld] (nullable) + planes [3][.][ld].
-// A thread moves 8 columns (two float4 in, two float4 + three 16-byte plane stores out).
+// A thread moves 8 columns (two float4 in, two float4 + three 16-byte plane stores out) of GR consecutive minibatch
+// rows, all its loads issued before the first store.  GR = 1: more rows per thread change nothing on the step
+// (same-box builds, scripts/build_variants.py: 149.2 / 150.6 / 150.2 / 150.0 us at GR = 1 / 2 / 4 / 8).
+#ifndef MDBN_GATHER_ROWS
+#define MDBN_GATHER_ROWS 1
+#endif
+constexpr int GR = MDBN_GATHER_ROWS;
 __global__ __launch_bounds__(256) void gather_planes_kernel(const float* __restrict__ src, int64_t n_rows, int64_t ld_src,
-                                                            const void* __restrict__ idx, int idx64, int64_t ld8,
+                                                            const void* __restrict__ idx, int idx64, int64_t ld8, int64_t n_idx,
                                                             float* __restrict__ dst, int64_t ld_dst,
                                                             unsigned short* __restrict__ P, int64_t plane_stride)
 {
-    const int64_t r = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.y * GR;
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ld8) return;
-    int64_t s = r;
-    if (idx) s = idx64 ? reinterpret_cast<const int64_t*>(idx)[r] : (int64_t)reinterpret_cast<const int32_t*>(idx)[r];
-    if (s < 0) s += n_rows;
-    s = s < 0 ? 0 : (s >= n_rows ? n_rows - 1 : s);
-    const float4 v0 = reinterpret_cast<const float4*>(src + s * ld_src)[2 * c];
-    const float4 v1 = reinterpret_cast<const float4*>(src + s * ld_src)[2 * c + 1];
-    if (dst) {                                    // the float32 copy is optional (mdbn_cd_args.keep_f32)
-        reinterpret_cast<float4*>(dst + r * ld_dst)[2 * c] = v0;
-        reinterpret_cast<float4*>(dst + r * ld_dst)[2 * c + 1] = v1;
+    float4 v[GR][2];
+#pragma unroll
+    for (int i = 0; i < GR; ++i) {
+        const int64_t r = r0 + i < n_idx ? r0 + i : n_idx - 1;          // clamped: the value is not stored
+        int64_t s = r;
+        if (idx) s = idx64 ? reinterpret_cast<const int64_t*>(idx)[r] : (int64_t)reinterpret_cast<const int32_t*>(idx)[r];
+        if (s < 0) s += n_rows;
+        s = s < 0 ? 0 : (s >= n_rows ? n_rows - 1 : s);
+        v[i][0] = reinterpret_cast<const float4*>(src + s * ld_src)[2 * c];
+        v[i][1] = reinterpret_cast<const float4*>(src + s * ld_src)[2 * c + 1];
     }
-    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    unsigned short q[3][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) split3(x[j], q[0][j], q[1][j], q[2][j]);
+    for (int i = 0; i < GR; ++i) {
+        const int64_t r = r0 + i;
+        if (r >= n_idx) break;
+        if (dst) {                                    // the float32 copy is optional (mdbn_cd_args.keep_f32)
+            reinterpret_cast<float4*>(dst + r * ld_dst)[2 * c] = v[i][0];
+            reinterpret_cast<float4*>(dst + r * ld_dst)[2 * c + 1] = v[i][1];
+        }
+        const float x[8] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
+        unsigned short q[3][8];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        uint4 w;
-        w.x = q[p][0] | ((unsigned)q[p][1] << 16); w.y = q[p][2] | ((unsigned)q[p][3] << 16);
-        w.z = q[p][4] | ((unsigned)q[p][5] << 16); w.w = q[p][6] | ((unsigned)q[p][7] << 16);
-        *reinterpret_cast<uint4*>(P + p * plane_stride + r * ld_dst + 8 * c) = w;
+        for (int j = 0; j < 8; ++j) split3(x[j], q[0][j], q[1][j], q[2][j]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            uint4 w;
+            w.x = q[p][0] | ((unsigned)q[p][1] << 16); w.y = q[p][2] | ((unsigned)q[p][3] << 16);
+            w.z = q[p][4] | ((unsigned)q[p][5] << 16); w.w = q[p][6] | ((unsigned)q[p][7] << 16);
+            *reinterpret_cast<uint4*>(P + p * plane_stride + r * ld_dst + 8 * c) = w;
+        }
     }
 }
 
@@ -979,8 +995,8 @@ hipError_t launch_gather_planes(const float* src, int64_t n_rows, int64_t cols_l
     if (n_idx > 65535 || (cols_ld & 7)) return hipErrorInvalidValue;         // the plane path has ld % 128 == 0
     const int64_t ld8 = cols_ld >> 3;
     const int threads = ld8 >= 256 ? 256 : 64;
-    hipLaunchKernelGGL(gather_planes_kernel, dim3((unsigned)((ld8 + threads - 1) / threads), (unsigned)n_idx), dim3(threads), 0, s,
-                       src, n_rows, ld_src, idx, idx64, ld8, dst, ld_dst, P, plane_stride);
+    hipLaunchKernelGGL(gather_planes_kernel, dim3((unsigned)((ld8 + threads - 1) / threads), (unsigned)((n_idx + GR - 1) / GR)),
+                       dim3(threads), 0, s, src, n_rows, ld_src, idx, idx64, ld8, n_idx, dst, ld_dst, P, plane_stride);
     return hipGetLastError();
 }
 
