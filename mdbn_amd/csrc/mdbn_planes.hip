@@ -40,6 +40,12 @@ typedef float pf32x16 __attribute__((ext_vector_type(16)));
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PL_PLANE = 8192, PL_STAGE = 6 * PL_PLANE, PL_NSTAGE = 3, PL_LW = 4;
+// PL_COALESCED_SLABS = 1: split-K partial tiles leave through the LDS-parked tile in whole rows (16 bytes per lane, all 8
+// waves) instead of 64 four-byte stores per lane.  Measured on the step (same box, scripts/build_variants.py): 153.7 us
+// against 153.0 / 153.5 with the direct stores -- the tail is not store-issue bound.  Off.
+#ifndef PL_COALESCED_SLABS
+#define PL_COALESCED_SLABS 0
+#endif
 
 __device__ __forceinline__ void pl_glds16(const void* g, unsigned lds_off, char* smem)
 {
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
 
     if (wave >= 4) {
         pl_loader<LA, LB, AP, MS>(g, smem, wave - 4, lane, m0, n0, kbeg, nt);
-        if constexpr (FUSED == 0) return;
+        if constexpr (FUSED == 0 && !(MS == 16 && PL_COALESCED_SLABS)) return;
     } else {
         const int r = lane & 31, h = lane >> 5;
         const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
             pl_consume16<LA, LB, AP>(smem, nt, lane, wm, wn, acc);
             // accumulator (16x16): col = lane & 15, row = 4 * (lane >> 4) + e
             const int c16 = lane & 15, q4 = lane >> 4;
-            if constexpr (FUSED != 0) {
+            if constexpr (FUSED != 0 || PL_COALESCED_SLABS) {
                 float* T = reinterpret_cast<float*>(smem);
                 constexpr int LDT = 128 + 8;
 #pragma unroll
@@ -476,6 +482,19 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
             return;
         }
             }
+    }
+    if constexpr (FUSED == 0 && MS == 16 && PL_COALESCED_SLABS) {
+        // the partial tile goes out in whole rows: 16 bytes per lane, 1 KiB (two 512-byte row pieces) per wave
+        // instruction, from all 8 waves -- instead of 64 four-byte stores per lane that touch 64 bytes of four rows each
+        __syncthreads();
+        const float* T = reinterpret_cast<const float*>(smem);
+        constexpr int NT = 64 * (4 + PL_LW), LDT = 128 + 8;
+        float* C = g.C + (int64_t)ks * g.slab_stride;
+#pragma unroll 4
+        for (int idx = threadIdx.x; idx < 128 * 32; idx += NT) {
+            const int row = idx >> 5, c4 = idx & 31;
+            *reinterpret_cast<pf32x4*>(C + (int64_t)(m0 + row) * g.ldc + n0 + 4 * c4) = *reinterpret_cast<const pf32x4*>(T + row * LDT + 4 * c4);
+        }
     }
     if constexpr (FUSED != 0) {     // all 8 waves work on the parked tile (every DMA has landed: the loaders drained vmcnt)
         __syncthreads();
