@@ -488,6 +488,7 @@ int check_mat(const void* p, int64_t ld, int64_t cols, const char* name)
 hipError_t timed_gemm_planes(int la, int lb, const PlaneGemmArgs& g_in, hipStream_t s)
 {
     PlaneGemmArgs g = g_in;
+    g.stamps = g_stamps;
     g.ms = g_opt_planes_mfma;
     if (g_opt_bf16_inputs) g.ap = 0;
     auto launch = [&]() { return g.bal ? launch_gemm_planes_bal(la, lb, g, s) : launch_gemm_planes(la, lb, g, s); };

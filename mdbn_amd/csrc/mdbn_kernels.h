@@ -118,6 +118,7 @@ struct PlaneGemmArgs {
     int* counters;         // fused == 3: one arrival counter per output tile, zero on entry, zero again on exit
     // balanced launches (launch_gemm_planes_bal): `bal` workgroups share tiles x (K / 32) stages evenly;
     // fused = 0: slabs, one per piece of a tile; fused = 4: result in place, pieces of shared tiles through `scratch`
+    unsigned long long* stamps;   // diagnostic builds only (-DMDBN_STAMP): 8 wall-clock stamps per workgroup (propup)
     int bal;
     int xcd_group;         // balanced: 1 = consecutive workgroups on one XCD, 0 = dealt over the XCDs
     float* scratch;        // fused == 4: 128 KB per workgroup

@@ -46,6 +46,12 @@ constexpr int PL_PLANE = 8192, PL_STAGE = 6 * PL_PLANE, PL_NSTAGE = 3, PL_LW = 4
 #ifndef PL_COALESCED_SLABS
 #define PL_COALESCED_SLABS 0
 #endif
+#ifndef PL_REG_COPY
+#define PL_REG_COPY 0
+#endif
+#ifndef PL_RAMP_SPLIT
+#define PL_RAMP_SPLIT 1      // loader ramp-up: stage 0 alone before the first barrier (pl_loader)
+#endif
 
 __device__ __forceinline__ void pl_glds16(const void* g, unsigned lds_off, char* smem)
 {
@@ -68,9 +74,20 @@ template <int MS> __device__ __forceinline__ int pl_col_swz(int k)
 
 // One loader wave's share of the staging: instructions q = w, w + LW, ... of the 8 * (AP + 3) per stage
 // (8 per plane: 1 KiB each).
+// diagnostic builds (-DMDBN_STAMP): wall-clock (100 MHz) stamps of one propup workgroup's phases, slot per phase
+#ifdef MDBN_STAMP
+#define PL_STAMP(SLOT)                                                                        \
+    do {                                                                                      \
+        if (LA == LAY_K && LB == LAY_MN && AP == 3 && g.stamps && w == 0 && lane == 0)        \
+            g.stamps[(int64_t)blockIdx.x * 16 + (SLOT)] = wall_clock64();                     \
+    } while (0)
+#else
+#define PL_STAMP(SLOT) do {} while (0)
+#endif
 template <int LA, int LB, int AP, int MS>
 __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, int w, int lane, int m0, int n0, int kbeg, int nt)
 {
+    PL_STAMP(0);
     // AP = planes of A (3 | 1); AP = 0 is the bf16-input REPORTING mode: one plane of each operand, one product
     constexpr int NA = AP == 3 ? 3 : 1, NB = AP == 0 ? 1 : 3;
     constexpr int NQ = 8 * (NA + NB), PER = NQ / PL_LW;
@@ -99,6 +116,51 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
             step[j] = 64 * ld;
         }
     }
+#if PL_REG_COPY
+    // Experiment: the loader copies through registers (global_load_dwordx4 -> ds_write_b128, the same per-lane source
+    // addresses and the same LDS images as the DMA) instead of LDS-DMA, whose path moves ~24 bytes per clock and CU
+    // against 64 for loads into registers.  Three register sets during ramp-up (all three stages in flight at once),
+    // one in steady state: the registers are a fourth stage of the ring.
+    {
+        typedef unsigned int lu32x4 __attribute__((ext_vector_type(4)));
+        lu32x4 R0[PER], R1[PER], R2[PER];
+#define PL_LOAD(R) _Pragma("unroll") for (int j = 0; j < PER; ++j) { R[j] = *reinterpret_cast<const lu32x4*>(src[j]); src[j] += step[j]; }
+#define PL_STORE(R, T)                                                                        \
+    do {                                                                                      \
+        const unsigned so = ((T) % PL_NSTAGE) * PL_STAGE + lane * 16;                         \
+        _Pragma("unroll") for (int j = 0; j < PER; ++j) *reinterpret_cast<lu32x4*>(smem + so + dst[j]) = R[j]; \
+    } while (0)
+        PL_LOAD(R0);
+        if (nt > 1) { PL_LOAD(R1); }
+        if (nt > 2) { PL_LOAD(R2); }
+        if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER) : "memory");
+        else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PL_STORE(R0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // stage 0 landed
+        if (nt > 1) {
+            if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PL_STORE(R1, 1);
+        }
+        if (nt > 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PL_STORE(R2, 2); }
+        if (nt > 3) { PL_LOAD(R0); }                 // stage 3 on its way into the registers
+        for (int it = 0; it < nt; ++it) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's LDS stores (stages <= it + 2) are done
+            __builtin_amdgcn_s_barrier();            // every read of stage `it` is done: its slot is free
+            if (it + 3 < nt) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PL_STORE(R0, it + 3);
+                if (it + 4 < nt) { PL_LOAD(R0); }
+            }
+        }
+#undef PL_LOAD
+#undef PL_STORE
+        PL_STAMP(4);
+        return;
+    }
+#endif
 #define PL_ISSUE(T)                                                                           \
     do {                                                                                      \
         const unsigned so = ((T) % PL_NSTAGE) * PL_STAGE;                                     \
@@ -107,13 +169,29 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
             src[j] += step[j];                                                                \
         }                                                                                     \
     } while (0)
+    // Ramp-up: LDS-DMA issue BLOCKS at the rate the path moves data (~58 GB/s per CU: the three stages of the ring take
+    // 2.5 us to issue, scripts/experiments/planes_stamps.py), so a loader that issued all three before waiting for the
+    // first kept the MFMA waves idle for 2.8 us per launch.  Stage 0 alone goes first; the others follow once the MFMA
+    // waves are running on it.
+    PL_STAMP(1);
     PL_ISSUE(0);
+#if PL_RAMP_SPLIT
+    PL_STAMP(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PL_STAMP(3);
+    __builtin_amdgcn_s_barrier();                    // stage 0 landed
     if (nt > 1) { PL_ISSUE(1); }
     if (nt > 2) { PL_ISSUE(2); }
+#else
+    if (nt > 1) { PL_ISSUE(1); }
+    if (nt > 2) { PL_ISSUE(2); }
+    PL_STAMP(2);
     if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER) : "memory");
     else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PL_STAMP(3);
     __builtin_amdgcn_s_barrier();                    // stage 0 landed
+#endif
     for (int it = 0; it < nt; ++it) {
         // stage it + 1 must have landed before the MFMA waves pass barrier `it`; stage it + 2 may still fly
         if (it + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
@@ -121,6 +199,7 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
         __builtin_amdgcn_s_barrier();                // every read of stage `it` is done: its slot is free
         if (it + 3 < nt) { PL_ISSUE(it + 3); }
     }
+    PL_STAMP(4);
 #undef PL_ISSUE
 }
 
@@ -255,13 +334,14 @@ __device__ __forceinline__ void pl_offsets16(int lane, int wm, int wn, int (&off
                   NM = 4 * (AP == 3 ? 6 : (AP == 1 ? 3 : 1));
 
 template <int LA, int LB, int AP>
-__device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int wm, int wn, pf32x4a (&acc)[4][4])
+__device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int wm, int wn, pf32x4a (&acc)[4][4],
+                                             bool open_barrier = true)
 {
     int offA[4][2], offB[4][2];
     pl_offsets16<LA, LB>(lane, wm, wn, offA, offB);
     PL_CONSUME_CONSTS();
     pbf16x8 Alo[3][2], Ahi[3][2], Blo[3][2], Bhi[3][2];
-    __syncthreads();                                 // stage 0 landed
+    if (open_barrier) __syncthreads();               // stage 0 landed
     RD_A(Alo, smem, 0);
     RD_B(Blo, smem, 0);
     for (int it = 0; it < nt; it += 2) {
@@ -331,7 +411,28 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = pf32x4a{0.f, 0.f, 0.f, 0.f};
-            pl_consume16<LA, LB, AP>(smem, nt, lane, wm, wn, acc);
+#ifdef MDBN_STAMP
+#define PL_MSTAMP(SLOT)                                                                       \
+    do {                                                                                      \
+        if (LA == LAY_K && LB == LAY_MN && AP == 3 && g.stamps && wave == 0 && lane == 0)     \
+            g.stamps[(int64_t)blockIdx.x * 16 + (SLOT)] = wall_clock64();                     \
+    } while (0)
+#else
+#define PL_MSTAMP(SLOT) do {} while (0)
+#endif
+            PL_MSTAMP(8);
+            __syncthreads();                         // (the barrier pl_consume16 opens with: stage 0 landed)
+            PL_MSTAMP(9);
+#ifdef MDBN_STAMP
+            if (LA == LAY_K && LB == LAY_MN && AP == 3 && g.stamps && wave == 0 && lane == 0)
+                g.stamps[(int64_t)blockIdx.x * 16 + 13] = clock64();         // shader-clock cycles (s_memtime)
+#endif
+            pl_consume16<LA, LB, AP>(smem, nt, lane, wm, wn, acc, false);
+            PL_MSTAMP(10);
+#ifdef MDBN_STAMP
+            if (LA == LAY_K && LB == LAY_MN && AP == 3 && g.stamps && wave == 0 && lane == 0)
+                g.stamps[(int64_t)blockIdx.x * 16 + 14] = clock64();
+#endif
             // accumulator (16x16): col = lane & 15, row = 4 * (lane >> 4) + e
             const int c16 = lane & 15, q4 = lane >> 4;
             if constexpr (FUSED != 0 || PL_COALESCED_SLABS) {
@@ -353,6 +454,11 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             C[(int64_t)(m0 + wm + 16 * a + 4 * q4 + e) * g.ldc + n0 + wn + 16 * b + c16] = acc[a][b][e];
+                PL_MSTAMP(11);
+#ifdef MDBN_STAMP
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                PL_MSTAMP(12);
                 return;
             }
         } else {
@@ -714,13 +820,11 @@ __device__ __forceinline__ void pl_loader_bal(const PlaneGemmArgs& g, char* smem
         }                                                                                     \
         if (--left == 0 && seg < r.nseg) next_segment();                                      \
     } while (0)
-    PL_ISSUE(0);
+    PL_ISSUE(0);                                     // stage 0 alone first (see pl_loader)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // stage 0 landed
     if (nt > 1) { PL_ISSUE(1); }
     if (nt > 2) { PL_ISSUE(2); }
-    if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER) : "memory");
-    else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                    // stage 0 landed
     for (int it = 0; it < nt; ++it) {
         if (it + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
