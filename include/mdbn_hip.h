@@ -164,6 +164,10 @@ int  mdbn_ctx_destroy(mdbn_ctx *ctx);
  *   every operand (one product instead of six; probabilities off by ~4e-3).
  * "update_overlap": 1 = mdbn_cd_train_step overlaps part of the update with the statistics GEMM
  * on a side stream (default 0: measured slower, see csrc/mdbn_capi.hip). */
+/* Introspection of the balanced launches of the data-parallel mode (no GPU work): segment k of workgroup w when
+ * `workgroups` workgroups share `tiles` x `stages` evenly.  out[6] = {tile, first stage, end stage, segments of this
+ * workgroup, stages of this workgroup, slabs (= sharing workgroups) of that tile}; tile = -1 when k is out of range. */
+int  mdbn_bal_segment(int32_t tiles, int32_t stages, int32_t workgroups, int32_t w, int32_t k, int32_t *out);
 int  mdbn_set_option(mdbn_ctx *ctx, const char *name, int64_t value);
 
 /* Measurement hook (bench.py): while enabled, every GEMM launch (the dominant kernel) is

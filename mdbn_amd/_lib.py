@@ -55,6 +55,7 @@ SIGNATURES = {
     "mdbn_ctx_create": [C.POINTER(_vp), _i32],
     "mdbn_ctx_destroy": [_vp],
     "mdbn_set_option": [_vp, C.c_char_p, _i64],
+    "mdbn_bal_segment": [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)],
     "mdbn_kernel_timing": [_vp, _i32],
     "mdbn_kernel_timing_read": [_vp, C.POINTER(_i64), C.POINTER(C.c_double)],
     "mdbn_kernel_timing_detail": [_vp, _i64, C.POINTER(C.c_double), C.POINTER(C.c_double),

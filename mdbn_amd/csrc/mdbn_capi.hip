@@ -840,6 +840,17 @@ int mdbn_ctx_destroy(mdbn_ctx* ctx)
 int mdbn_debug_set_stamps(void* p) { g_stamps = (unsigned long long*)p; return MDBN_OK; }
 #endif
 
+int mdbn_bal_segment(int32_t tiles, int32_t stages, int32_t workgroups, int32_t w, int32_t k, int32_t* out)
+{
+    REQUIRE(out != nullptr, "out is NULL");
+    int tile, s0, s1, nseg, nt;
+    if (bal_segment_host(tiles, stages, workgroups, w, k, &tile, &s0, &s1, &nseg, &nt) != 0)
+        return fail(MDBN_EINVAL, "bad arguments");
+    out[0] = tile; out[1] = s0; out[2] = s1; out[3] = nseg; out[4] = nt;
+    out[5] = tile >= 0 ? bal_tile_slabs(tile, tiles, stages, workgroups) : 0;
+    return MDBN_OK;
+}
+
 int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
 {
     REQUIRE(ctx != nullptr && name != nullptr, "NULL argument");

@@ -151,6 +151,7 @@ __host__ __device__ inline int bal_tile_slabs(int t, int tiles, int S, int P)
 hipError_t launch_gemm_planes(int la, int lb, const PlaneGemmArgs& g, hipStream_t s);
 hipError_t launch_gemm_planes_bal(int la, int lb, const PlaneGemmArgs& g, hipStream_t s);
 int bal_max_segments(int tiles, int stages, int P);     // slabs a balanced fused == 0 launch needs
+int bal_segment_host(int tiles, int S, int P, int w, int k, int* tile, int* s0, int* s1, int* nseg, int* nt);
 hipError_t launch_split_planes(const float* X, int64_t rows, int64_t ld, unsigned short* P, int64_t plane_stride, hipStream_t s);
 hipError_t launch_gather_planes(const float* src, int64_t n_rows, int64_t cols_ld, int64_t ld_src, const void* idx, int idx64,
                                 int64_t n_idx, float* dst, int64_t ld_dst, unsigned short* P, int64_t plane_stride, hipStream_t s);

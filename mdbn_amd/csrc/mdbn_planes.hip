@@ -326,7 +326,11 @@ __device__ __forceinline__ void pl_offsets16(int lane, int wm, int wn, int (&off
 // returned (PIN), so wait for LDS and meet.
 #define PL_RAW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #ifndef PL_MAIN_BARRIER
+#ifdef MDBN_STAMP
+#define PL_MAIN_BARRIER() do { const long long t_ = clock64(); __syncthreads(); bar_wait += clock64() - t_; } while (0)
+#else
 #define PL_MAIN_BARRIER() __syncthreads()
+#endif
 #endif
 #define PL_CONSUME_CONSTS()                                                                   \
     constexpr int NA = AP == 3 ? 3 : 1, NB = AP == 0 ? 1 : 3;      /* AP = 0: bf16-input reporting mode */ \
@@ -335,8 +339,10 @@ __device__ __forceinline__ void pl_offsets16(int lane, int wm, int wn, int (&off
 
 template <int LA, int LB, int AP>
 __device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int wm, int wn, pf32x4a (&acc)[4][4],
-                                             bool open_barrier = true)
+                                             bool open_barrier = true, long long* bar_wait_out = nullptr)
 {
+    long long bar_wait = 0;       // diagnostic builds: shader cycles spent at the stage barriers
+    (void)bar_wait;
     int offA[4][2], offB[4][2];
     pl_offsets16<LA, LB>(lane, wm, wn, offA, offB);
     PL_CONSUME_CONSTS();
@@ -356,6 +362,7 @@ __device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int w
             PL_STAGE_ODD(base, next, PL_MAIN_BARRIER());
         }
     }
+    if (bar_wait_out) *bar_wait_out = bar_wait;
 }
 
 // FUSED: 0 = split-K slab / plain C store; 1 = activation + sampling epilogue on the parked tile (unsplit
@@ -427,11 +434,18 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
             if (LA == LAY_K && LB == LAY_MN && AP == 3 && g.stamps && wave == 0 && lane == 0)
                 g.stamps[(int64_t)blockIdx.x * 16 + 13] = clock64();         // shader-clock cycles (s_memtime)
 #endif
+#ifdef MDBN_STAMP
+            long long bw = 0;
+            pl_consume16<LA, LB, AP>(smem, nt, lane, wm, wn, acc, false, &bw);
+#else
             pl_consume16<LA, LB, AP>(smem, nt, lane, wm, wn, acc, false);
+#endif
             PL_MSTAMP(10);
 #ifdef MDBN_STAMP
-            if (LA == LAY_K && LB == LAY_MN && AP == 3 && g.stamps && wave == 0 && lane == 0)
+            if (LA == LAY_K && LB == LAY_MN && AP == 3 && g.stamps && wave == 0 && lane == 0) {
                 g.stamps[(int64_t)blockIdx.x * 16 + 14] = clock64();
+                g.stamps[(int64_t)blockIdx.x * 16 + 15] = bw;
+            }
 #endif
             // accumulator (16x16): col = lane & 15, row = 4 * (lane >> 4) + e
             const int c16 = lane & 15, q4 = lane >> 4;
@@ -1003,6 +1017,17 @@ static hipError_t launch_planes_bal_t(const PlaneGemmArgs& g, hipStream_t s)
     if (rem > 0)
         hipLaunchKernelGGL(bal_fixup_kernel, dim3(4 * rem), dim3(256), 0, s, g.scratch, g.C, g.ldc, g.tiles_m, g.tiles_n, g.K / 32, g.bal);
     return hipGetLastError();
+}
+
+// host view of the cut (mdbn_bal_segment: tests check coverage, balance and slab bookkeeping without a GPU)
+int bal_segment_host(int tiles, int S, int P, int w, int k, int* tile, int* s0, int* s1, int* nseg, int* nt)
+{
+    if (tiles < 1 || S < 1 || P < 1 || w < 0 || w >= P) return -1;
+    const BalRange r = bal_range(w, P, tiles, S);
+    *nseg = r.nseg; *nt = r.nt;
+    if (k < 0 || k >= r.nseg) { *tile = *s0 = *s1 = -1; return 0; }
+    bal_segment(r, w, k, S, *tile, *s0, *s1);
+    return 0;
 }
 
 int bal_max_segments(int tiles, int S, int P)

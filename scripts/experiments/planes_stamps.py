@@ -41,6 +41,7 @@ for rep in range(5):
         mfma_wait_stage0=np.median(st[:, 9] - st[:, 8]) / 100.0, loop=np.median(st[:, 10] - st[:, 9]) / 100.0,
         stores_issued=np.median(st[:, 11] - st[:, 10]) / 100.0, stores_acked=np.median(st[:, 12] - st[:, 11]) / 100.0,
         loop_shader_cycles=np.median(st[:, 14] - st[:, 13]), loop_clock_ghz=np.median((st[:, 14] - st[:, 13]) / np.maximum(1, (st[:, 10] - st[:, 9]) * 10.0)),
+        barrier_wait_cycles=np.median(st[:, 15]), barrier_wait_frac=np.median(st[:, 15] / np.maximum(1, st[:, 14] - st[:, 13])),
         first_loop_end=us(st[:, 10].min()), last_loop_end=us(st[:, 10].max()), last_done=us(st[:, 12].max())))
 eng.lib.mdbn_debug_set_stamps(C.c_void_p(0))
 keys = list(rows[0].keys())

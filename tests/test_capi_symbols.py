@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -58,3 +60,43 @@ def test_engine_fails_loudly_without_gpu(built_lib):
         pytest.skip("GPU present")
     with pytest.raises(mdbn_amd.MdbnError):
         mdbn_amd.HipEngine()
+
+
+@pytest.mark.parametrize("tiles,stages,P", [(32, 128, 224), (128, 32, 224), (256, 32, 224), (256, 32, 255), (256, 32, 256),
+                                            (144, 64, 199), (300, 24, 100), (8, 32, 64), (1, 40, 7), (257, 4, 31)])
+def test_balanced_cut_covers_every_stage_once(built_lib, tiles, stages, P):
+    """The cut behind mdbn_cd_args.comm_cus (csrc/mdbn_planes.hip, "BALANCED launches"), checked on the host: the
+    segments of the P workgroups tile the (tile, stage) grid exactly once, a workgroup's stages differ by at most one,
+    whole tiles are swept from stage 0, the workgroups that share a tile are consecutive and as many as the slab count
+    the epilogue is told, and only a tile's LAST sharer holds the piece that ends it (what the fix-up kernel assumes)."""
+    import ctypes as C
+    from mdbn_amd import _lib
+    lib = _lib.load()
+    out = (C.c_int32 * 6)()
+    seen = {}
+    nts = []
+    for w in range(P):
+        _lib.check(lib.mdbn_bal_segment(tiles, stages, P, w, 0, out), "mdbn_bal_segment")
+        nseg, nt = out[3], out[4]
+        nts.append(nt)
+        total = 0
+        for k in range(nseg):
+            _lib.check(lib.mdbn_bal_segment(tiles, stages, P, w, k, out), "mdbn_bal_segment")
+            t, s0, s1, slabs = out[0], out[1], out[2], out[5]
+            assert 0 <= t < tiles and 0 <= s0 < s1 <= stages
+            total += s1 - s0
+            for st in range(s0, s1):
+                assert (t, st) not in seen, "stage covered twice"
+                seen[(t, st)] = (w, s1 == stages, slabs)
+        assert total == nt
+    assert len(seen) == tiles * stages
+    whole = (tiles // P) * P
+    if tiles * stages - whole * stages >= P:
+        assert max(nts) - min(nts) <= 1
+    for t in range(tiles):
+        owners = sorted({seen[(t, st)][0] for st in range(stages)})
+        slabs = seen[(t, 0)][2]
+        assert owners == list(range(owners[0], owners[-1] + 1)) and len(owners) == slabs
+        if t < whole:
+            assert slabs == 1
+        assert seen[(t, stages - 1)][0] == owners[-1]
