@@ -639,6 +639,63 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave drains its stores
             __syncthreads();
             int* flag = reinterpret_cast<int*>(T + 128 * LDT + 32);      // beyond the tile and block_sum's scratch
+            if (g.reduce_all) {
+                // Variant 2: EVERY workgroup of the tile waits until all splitk partials are published, then reduces and
+                // finishes its own 128 / splitk rows of the tile -- the reduction and the activation run on all CUs at
+                // once instead of on the last arriver of each tile.  Needs the tile's workgroups resident together: the
+                // host selects it only when the whole grid fits the device (one workgroup per CU) and nothing is known
+                // to share it; the wait is bounded all the same (2 s), after which the rows are poisoned with NaN.
+                int* cnt = g.counters + 2 * tile;                        // [arrived, departed]
+                if (threadIdx.x == 0) {
+                    __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    const long long t0 = wall_clock64();
+                    int ok = 1;
+                    while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < g.splitk) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (wall_clock64() - t0 > 200000000ll) { ok = 0; break; }
+                    }
+                    *flag = ok;
+                }
+                __syncthreads();
+                const bool ok = *flag != 0;
+                const int bms = 128 / g.splitk, r_first = ks * bms;      // this workgroup's rows of the tile
+#pragma unroll 1
+                for (int idx = threadIdx.x; idx < bms * 32; idx += NT) {
+                    const int lr = idx >> 5, c4 = idx & 31;
+                    const int64_t base = (int64_t)(m0 + r_first + lr) * g.ldc + n0 + 4 * c4;
+                    pf32x4 a = {0.f, 0.f, 0.f, 0.f};
+                    for (int s0 = 0; s0 < g.splitk; s0 += 8) {
+                        pu32x4 v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int sl = s0 + u < g.splitk ? s0 + u : g.splitk - 1;
+                            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((int64_t)sl * g.slab_stride + base) * 4), 0, 16);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (s0 + u < g.splitk) a += __builtin_bit_cast(pf32x4, v[u]);
+                    }
+                    if (!ok) a = pf32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+                    *reinterpret_cast<pf32x4*>(T + lr * LDT + 4 * c4) = a;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {      // the last to leave puts the counters back to zero (nobody can still be waiting)
+                    const int left = __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (left == g.splitk - 1) {
+                        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                const int rows0 = m0 + r_first, slot = (int)blockIdx.x;
+                switch (g.splitk) {
+                    case 2: fused_tile_epilogue<64, 128, NT>(g.epi, T, rows0, n0, slot); break;
+                    case 4: fused_tile_epilogue<32, 128, NT>(g.epi, T, rows0, n0, slot); break;
+                    case 8: fused_tile_epilogue<16, 128, NT>(g.epi, T, rows0, n0, slot); break;
+                    case 16: fused_tile_epilogue<8, 128, NT>(g.epi, T, rows0, n0, slot); break;
+                    default: fused_tile_epilogue<4, 128, NT>(g.epi, T, rows0, n0, slot); break;
+                }
+                return;
+            }
             if (threadIdx.x == 0) {
                 const int ticket = __hip_atomic_fetch_add(g.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *flag = ticket == g.splitk - 1;
