@@ -40,15 +40,6 @@ typedef float pf32x16 __attribute__((ext_vector_type(16)));
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PL_PLANE = 8192, PL_STAGE = 6 * PL_PLANE, PL_NSTAGE = 3, PL_LW = 4;
-// PL_COALESCED_SLABS = 1: split-K partial tiles leave through the LDS-parked tile in whole rows (16 bytes per lane, all 8
-// waves) instead of 64 four-byte stores per lane.  Measured on the step (same box, scripts/build_variants.py): 153.7 us
-// against 153.0 / 153.5 with the direct stores -- the tail is not store-issue bound.  Off.
-#ifndef PL_COALESCED_SLABS
-#define PL_COALESCED_SLABS 0
-#endif
-#ifndef PL_REG_COPY
-#define PL_REG_COPY 0
-#endif
 #ifndef PL_RAMP_SPLIT
 #define PL_RAMP_SPLIT 1      // loader ramp-up: stage 0 alone before the first barrier (pl_loader)
 #endif
@@ -116,51 +107,6 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
             step[j] = 64 * ld;
         }
     }
-#if PL_REG_COPY
-    // Experiment: the loader copies through registers (global_load_dwordx4 -> ds_write_b128, the same per-lane source
-    // addresses and the same LDS images as the DMA) instead of LDS-DMA, whose path moves ~24 bytes per clock and CU
-    // against 64 for loads into registers.  Three register sets during ramp-up (all three stages in flight at once),
-    // one in steady state: the registers are a fourth stage of the ring.
-    {
-        typedef unsigned int lu32x4 __attribute__((ext_vector_type(4)));
-        lu32x4 R0[PER], R1[PER], R2[PER];
-#define PL_LOAD(R) _Pragma("unroll") for (int j = 0; j < PER; ++j) { R[j] = *reinterpret_cast<const lu32x4*>(src[j]); src[j] += step[j]; }
-#define PL_STORE(R, T)                                                                        \
-    do {                                                                                      \
-        const unsigned so = ((T) % PL_NSTAGE) * PL_STAGE + lane * 16;                         \
-        _Pragma("unroll") for (int j = 0; j < PER; ++j) *reinterpret_cast<lu32x4*>(smem + so + dst[j]) = R[j]; \
-    } while (0)
-        PL_LOAD(R0);
-        if (nt > 1) { PL_LOAD(R1); }
-        if (nt > 2) { PL_LOAD(R2); }
-        if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER) : "memory");
-        else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PL_STORE(R0, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                // stage 0 landed
-        if (nt > 1) {
-            if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PL_STORE(R1, 1);
-        }
-        if (nt > 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PL_STORE(R2, 2); }
-        if (nt > 3) { PL_LOAD(R0); }                 // stage 3 on its way into the registers
-        for (int it = 0; it < nt; ++it) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's LDS stores (stages <= it + 2) are done
-            __builtin_amdgcn_s_barrier();            // every read of stage `it` is done: its slot is free
-            if (it + 3 < nt) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                PL_STORE(R0, it + 3);
-                if (it + 4 < nt) { PL_LOAD(R0); }
-            }
-        }
-#undef PL_LOAD
-#undef PL_STORE
-        PL_STAMP(4);
-        return;
-    }
-#endif
 #define PL_ISSUE(T)                                                                           \
     do {                                                                                      \
         const unsigned so = ((T) % PL_NSTAGE) * PL_STAGE;                                     \
@@ -169,6 +115,9 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
             src[j] += step[j];                                                                \
         }                                                                                     \
     } while (0)
+    // (Rejected on the way, same-box builds, profiles/r02z_*_variants.log: a loader that copies through registers
+    // -- global_load_dwordx4 -> ds_write_b128, same images -- 159.4 vs 150.9 us per step; partial tiles stored in whole
+    // rows through the LDS-parked tile 153.7 vs 153.0 / 153.5.)
     // Ramp-up: LDS-DMA issue BLOCKS at the rate the path moves data (~58 GB/s per CU: the three stages of the ring take
     // 2.5 us to issue, scripts/experiments/planes_stamps.py), so a loader that issued all three before waiting for the
     // first kept the MFMA waves idle for 2.8 us per launch.  Stage 0 alone goes first; the others follow once the MFMA
@@ -401,7 +350,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
 
     if (wave >= 4) {
         pl_loader<LA, LB, AP, MS>(g, smem, wave - 4, lane, m0, n0, kbeg, nt);
-        if constexpr (FUSED == 0 && !(MS == 16 && PL_COALESCED_SLABS)) return;
+        if constexpr (FUSED == 0) return;
     } else {
         const int r = lane & 31, h = lane >> 5;
         const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -449,7 +398,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
 #endif
             // accumulator (16x16): col = lane & 15, row = 4 * (lane >> 4) + e
             const int c16 = lane & 15, q4 = lane >> 4;
-            if constexpr (FUSED != 0 || PL_COALESCED_SLABS) {
+            if constexpr (FUSED != 0) {
                 float* T = reinterpret_cast<float*>(smem);
                 constexpr int LDT = 128 + 8;
 #pragma unroll
@@ -602,19 +551,6 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
             return;
         }
             }
-    }
-    if constexpr (FUSED == 0 && MS == 16 && PL_COALESCED_SLABS) {
-        // the partial tile goes out in whole rows: 16 bytes per lane, 1 KiB (two 512-byte row pieces) per wave
-        // instruction, from all 8 waves -- instead of 64 four-byte stores per lane that touch 64 bytes of four rows each
-        __syncthreads();
-        const float* T = reinterpret_cast<const float*>(smem);
-        constexpr int NT = 64 * (4 + PL_LW), LDT = 128 + 8;
-        float* C = g.C + (int64_t)ks * g.slab_stride;
-#pragma unroll 4
-        for (int idx = threadIdx.x; idx < 128 * 32; idx += NT) {
-            const int row = idx >> 5, c4 = idx & 31;
-            *reinterpret_cast<pf32x4*>(C + (int64_t)(m0 + row) * g.ldc + n0 + 4 * c4) = *reinterpret_cast<const pf32x4*>(T + row * LDT + 4 * c4);
-        }
     }
     if constexpr (FUSED != 0) {     // all 8 waves work on the parked tile (every DMA has landed: the loaders drained vmcnt)
         __syncthreads();
