@@ -1346,6 +1346,8 @@ static void launch_act_epilogue_cw(const EpiArgs& e, hipStream_t s)
         case 2: hipLaunchKernelGGL((act_epilogue_kernel<2, CW>), grid, block, 0, s, e); break;
         case 4: hipLaunchKernelGGL((act_epilogue_kernel<4, CW>), grid, block, 0, s, e); break;
         case 8: hipLaunchKernelGGL((act_epilogue_kernel<8, CW>), grid, block, 0, s, e); break;
+        case 7: hipLaunchKernelGGL((act_epilogue_kernel<7, CW>), grid, block, 0, s, e); break;      // balanced propup at P = 224
+        case 6: hipLaunchKernelGGL((act_epilogue_kernel<6, CW>), grid, block, 0, s, e); break;      // ... at P = 192
         default: hipLaunchKernelGGL((act_epilogue_kernel<0, CW>), grid, block, 0, s, e); break;
     }
 }
