@@ -264,3 +264,24 @@ def test_bf16_input_reporting_mode(hip_engine):
     assert 1e-5 < err <= 3e-2, err
     again, _ = eng.cd_step(dx, None, dW, dhb, dvb, True, 1, RngAddr(2, 0, 0, 0, 0))
     assert torch.equal(again, ref_stats) and np.array_equal(eng.last_scratch.P2[:B].cpu().numpy(), good)
+
+
+def test_plane_path_serves_big_layers_only_by_default(built_lib):
+    """Product default (no fixture overrides): whole-tile layers below B * V * H = 2^30 (or V * H < 2^21) stay on the
+    f32-operand kernels, where they are faster (c4's 1024 -> 256: 69 vs 77 us); the headline shape takes the planes."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import mdbn_amd
+    eng = mdbn_amd.HipEngine()
+    try:
+        eng.set_planes_min_work(1 << 30)
+        assert eng.plane_shape(512, 4096, 1024, 4096, 1024)
+        assert eng.plane_shape(512, 2048, 1024, 2048, 1024)
+        assert not eng.plane_shape(512, 1024, 256, 1024, 256)          # c4 L1
+        assert not eng.plane_shape(1024, 1024, 1024, 1024, 1024)       # V * H < 2^21
+        assert not eng.plane_shape(512, 4096, 1000, 4096, 1000)        # not whole tiles
+        assert eng.cd_scratch(512, 1024, 256, True, 1024, 256).planes is None
+        assert eng.cd_scratch(512, 4096, 1024, False, 4096, 1024).planes is not None
+    finally:
+        eng.set_planes_min_work(0)          # what the other tests of this process expect from the library option
