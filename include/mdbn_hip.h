@@ -197,6 +197,12 @@ int  mdbn_padded_ld(int64_t cols, int64_t *ld);
 /* bytes of plane scratch (mdbn_cd_args.planes) for a minibatch of B rows: planes of [v0; nv], [ph; -nh],
  * the hidden and the visible sample */
 int  mdbn_planes_bytes(int64_t B, int64_t ldv, int64_t ldh, int64_t *bytes);
+/* Does the plane path of mdbn_cd_step / mdbn_cd_train_step serve this shape under the CURRENT options (whole 128-row /
+ * 128-column tiles, ldv == V, ldh == H, "gemm_planes" on, B * V * H >= "planes_min_work")?  The one statement of the
+ * rule: a host allocates mdbn_cd_args.planes / W_planes for exactly these shapes.  (Per call the step also needs CD
+ * without a persistent chain, no sample_stats and no GRBM noise.)  W planes handed to a step with W_planes_valid = 0
+ * are re-split on entry whichever path the step takes, so they are valid after ANY step that received them. */
+int  mdbn_planes_eligible(int64_t B, int64_t V, int64_t H, int64_t ldv, int64_t ldh, int32_t *eligible);
 /* exact three-way bf16 split of an f32 matrix [rows, ld] into planes [3][rows][ld] (x = p1 + p2 + p3) */
 int  mdbn_split_planes(mdbn_ctx *ctx, void *stream, const float *x, int64_t rows, int64_t ld, void *planes);
 /* floats in the packed statistics buffer [S (V*ldh) | s_h (ldh) | s_v (ldv) | 4] */

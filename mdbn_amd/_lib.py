@@ -63,6 +63,7 @@ SIGNATURES = {
     "mdbn_workspace_bytes": [_i64, _i64, _i64, C.POINTER(_i64)],
     "mdbn_padded_ld": [_i64, C.POINTER(_i64)],
     "mdbn_planes_bytes": [_i64, _i64, _i64, C.POINTER(_i64)],
+    "mdbn_planes_eligible": [_i64, _i64, _i64, _i64, _i64, C.POINTER(_i32)],
     "mdbn_split_planes": [_vp, _vp, _vp, _i64, _i64, _vp],
     "mdbn_stats_floats": [_i64, _i64, _i64, C.POINTER(_i64)],
     "mdbn_gather_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _i64, _vp, _i64],
@@ -117,6 +118,14 @@ def load():
         fn.restype = C.c_int
     if lib.mdbn_version() != 1:
         raise MdbnError("libmdbn_hip.so version mismatch")
+    buf = C.create_string_buffer(80)
+    lib.mdbn_source_hash(buf, 80)
+    if buf.value.decode() != _build.source_hash():
+        # the mapped code is not what the ctypes layouts above describe (e.g. the path was dlopen'ed before a
+        # rebuild in this process): refuse to run kernels that would be attributed to the wrong sources
+        raise MdbnError("%s is loaded with source hash %s but the sources on disk hash to %s; rebuild "
+                        "(python -m mdbn_amd.build) and restart the process"
+                        % (LIB_PATH, buf.value.decode()[:16], _build.source_hash()[:16]))
     _lib = lib
     return lib
 

@@ -3,7 +3,6 @@
 Staleness is decided by CONTENT, not mtime: the SHA-256 of the sources is compiled into the library
 (``mdbn_source_hash``) and compared with the sources on disk -- a prebuilt .so that travelled to
 another box with rewritten mtimes is still recognised as current or stale."""
-import ctypes
 import hashlib
 import os
 import subprocess
@@ -13,6 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmdbn_hip.so")
 SOURCES = ["mdbn_kernels.hip", "mdbn_planes.hip", "mdbn_capi.hip"]
 HEADERS = ["mdbn_kernels.h", "mdbn_device.h", "philox.h", os.path.join("..", "..", "include", "mdbn_hip.h")]
+HASH_TAG = b"MDBN_SOURCE_HASH_TAG="
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"]
 
 
@@ -31,18 +31,20 @@ def source_hash():
 
 def built_hash(path=LIB):
     """The source hash compiled into an existing library, or None."""
+    # Read from the file's bytes, never through dlopen: glibc keys loaded objects by name, so a handle opened
+    # here would make a later CDLL of a library rebuilt at the same path return the OLD mapping.
     if not os.path.exists(path):
         return None
     try:
-        lib = ctypes.CDLL(path)
-        buf = ctypes.create_string_buffer(80)
-        lib.mdbn_source_hash.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
-        lib.mdbn_source_hash.restype = ctypes.c_int
-        if lib.mdbn_source_hash(buf, 80) != 0:
-            return None
-        return buf.value.decode()
-    except (OSError, AttributeError):
+        with open(path, "rb") as fh:
+            blob = fh.read()
+    except OSError:
         return None
+    at = blob.find(HASH_TAG)
+    if at < 0:
+        return None
+    end = blob.find(b"\0", at)
+    return blob[at + len(HASH_TAG):end].decode("ascii", "replace")
 
 
 def is_stale():

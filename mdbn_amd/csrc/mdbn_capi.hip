@@ -533,17 +533,23 @@ bool plane_plan(const Plan& p, int64_t M, int64_t N, int64_t K)
     return p.x6 && !p.skinny && M % 128 == 0 && N % 128 == 0 && p.kchunk % 32 == 0 && (int64_t)p.kchunk * p.splitk == K;
 }
 
-bool planes_eligible(const mdbn_cd_args* a, bool fused_update)
+// the shape half of the rule (mdbn_planes_eligible: the host allocates plane buffers only for shapes this accepts)
+bool plane_shape_ok(int64_t B, int64_t V, int64_t H, int64_t ldv, int64_t ldh)
 {
-    if (!g_opt_gemm_planes || !a->planes || !a->W_planes) return false;
-    if (a->persistent || a->sample_stats || (a->gauss && a->add_noise)) return false;
-    const int64_t B = a->B, V = a->V, H = a->H;
-    if (B % 128 || V % 128 || H % 128 || a->ldv != V || a->ldh != H || B > 65535) return false;
+    if (!g_opt_gemm_planes) return false;
+    if (B <= 0 || B % 128 || V % 128 || H % 128 || ldv != V || ldh != H || B > 65535) return false;
     if (g_opt_planes_min_work > 0 && (B * V * H < g_opt_planes_min_work || V * H < ((int64_t)1 << 21))) return false;
-    if (a->planes_bytes < 2 * planes_elems(B, V, H) || !aligned16(a->planes) || !aligned16(a->W_planes)) return false;
-    (void)fused_update;
     return plane_plan(plan_forward(B, H, V, H), B, H, V) && plane_plan(plan_forward(B, V, H, V), B, V, H) &&
            plane_plan(plan_stats(V, H, 2 * B, H), V, H, 2 * B);
+}
+
+bool planes_eligible(const mdbn_cd_args* a)
+{
+    if (!a->planes || !a->W_planes) return false;
+    if (a->persistent || a->sample_stats || (a->gauss && a->add_noise)) return false;
+    const int64_t B = a->B, V = a->V, H = a->H;
+    if (!plane_shape_ok(B, V, H, a->ldv, a->ldh)) return false;
+    return a->planes_bytes >= 2 * planes_elems(B, V, H) && aligned16(a->planes) && aligned16(a->W_planes);
 }
 
 // Workgroups of a balanced launch over `units` stage units (0: launch one workgroup per tile job as usual).  Balanced
@@ -655,8 +661,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
         pb.hsp = p; p += B * ldh;
         pb.vsp = p;
     }
-    unsigned short* Wp = reinterpret_cast<unsigned short*>(a->W_planes);
-    if (!a->W_planes_valid) HIP_OK(launch_split_planes(a->W, V, ldh, Wp, V * ldh, s));
+    unsigned short* Wp = reinterpret_cast<unsigned short*>(a->W_planes);    // (split on entry if stale: cd_step_impl)
     // float32 copies nobody on the path reads (the GEMMs take planes, the bias statistics their column partials)
     const bool keep = a->keep_f32 != 0 || a->trace_h != nullptr || a->trace_v != nullptr;
 
@@ -793,10 +798,13 @@ int mdbn_version(void) { return MDBN_VERSION; }
 #ifndef MDBN_SRC_HASH
 #define MDBN_SRC_HASH "unknown"
 #endif
+// tagged copy: build.py finds the hash of an existing .so by scanning the file's bytes for this tag, without
+// dlopen'ing it (a dlopen'ed path stays mapped by name: a rebuild at the same path would not be re-read)
+static const char mdbn_source_hash_tag[] __attribute__((used)) = "MDBN_SOURCE_HASH_TAG=" MDBN_SRC_HASH;
 int mdbn_source_hash(char* buf, size_t n)
 {
     if (!buf || n == 0) return MDBN_EINVAL;
-    snprintf(buf, n, "%s", MDBN_SRC_HASH);
+    snprintf(buf, n, "%s", mdbn_source_hash_tag + sizeof("MDBN_SOURCE_HASH_TAG=") - 1);
     return MDBN_OK;
 }
 
@@ -1023,6 +1031,13 @@ int mdbn_planes_bytes(int64_t B, int64_t ldv, int64_t ldh, int64_t* bytes)
 {
     REQUIRE(bytes != nullptr && B > 0 && ldv > 0 && ldh > 0, "bad arguments");
     *bytes = 2 * planes_elems(B, ldv, ldh);
+    return MDBN_OK;
+}
+
+int mdbn_planes_eligible(int64_t B, int64_t V, int64_t H, int64_t ldv, int64_t ldh, int32_t* eligible)
+{
+    REQUIRE(eligible != nullptr, "eligible is NULL");
+    *eligible = plane_shape_ok(B, V, H, ldv, ldh) ? 1 : 0;
     return MDBN_OK;
 }
 
@@ -1329,7 +1344,13 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
                 "update arguments do not match the step's buffers");
         REQUIRE(upd->W_planes == nullptr || upd->W_planes == a->W_planes, "update and step disagree about W_planes");
     }
-    if (planes_eligible(a, upd != nullptr) && !(upd && g_opt_update_overlap))
+    // Stale W planes are re-split HERE, whichever path the step then takes: a caller that handed planes in may mark them
+    // valid after ANY step (the f32-operand path would otherwise leave stale planes behind a "valid" flag).
+    if (a->W_planes && !a->W_planes_valid) {
+        REQUIRE(aligned16(a->W_planes), "W_planes not 16-byte aligned");
+        HIP_OK(launch_split_planes(a->W, V, ldh, reinterpret_cast<unsigned short*>(a->W_planes), V * ldh, s));
+    }
+    if (planes_eligible(a) && !(upd && g_opt_update_overlap))
         return cd_step_planes(ctx, s, a, upd, ws);
 
     float* v0 = a->V2;

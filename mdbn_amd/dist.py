@@ -121,9 +121,12 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if comm_cus() > 0:
-            # one RCCL channel = one workgroup = one CU: keep the collective within the CUs the step leaves it
-            os.environ.setdefault("NCCL_MAX_NCHANNELS", str(comm_cus()))
+        if os.environ.get("MDBN_RCCL_MAX_CHANNELS"):
+            # opt-in: one RCCL channel = one workgroup = one CU, so capping the channels at `comm_cus` keeps the
+            # collective within the CUs an overlapped step leaves it.  NOT applied by default: the 32 / 224 split was
+            # sized against a stand-in kernel on one GPU and a cap may throttle the 16.8 MB
+            # all-reduce; bench.py --gpus N measures the step at several comm_cus and reports RCCL's own choice.
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ["MDBN_RCCL_MAX_CHANNELS"])
         if backend is None:
             # MDBN_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals (RCCL needs
             # one GPU per rank); the default on GPUs is nccl = RCCL over xGMI

@@ -221,17 +221,22 @@ class HipEngine(object):
     planes_min_work = 1 << 30
 
     def plane_shape(self, B, V, H, ldv, ldh):
-        """Shapes the plane path of the library takes (include/mdbn_hip.h): whole 128-row / column tiles, big enough."""
-        if not (B > 0 and B % 128 == 0 and V % 128 == 0 and H % 128 == 0 and ldv == V and ldh == H and B <= 65535):
-            return False
-        m = int(self.planes_min_work)
-        return m <= 0 or (B * V * H >= m and V * H >= (1 << 21))
+        """Shapes the plane path of the library takes under its CURRENT options: asked of the library itself
+        (mdbn_planes_eligible), so the host's buffers and the library's choice of path cannot disagree."""
+        ok = C.c_int32()
+        _lib.check(self.lib.mdbn_planes_eligible(B, V, H, ldv, ldh, C.byref(ok)), "mdbn_planes_eligible")
+        return bool(ok.value)
 
     def set_planes_min_work(self, work):
-        """Smallest B * V * H the plane path serves (0: every whole-tile shape)."""
+        """Smallest B * V * H the plane path serves (0: every whole-tile shape).  Library options are process-wide:
+        this changes the rule for every engine of the process."""
         self.planes_min_work = int(work)
         self.set_option("planes_min_work", int(work))
-        self._scratch.clear()            # the plane scratch of a shape exists only when the shape is served
+
+    def set_option(self, name, value):
+        """Library tuning knob (mdbn_set_option), e.g. ``set_option('gemm_bk', 32)``; process-wide."""
+        _lib.check(self.lib.mdbn_set_option(self.ctx, name.encode(), int(value)), "mdbn_set_option")
+        self._scratch.clear()            # options decide which scratch a shape needs (planes, slabs)
 
     def w_planes(self, W, create=False):
         """(planes, valid) for a weight matrix: the [3, V, ldh] bf16 planes the library keeps in step with W, and
@@ -420,8 +425,14 @@ class HipEngine(object):
     def _update_args(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats, lr, lambda_1,
                      lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale, phase, ldv):
         V, H = W.shape
+        # Step costs are 0-d views into a block of 1024 floats.  A block is never reused: when it is full a fresh one is
+        # allocated (4 KB per 1024 steps) and the old one lives as long as a caller still holds one of its views, so a
+        # cost kept unread for any number of steps can never show another step's value.
+        if self._cost_slot >= self._cost_ring.numel():
+            self._cost_ring = torch.zeros(1024, dtype=torch.float32, device=self.device)
+            self._cost_slot = 0
         slot = self._cost_slot
-        self._cost_slot = (slot + 1) % self._cost_ring.numel()
+        self._cost_slot = slot + 1
         cost = self._cost_ring[slot]
         u = _lib.UpdateArgs()
         u.W, u.W_speed = W.data_ptr(), W_speed.data_ptr()
@@ -521,10 +532,6 @@ class HipEngine(object):
         _lib.check(fn(self.ctx, self._stream(), self._p(out), rows, cols, out.stride(0), C.byref(r)),
                    "mdbn_rng_*")
         return out
-
-    def set_option(self, name, value):
-        """Library tuning knob (mdbn_set_option), e.g. ``set_option('gemm_bk', 32)``."""
-        _lib.check(self.lib.mdbn_set_option(self.ctx, name.encode(), int(value)), "mdbn_set_option")
 
     def kernel_timing(self, enable):
         """Bracket every GEMM launch with HIP events (measurement only; bench.py)."""

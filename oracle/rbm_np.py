@@ -185,6 +185,11 @@ def cd_chain(s, v0, draws, k, persistent=None):
     return ph_mean, ph_sample, out
 
 
+# largest |u - p| at which a recorded draw has differed from the oracle's own since the last reset (test bookkeeping:
+# the margin left under the allowed tie width)
+FLIP_GAP = {"max": 0.0}
+
+
 def _follow(own, recorded, u, mean, tie, what):
     """Teacher forcing: the recorded sample must equal the oracle's own except where the uniform lies
     within ``tie`` of the probability (a draw that fp32 rounding can push either way)."""
@@ -192,6 +197,7 @@ def _follow(own, recorded, u, mean, tie, what):
     differ = own != recorded
     if differ.any():
         gap = np.abs(np.asarray(u, dtype=np.float64) - mean)[differ]
+        FLIP_GAP["max"] = max(FLIP_GAP["max"], float(gap.max()))
         assert gap.max() < tie, "%s: recorded sample differs from the oracle's away from a tie (|u - p| = %g)" % (what, gap.max())
     return recorded, int(differ.sum())
 

@@ -108,8 +108,25 @@ class ShadowEngine(mdbn_amd.HipEngine):
             st = self.shadow[W.data_ptr()]
             st.W0 = None if W0 is None else W0.cpu().numpy().astype(np.float64)
             S, s_h, s_v, _ = pend
+            S, s_h, s_v = self._reduce_oracle_stats(S, s_h, s_v)
             g = rbm_np.rbm_grad(st, S, s_h, s_v, batch_size, n_rows, weightcost, strict_reference=W0 is not None)
             rbm_np.apply_update(st, g[0], g[1], g[2], lr, lambda_1, lambda_2, momentum)
+        return out
+
+    def _reduce_oracle_stats(self, S, s_h, s_v):
+        """Data-parallel runs: the oracle's per-shard statistics are summed over the ranks in float64 (the device sums
+        its float32 shards through the job's collective), so every rank's shadow applies the update of the GLOBAL
+        minibatch -- `N ranks == the oracle on the global batch`, teacher-forced shard by shard."""
+        import torch.distributed as td
+        if not (td.is_available() and td.is_initialized() and td.get_world_size() > 1):
+            return S, s_h, s_v
+        out = []
+        for a in (S, s_h, s_v):
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+            if td.get_backend() == "nccl":
+                t = t.to(self.device)
+            td.all_reduce(t)
+            out.append(t.cpu().numpy())
         return out
 
     # -- verdicts

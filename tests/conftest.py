@@ -4,12 +4,23 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, HERE):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """GPU sessions leave the measured tolerance margins behind (tests/_margins.py)."""
+    try:
+        import _margins
+        _margins.dump(os.path.join(ROOT, "gpurun_out", "tolerance_margins.json"))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -8,6 +8,7 @@ import torch
 
 from oracle import philox_np, rbm_np
 from oracle.philox_np import PhiloxDraws
+from _margins import check
 
 pytestmark = pytest.mark.gpu
 
@@ -56,8 +57,8 @@ def test_propup_sample(hip_engine, V, H, B):
     pre, mean, sample = [t.cpu().numpy() for t in hip_engine.propup(dx, dW, dhb, rng=addr)]
     s = state64(W, hb, vb, True)
     pre_o, mean_o = rbm_np.propup(s, x.astype(np.float64))
-    assert np.abs(mean - mean_o).max() <= ptol(V)
-    assert np.abs(pre - pre_o).max() <= 4 * ptol(V) * max(1.0, np.abs(pre_o).max())
+    check("propup p [V=%d]" % V, np.abs(mean - mean_o).max(), ptol(V), "prob")
+    check("propup pre / max|pre| [V=%d]" % V, np.abs(pre - pre_o).max() / max(1.0, np.abs(pre_o).max()), 4 * ptol(V))
     u = philox_np.uniform(B, H, 77, 1, 5, 0, 8).astype(np.float64)
     want = (u < mean_o).astype(np.float32)
     bad = sample != want
@@ -82,17 +83,18 @@ def test_propdown_sample(hip_engine, V, H, B, gauss):
     if gauss:
         z = philox_np.normal(B, V, 78, 2, 6, 3, 0)
         pre_o, mean_o, samp_o = rbm_np.sample_v_given_h(s, h64, z)
-        assert np.abs(mean - mean_o).max() <= 4e-6 * max(1.0, np.abs(mean_o).max())
-        assert np.abs(sample - samp_o).max() <= 5e-5
+        check("propdown GRBM nv_mean / max|nv| [H=%d]" % H, np.abs(mean - mean_o).max() / max(1.0, np.abs(mean_o).max()),
+              4e-6, "nv_mean")
+        check("propdown GRBM noisy sample [H=%d]" % H, np.abs(sample - samp_o).max(), 5e-5)
         want_cost = ((rbm_np.sigmoid(mean_o) - x) ** 2).sum()
     else:
         u = philox_np.uniform(B, V, 78, 2, 6, 3, 0).astype(np.float64)
         pre_o, mean_o, samp_o = rbm_np.sample_v_given_h(s, h64, u)
-        assert np.abs(mean - mean_o).max() <= ptol(H)
+        check("propdown RBM p [H=%d]" % H, np.abs(mean - mean_o).max(), ptol(H), "prob")
         bad = sample != samp_o
         assert np.all(np.abs(u - mean_o)[bad] < 1e-6) and bad.sum() <= 2
         want_cost = (x * rbm_np.softplus(-pre_o) + (1 - x) * rbm_np.softplus(pre_o)).sum()
-    assert abs(cost - want_cost) <= 2e-5 * abs(want_cost) + 1e-6
+    check("propdown recon cost rel [H=%d]" % H, abs(cost - want_cost) / (abs(want_cost) + 0.05), 2e-5)
 
 
 @pytest.mark.parametrize("V,H,B", SHAPES)
@@ -104,11 +106,11 @@ def test_free_energy(hip_engine, V, H, B, gauss):
     s = state64(W, hb, vb, gauss)
     F_o = rbm_np.free_energy(s, x.astype(np.float64))
     rel = np.abs(F - F_o) / np.maximum(np.abs(F_o), 1.0)
-    assert rel.max() <= 1e-4, rel.max()            # north-star bound
+    check("free energy rel [V=%d]" % V, rel.max(), 1e-4, "free_energy")            # north-star bound
     # F is a difference of two O(V) terms: fp32-level accuracy is relative to their magnitude
     hid = rbm_np.softplus(x.astype(np.float64) @ s.W + s.hbias).sum(axis=1)
     scale = np.maximum(hid + np.abs(F_o + hid), 1.0)
-    assert (np.abs(F - F_o) / scale).max() <= 2e-6
+    check("free energy / term magnitude [V=%d]" % V, (np.abs(F - F_o) / scale).max(), 2e-6)
 
 
 @pytest.mark.parametrize("V,H,B,k", [(6, 4, 3, 1), (64, 32, 8, 3), (130, 70, 37, 2), (784, 500, 20, 1),
@@ -143,7 +145,7 @@ def test_cd_step_statistics(hip_engine, V, H, B, k, gauss):
     v0 = data[idx].astype(np.float64)
     draws = PhiloxDraws(4242, 1, 9, 0)
     ph_mean, ph_sample, out = rbm_np.cd_chain(s, v0, draws, k)
-    assert np.abs(sc.P2[:B].cpu().numpy() - ph_mean).max() <= ptol(V)
+    check("cd_step ph_mean [V=%d]" % V, np.abs(sc.P2[:B].cpu().numpy() - ph_mean).max(), ptol(V), "prob")
     if k == 1:
         hs = sc.hs.cpu().numpy()
         bad = hs != ph_sample
@@ -153,17 +155,18 @@ def test_cd_step_statistics(hip_engine, V, H, B, k, gauss):
             out = rbm_np.gibbs_hvh(s, hs.astype(np.float64), dv, draws.u(2, B, H))
     pre_nv, nv_mean, nv_sample, pre_nh, nh_mean, nh_sample = out
     scale_v = max(1.0, np.abs(nv_mean).max())
-    assert np.abs(sc.V2[B:].cpu().numpy() - nv_mean).max() <= 4e-6 * scale_v
-    assert np.abs(-sc.P2[B:].cpu().numpy() - nh_mean).max() <= 3 * ptol(V)
+    tag = "[V=%d %s]" % (V, "GRBM" if gauss else "RBM")
+    check("cd_step nv_mean / max|nv| " + tag, np.abs(sc.V2[B:].cpu().numpy() - nv_mean).max() / scale_v, 4e-6, "nv_mean")
+    check("cd_step nh_mean " + tag, np.abs(-sc.P2[B:].cpu().numpy() - nh_mean).max(), 3 * ptol(V), "prob")
     S_o, s_h_o, s_v_o = rbm_np.cd_statistics(v0, ph_mean, nv_mean, nh_mean)
-    assert np.abs(S - S_o).max() <= 1e-5 * max(1.0, np.abs(S_o).max())
-    assert np.abs(s_h - s_h_o).max() <= 1e-5 * max(1.0, np.abs(s_h_o).max())
-    assert np.abs(s_v - s_v_o).max() <= 1e-5 * max(1.0, np.abs(s_v_o).max())
+    check("cd_step S / max|S| " + tag, np.abs(S - S_o).max() / max(1.0, np.abs(S_o).max()), 1e-5, "stats")
+    check("cd_step s_h / max " + tag, np.abs(s_h - s_h_o).max() / max(1.0, np.abs(s_h_o).max()), 1e-5, "stats")
+    check("cd_step s_v / max " + tag, np.abs(s_v - s_v_o).max() / max(1.0, np.abs(s_v_o).max()), 1e-5, "stats")
     if gauss:
         cost_o = ((rbm_np.sigmoid(pre_nv) - v0) ** 2).sum()
     else:
         cost_o = (v0 * rbm_np.softplus(-pre_nv) + (1 - v0) * rbm_np.softplus(pre_nv)).sum()
-    assert abs(cost - cost_o) <= 2e-5 * abs(cost_o)
+    check("cd_step cost rel " + tag, abs(cost - cost_o) / abs(cost_o), 2e-5)
 
 
 @pytest.mark.parametrize("V,H", [(6, 4), (130, 70), (784, 500), (4096, 1024)])
@@ -202,7 +205,8 @@ def test_apply_update(hip_engine, V, H, l1, l2, wc, mu, frozen):
     for name, t in (("W", dW), ("W_speed", dWs), ("hbias", dhb), ("hbias_speed", dhbs), ("vbias", dvb),
                     ("vbias_speed", dvbs)):
         got, want = t.cpu().numpy(), getattr(s, name)
-        assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), name
+        check("apply_update %s / max [V=%d]" % (name, V), np.abs(got - want).max() / max(1.0, np.abs(want).max()), 1e-6,
+              "update")
 
 
 def test_classes_same_host_code_both_engines(hip_engine):
@@ -288,7 +292,7 @@ def test_multi_step_weights_track_oracle(hip_engine):
             forks += 1
     W, W_o = rbm.W.get_value(), st.W
     assert forks <= 1
-    assert np.abs(W - W_o).max() <= 1e-4 * np.abs(W_o).max()
+    check("100-step W drift rel (256->128)", np.abs(W - W_o).max() / np.abs(W_o).max(), 1e-4, "drift100")
 
 
 def test_checkpoint_resume_is_exact_on_device(hip_engine, tmp_path):

@@ -285,3 +285,57 @@ def test_plane_path_serves_big_layers_only_by_default(built_lib):
         assert eng.cd_scratch(512, 4096, 1024, False, 4096, 1024).planes is not None
     finally:
         eng.set_planes_min_work(0)          # what the other tests of this process expect from the library option
+
+
+@pytest.mark.parametrize("gauss", [True, False])
+def test_product_default_c2_statistics_against_forced_oracle(built_lib, gauss):
+    """The path bench.py times, untouched: a fresh HipEngine (keep_f32 = 0: no float32 copies of ph / nh / nv / samples,
+    cost target read through the minibatch index; default planes_min_work) at the c2 shape, mdbn_cd_step.  Its packed
+    statistics S / s_h / s_v and cost are compared with the float64 oracle FOLLOWING the device's chain: without the
+    float32 taps the positive-phase sample (and the visible sample of the Bernoulli RBM) is read from the step's own
+    bf16 sample planes -- the very operands its next GEMM consumed."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import mdbn_amd
+    from mdbn_amd import RngAddr
+    from _margins import check
+    V, H, B, N = 4096, 1024, 512, 2048
+    eng = mdbn_amd.HipEngine()
+    assert eng.keep_f32 is False and eng.trace_chain is False
+    try:
+        eng.set_planes_min_work(1 << 30)                        # the library default (another test's fixture sets 0)
+        rs = np.random.RandomState(5)
+        W = rbm_np.init_W(rs, V, H, np.float32)
+        hb, vb = rs.normal(0, 0.2, H).astype(np.float32), rs.normal(0, 0.2, V).astype(np.float32)
+        data = rs.normal(size=(N, V)).astype(np.float32) if gauss else (rs.uniform(size=(N, V)) < 0.3).astype(np.float32)
+        idx = rs.permutation(N)[:B].astype(np.int64)
+        dW, dhb, dvb, ddata = [eng.to_device(a) for a in (W, hb, vb, data)]
+        stats, sc = eng.cd_step(ddata, idx, dW, dhb, dvb, gauss, 1, RngAddr(31, 2, 11, 0, 0))
+        eng.synchronize()
+        assert sc.planes is not None, "c2 must be on the plane path by default"
+        # sample planes inside mdbn_cd_args.planes (mdbn_planes_bytes): [6 B V | 6 B H | hs: B H | vs: B V] bf16
+        pl = sc.planes
+        hs = ((pl[6 * B * V + 6 * B * H:][:B * H].to(torch.int32) & 0xffff) << 16).view(torch.float32).view(B, H).cpu().numpy()
+        vs = ((pl[6 * B * V + 7 * B * H:][:B * V].to(torch.int32) & 0xffff) << 16).view(torch.float32).view(B, V).cpu().numpy()
+        assert set(np.unique(hs)) <= {0.0, 1.0}
+        st = rbm_np.RBMState(V, H, W=W, hbias=hb, vbias=vb, gauss=gauss)
+        v0 = data[idx].astype(np.float64)
+        th = np.stack([hs, np.zeros_like(hs)])
+        tv = None if gauss else vs[None]
+        rbm_np.FLIP_GAP["max"] = 0.0
+        ph, _, out, flips = rbm_np.cd_chain_forced(st, v0, PhiloxDraws(31, 2, 11, 0), 1, th, tv)
+        S_o, s_h_o, s_v_o = rbm_np.cd_statistics(v0, ph, out[1], out[4])
+        d = stats.cpu().numpy()
+        S, s_h, s_v, cost = d[:V * H].reshape(V, H), d[V * H:V * H + H], d[V * H + H:V * H + H + V], d[V * H + H + V]
+        tag = "product-default c2 %s" % ("GRBM" if gauss else "RBM")
+        check(tag + ": S / max|S|", np.abs(S - S_o).max() / np.abs(S_o).max(), 1e-5, "stats")
+        check(tag + ": s_h / max", np.abs(s_h - s_h_o).max() / max(1.0, np.abs(s_h_o).max()), 1e-5, "stats")
+        check(tag + ": s_v / max", np.abs(s_v - s_v_o).max() / max(1.0, np.abs(s_v_o).max()), 1e-5, "stats")
+        check(tag + ": |u - p| of a flipped draw", rbm_np.FLIP_GAP["max"], 1e-6, "tie")
+        pre_nv = out[0]
+        cost_o = ((rbm_np.sigmoid(pre_nv) - v0) ** 2).sum() if gauss else \
+            (v0 * rbm_np.softplus(-pre_nv) + (1 - v0) * rbm_np.softplus(pre_nv)).sum()
+        check(tag + ": cost rel", abs(cost - cost_o) / abs(cost_o), 2e-5)
+        assert flips <= 3
+    finally:
+        eng.set_planes_min_work(0)
