@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--windows", type=int, default=0, help="timed windows of --steps steps (0 = auto, >= 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--default-only", action="store_true",
+                    help="only the default (product) path: no exact-f32 / bf16-input re-runs, no CPU baseline (profiling runs)")
+    ap.add_argument("--no-sweep", action="store_true", help="N > 1: keep the default data-parallel setting, no comm_cus sweep")
     return ap.parse_args()
 
 
@@ -65,6 +68,10 @@ def launch_ranks(args):
            "--windows", str(args.windows)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
+    if args.default_only:
+        cmd.append("--default-only")
+    if args.no_sweep:
+        cmd.append("--no-sweep")
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for line in proc.stdout:
         sys.stdout.write(line)
@@ -73,17 +80,46 @@ def launch_ranks(args):
 
 
 def pmc_traffic():
-    """HBM bytes per GEMM launch from the newest committed PMC profile (FETCH_SIZE / WRITE_SIZE
-    collected in separate rocprofv3 passes and corrected as MI355X_MICROARCH.md prescribes);
-    counters cannot be read from inside this process, so the figure is the profiled one, or null."""
+    """HBM bytes per CD STEP, summed over every kernel of the step, from the newest committed PMC profile of the
+    default path (FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 passes and corrected as
+    MI355X_MICROARCH.md prescribes; scripts/pmc_traffic.py).  Counters cannot be read from inside this process, so
+    the figure is the profiled one, or null."""
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
         try:
             with open(path) as f:
-                best = (os.path.basename(path), json.load(f)["gemm_avg_bytes_per_launch"])
+                d = json.load(f)
+            if "step_bytes" in d:
+                best = (os.path.basename(path), d["step_bytes"], d.get("step_kernels"))
         except Exception:
             pass
-    return best if best else (None, None)
+    return best if best else (None, None, None)
+
+
+def rccl_summary(path):
+    """What RCCL logged about its channels (NCCL_DEBUG=INFO, INIT subsystem); None when nothing is found."""
+    import re
+    if not path or not os.path.exists(path):
+        return None
+    try:
+        with open(path, errors="replace") as f:
+            text = f.read()
+    except OSError:
+        return None
+    out = {"log_bytes": len(text)}
+    m = re.findall(r"(\d+) coll channels", text)
+    if m:
+        out["coll_channels"] = sorted(set(int(x) for x in m))
+    m = re.findall(r"Channel (\d+)/(\d+)", text)
+    if m:
+        out["channels_listed"] = max(int(b) for _, b in m)
+    m = re.findall(r"(NCCL_[A-Z_]+) set by environment to ([^\s]+)", text)
+    if m:
+        out["env"] = dict(m)
+    keep = [ln.split("NCCL INFO", 1)[-1].strip() for ln in text.splitlines()
+            if ("channels" in ln or "Connected all" in ln or "Init COMPLETE" in ln or "Using network" in ln)]
+    out["lines"] = keep[:12]
+    return out
 
 
 def _blas_threads():
@@ -200,6 +236,13 @@ def main():
     import mdbn_amd
     from mdbn_amd import dist
 
+    rccl_log = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not os.environ.get("MDBN_DIST_BACKEND"):
+        # let RCCL say what it chose (channels = workgroups = CUs its kernels occupy): INIT lines into a per-rank file
+        rccl_log = "/tmp/mdbn_bench_rccl_%d_rank%s.log" % (os.getppid(), os.environ.get("RANK", "0"))
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,ENV")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
     rank, local_rank, world = dist.init_from_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -207,6 +250,7 @@ def main():
     dev = eng.device
     B_global = B_PER_GPU * world
     td = torch.distributed
+    backend_name = td.get_backend() if world > 1 else None
 
     # synthetic z-scored features, identical on every rank
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -243,8 +287,9 @@ def main():
             dt = float(t.item())
         return dt, cost
 
-    def measure(first):
-        """Median of >= 5 windows of exactly --steps steps (short windows: up to 40, ~0.25 s in all)."""
+    def measure(first, min_total=1.0):
+        """Median of >= 5 windows of exactly --steps steps; short windows are repeated until >= 1 s of steps has been
+        timed (at most 2000 windows), so that a sampler beside the run sees the GPU busy."""
         n_win = args.windows
         wins, cost = [], None
         while True:
@@ -254,11 +299,41 @@ def main():
             if n_win:
                 if len(wins) >= n_win:
                     break
-            elif len(wins) >= 5 and (sum(wins) >= 0.25 or len(wins) >= 40):
+            elif len(wins) >= 5 and (sum(wins) >= min_total or len(wins) >= 2000):
                 break
         return wins, cost, first
 
     run(args.warmup, 0)
+    # N > 1: how many CUs to leave to the collective (and which collective) cannot be known from one GPU -- measure it
+    # here: short windows at every setting, all reported in `distributed.sweep`; the fastest is then installed and timed
+    # like the single-GPU run (it is `value`).  Every rank sees the same all-reduced times, so all pick the same setting.
+    sweep = None
+    if world > 1 and not args.no_sweep and getattr(step_fn, "overlap", False):
+        sweep = []
+        settings = [(ov, cus, nat) for nat in (False, True) for ov, cus in ((True, 0), (True, 8), (True, 16), (True, 32),
+                                                                             (True, 64), (False, 0))]
+        nxt0 = args.warmup
+        for ov, cus, nat in settings:
+            if nat and backend_name != "nccl":
+                continue                                  # the C-ABI communicator is RCCL: needs one GPU per rank
+            step_fn.flush()
+            step_fn.overlap, step_fn.comm_cus, step_fn.group.native = ov, (cus if ov else 0), nat
+            try:
+                run(max(5, args.warmup // 2), nxt0)
+                w, _, nxt0 = measure(nxt0, min_total=0.15)
+                step_fn.flush()
+                ms = 1e3 * float(np.median(w)) / args.steps
+                err = None
+            except Exception as exc:                      # a setting that cannot run is reported, not fatal
+                ms, err = None, repr(exc)[:200]
+            sweep.append({"overlap": ov, "comm_cus": cus if ov else 0, "collective": "capi" if nat else "torch",
+                          "ms_per_step": ms, "windows": len(w) if ms else 0, "error": err})
+        ok = [r for r in sweep if r["ms_per_step"]]
+        best = min(ok, key=lambda r: r["ms_per_step"])
+        step_fn.flush()
+        step_fn.overlap, step_fn.comm_cus = best["overlap"], best["comm_cus"]
+        step_fn.group.native = best["collective"] == "capi"
+        run(args.warmup, nxt0)
     wins, cost, nxt = measure(args.warmup)
     elapsed = float(np.median(wins))
     final_cost = float(cost)
@@ -286,26 +361,31 @@ def main():
         allreduce_us = 1e3 * e0.elapsed_time(e1) / 20
 
     # per-kernel durations: HIP events around every GEMM launch on its stream, over K more steps
+    # (the library keeps at most 8192 event pairs: time a bounded number of steps and count THOSE)
+    n_timed_steps = max(1, min(args.steps, 1000))
     eng.kernel_timing(True)
-    run(args.steps, nxt)
+    run(n_timed_steps, nxt)
     torch.cuda.synchronize(dev)
     detail = eng.kernel_timing_detail()
+    n_recorded, _ = eng.kernel_timing_read()
     eng.kernel_timing(False)
-    nxt += args.steps
+    nxt += n_timed_steps
+    if n_recorded != len(detail):
+        raise SystemExit("kernel timing buffer overflowed: %d launches recorded, %d returned" % (n_recorded, len(detail)))
 
     # the same steps with the GEMMs forced onto the exact-f32 MFMA (v_mfma_f32_32x32x2_f32): by default
     # they run on the bf16 matrix pipe with three-way split operands and f32 accumulation (f32 accuracy,
     # DESIGN.md section 3); both numbers are reported
     exact_ms = None
     exact_rows = None
-    if world == 1:
+    if world == 1 and not args.default_only:
         eng.set_option("gemm_bf16x6", 0)
         eng.set_option("gemm_planes", 0)
         run(args.warmup, 0)
-        ewins, _, _ = measure(args.warmup)
+        ewins, _, _ = measure(args.warmup, min_total=0.25)
         exact_ms = 1e3 * float(np.median(ewins)) / args.steps
         eng.kernel_timing(True)
-        run(args.steps, args.warmup)
+        run(n_timed_steps, args.warmup)
         torch.cuda.synchronize(dev)
         exact_rows = kernel_breakdown(eng.kernel_timing_detail())
         eng.kernel_timing(False)
@@ -316,10 +396,10 @@ def main():
     # GEMM instead of six, f32 accumulation) is a REPORTING figure only -- probabilities are then off by ~4e-3, so it
     # is never the parity path and never `value`
     bf16_in = None
-    if world == 1:
+    if world == 1 and not args.default_only:
         eng.set_option("bf16_inputs", 1)
         run(args.warmup, 0)
-        bwins, _, _ = measure(args.warmup)
+        bwins, _, _ = measure(args.warmup, min_total=0.25)
         eng.set_option("bf16_inputs", 0)
         bms = 1e3 * float(np.median(bwins)) / args.steps
         bf16_in = {"ms_per_step": bms, "samples_per_s": B_global * K_GIBBS * 1e3 / bms,
@@ -344,6 +424,7 @@ def main():
 
     if rank != 0:
         return
+    rccl_info = rccl_summary(rccl_log)
     steps_per_s = args.steps / elapsed
     # algorithmic FLOPs: 2*B*V*H per product, 2k+3 products per CD-k step
     flop_per_step = 2.0 * B_PER_GPU * V * H * (2 * K_GIBBS + 3)
@@ -355,7 +436,8 @@ def main():
     on_bf16 = all(((d[3] // 100) % 10) != 0 for d in detail) and n_launch > 0
     peak = MFMA_BF16_PEAK_TFLOPS if on_bf16 else MFMA_F32_PEAK_TFLOPS
     achieved = issued / t_all / 1e12 if n_launch else None
-    traffic_file, traffic = pmc_traffic()
+    traffic_file, traffic, traffic_kernels = pmc_traffic()
+    algorithmic_bytes = 4.0 * B_PER_GPU * V + 16.0 * V * H           # v0 read once, W and W_speed read + written
     worst = min(rows.items(), key=lambda kv: kv[1]["frac_of_pipe"])[0] if rows else None
     out = {
         "metric": "CD-k Gibbs steps/sec (samples/sec), GRBM 4096->1024 CD-1",
@@ -367,7 +449,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "timing": "median of %d windows of %d steps, each bracketed by barrier + synchronize (max over ranks)"
                   % (len(wins), args.steps),
-        "windows_ms_per_step": [1e3 * w / args.steps for w in wins],
+        "windows_ms_per_step": [1e3 * w / args.steps for w in wins[:40]],
+        "windows_ms_per_step_min_max": [1e3 * min(wins) / args.steps, 1e3 * max(wins) / args.steps],
         "arithmetic": "f32 operands split exactly into 3 bf16 pieces; 6 piece products (3 when one operand holds 0/1 "
                       "samples) on v_mfma_f32_16x16x32_bf16 with f32 accumulation, operands pre-split into bf16 planes in "
                       "HBM (error vs float64 = rocBLAS sgemm's); "
@@ -391,7 +474,8 @@ def main():
                         "allreduce_bytes": 4 * (V * H + H + V + 4) if world > 1 else 0,
                         "overlap": bool(getattr(step_fn, "overlap", False)),
                         "comm_cus": int(getattr(step_fn, "comm_cus", 0)),
-                        "collective": step_fn.group.collective if getattr(step_fn, "group", None) is not None else None},
+                        "collective": step_fn.group.collective if getattr(step_fn, "group", None) is not None else None,
+                        "sweep": sweep, "rccl": rccl_info},
         # achieved = FLOPs ISSUED on the matrix pipe the GEMM kernels execute on (six / three bf16 products per
         # algorithmic f32 product), summed over the step's GEMM launches, / their summed HIP-event durations;
         # peak = that pipe's dense peak.  `kernels` has the same per GEMM; the f32-equivalent (algorithmic)
@@ -401,15 +485,20 @@ def main():
                                                                    else "mixed / f32 matrix pipe"),
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": (achieved / peak) if achieved else None,
-                     "traffic": traffic, "traffic_source": traffic_file,
-                     "launches_timed": n_launch, "launches_per_step": n_launch / float(args.steps),
+                     # HBM bytes per CD STEP over ALL kernels of the step (PMC, profiled run of the default path) beside
+                     # the algorithmic bytes of SURVEY 8d; their ratio is the re-read / double-storage overhead
+                     "traffic": traffic, "traffic_unit": "bytes per CD step, all kernels", "traffic_source": traffic_file,
+                     "traffic_by_kernel": traffic_kernels,
+                     "algorithmic_bytes": algorithmic_bytes,
+                     "traffic_over_algorithmic": (traffic / algorithmic_bytes) if traffic else None,
+                     "launches_timed": n_launch, "launches_per_step": n_launch / float(n_timed_steps),
                      "avg_launch_us": 1e6 * t_all / max(n_launch, 1),
-                     "issued_flop_per_step": issued / float(args.steps), "algorithmic_flop_per_step": alg / float(args.steps),
+                     "issued_flop_per_step": issued / float(n_timed_steps), "algorithmic_flop_per_step": alg / float(n_timed_steps),
                      "algorithmic_f32_tflops": alg / t_all / 1e12 if n_launch else None,
                      "furthest_below_roof": worst,
                      "kernels": rows},
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.default_only:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
 

@@ -8,7 +8,7 @@ using the classes without the built library or without a GPU raises ``MdbnError`
 from ._lib import MdbnError
 from .engine import HipEngine, RngAddr, get_engine, set_engine
 from .rng import RandomStreams
-from .shared import SharedArray, shared
+from .shared import HostTable, SharedArray, shared
 from .utils import get_minibatches_idx
 from .mlp import HiddenLayer
 from .rbm import RBM, GRBM, Scalar, function
@@ -16,5 +16,5 @@ from .dbn import DBN
 from . import MDBN, checkpoint, dist, utils
 
 __all__ = ["MdbnError", "HipEngine", "RngAddr", "get_engine", "set_engine", "RandomStreams",
-           "SharedArray", "shared", "get_minibatches_idx", "HiddenLayer", "RBM", "GRBM",
+           "SharedArray", "HostTable", "shared", "get_minibatches_idx", "HiddenLayer", "RBM", "GRBM",
            "Scalar", "function", "DBN", "MDBN", "dist", "checkpoint", "utils"]

@@ -197,14 +197,9 @@ static int g_opt_gemm_bf16x6 = 3;
 // mdbn_set_option("gemm_planes"): the CD step runs on pre-split bf16 planes (mdbn_planes.hip) when the caller
 // supplies the plane buffers and the shape is made of whole 128-row / 128-column tiles (default on)
 static int g_opt_gemm_planes = 1;
-// mdbn_set_option("inkernel_reduce"): split-K forward passes of the plane path sum their partial tiles inside the
-// GEMM launch (last-arriving block per tile) instead of a second, epilogue launch.  Same bits, but MEASURED SLOWER
-// and therefore off by default: at c2 the last arriver of a tile reads 128-512 KB of partials alone while the other
-// CUs idle (propup 54 us against 26 + 7.4 us for GEMM + epilogue launch, propdown 53 against 17.7 + 10.6; step
-// 216.8 against 160.2 us) -- the seam the guides say to cut at these slab sizes (MI355X_MICROARCH.md, splitk-seam).
-// Value 2: every workgroup of a tile waits for all partials and finishes its own rows (no serial tail; whole grid must be
-// resident): bit-identical again, 178.6 against 152.0 us -- the write-through / bypassing-load round trips cost more than
-// the launch boundary they replace.
+// mdbn_set_option("inkernel_reduce"): split-K forward passes of the plane path are reduced INSIDE the GEMM launch by the
+// XCD-local scheme of mdbn_planes.hip (FUSED == 3) instead of a second, epilogue launch: same bits, three launches fewer
+// per CD-1 step.  Single-device steps only (never with comm_cus > 0).
 static int g_opt_inkernel_reduce = 0;
 // mdbn_set_option("planes_mfma"): MFMA shape of the plane GEMMs: 16 = v_mfma_f32_16x16x32_bf16 (default: the chip holds
 // a higher clock on it), 32 = v_mfma_f32_32x32x16_bf16 (the products and order of gemm_bf16x6_kernel: same bits as the
@@ -597,13 +592,14 @@ int run_affine_planes(mdbn_ctx* ctx, int comm_cus, const unsigned short* A, int6
         if ((int64_t)bal_slabs * rows * e.ld * 4 >= (int64_t)1 << 31) bal = 0;  // 32-bit buffer offsets
     }
     const bool fuse = !bal && g_opt_fused_epilogue && g.splitk == 1;
-    const bool reduce_inside = !bal && !fuse && g.splitk > 1 && g_opt_inkernel_reduce && g.tiles_m * g.tiles_n <= kMaxReduceTiles &&
-                               (int64_t)g.splitk * rows * e.ld * 4 < ((int64_t)1 << 31);
-    // variant 2 (every workgroup finishes its own rows): only when the whole grid is resident at once
+    // XCD-local in-launch reduction (mdbn_planes.hip, FUSED == 3): the split-K workgroups of a tile on one XCD, every one
+    // of them resident (one workgroup per CU), each finishing its own rows.  Never beside a collective (bal / comm_cus).
     const int jobs = g.tiles_m * g.tiles_n * g.splitk;
-    const bool reduce_all = reduce_inside && g_opt_inkernel_reduce == 2 && jobs <= ctx->num_cu && 2 * g.tiles_m * g.tiles_n <= kMaxReduceTiles &&
-                            (g.splitk == 2 || g.splitk == 4 || g.splitk == 8 || g.splitk == 16 || g.splitk == 32);
-    const int nb = reduce_all ? jobs : (fuse || reduce_inside) ? g.tiles_m * g.tiles_n : epilogue_blocks(rows, e.ld);
+    const bool reduce_inside = !bal && comm_cus <= 0 && g_opt_comm_cus <= 0 && !fuse && g_opt_inkernel_reduce && g_opt_planes_mfma == 16 &&
+                               (g.splitk == 2 || g.splitk == 4 || g.splitk == 8 || g.splitk == 16 || g.splitk == 32) &&
+                               (g.tiles_m * g.tiles_n) % 8 == 0 && jobs <= ctx->num_cu && 4 * g.tiles_m * g.tiles_n <= kMaxReduceTiles &&
+                               (int64_t)g.splitk * rows * e.ld * 4 < ((int64_t)1 << 31);
+    const int nb = reduce_inside ? jobs : fuse ? g.tiles_m * g.tiles_n : epilogue_blocks(rows, e.ld);
     e.rows = (int)rows; e.cols = (int)Ndim;
     e.cost_partials = nullptr;
     if (want_cost) {
@@ -635,7 +631,6 @@ int run_affine_planes(mdbn_ctx* ctx, int comm_cus, const unsigned short* A, int6
     } else if (reduce_inside) {
         REQUIRE((int64_t)g.splitk * rows * e.ld <= ws.slab_floats, "internal: plane GEMM slabs exceed the workspace");
         g.fused = 3; g.C = ws.slabs; g.ldc = e.ld; g.slab_stride = rows * e.ld; g.counters = ctx->counters;
-        g.reduce_all = reduce_all ? 1 : 0;
         g.epi = e;
         HIP_OK(timed_gemm_planes(LAY_K, lb, g, s));
     } else {
@@ -935,7 +930,7 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
         return MDBN_OK;
     }
     if (strcmp(name, "inkernel_reduce") == 0) {
-        if (value < 0 || value > 2) return fail(MDBN_EINVAL, "inkernel_reduce must be 0, 1 or 2");
+        if (value < 0 || value > 1) return fail(MDBN_EINVAL, "inkernel_reduce must be 0 or 1");
         g_opt_inkernel_reduce = (int)value;
         return MDBN_OK;
     }

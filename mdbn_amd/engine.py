@@ -364,6 +364,23 @@ class HipEngine(object):
             "mdbn_gather_rows")
         return out
 
+    def gather_host_rows(self, host, cols, indexes, out=None):
+        """``host[indexes]`` for a PINNED host matrix [n, ld] (shared.HostTable): the gather kernel reads the rows through
+        their device-accessible host address, over PCIe, on the current stream.  ``out``: a device matrix to fill."""
+        if not host.is_pinned():
+            raise _lib.MdbnError("gather_host_rows needs pinned host memory (torch.Tensor.pin_memory)")
+        idx = self.index_tensor(indexes, host.shape[0])
+        if out is None:
+            out = self.alloc_matrix(idx.numel(), cols, host.stride(0))
+        assert out.shape[0] == idx.numel() and out.shape[1] == cols
+        if idx.numel():
+            _lib.check(self.lib.mdbn_gather_rows(
+                self.ctx, self._stream(), C.c_void_p(host.data_ptr()), host.shape[0], cols, host.stride(0),
+                self._p(idx), int(idx.dtype == torch.int64), idx.numel(), self._p(out), out.stride(0)),
+                "mdbn_gather_rows (pinned host source)")
+        self._keep_alive = (host, idx)           # until the next call: the kernel reads them asynchronously
+        return out
+
     # ------------------------------------------------------------------ CD-k
     def _cd_args(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent, add_noise, stats_slot,
                  sample_stats=False, stats=None, comm_cus=0):

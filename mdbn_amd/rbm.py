@@ -20,7 +20,7 @@ import torch
 from . import dist as _dist
 from .engine import RngAddr, get_engine
 from .rng import RandomStreams
-from .shared import SharedArray, as_tensor, shared
+from .shared import HostTable, SharedArray, as_tensor, shared
 from .utils import get_minibatches_idx
 
 
@@ -105,6 +105,7 @@ class StepFunction(object):
                             and p.persistent is None and p.lambda_1 == 0.0
                             and (p.weightcost == 0.0 or p.W0 is not None))
         self._pending = None                # (work, stats, hyper-parameters, LazyCost) of the last step
+        self._staging = None                # double-buffered minibatch staging of a host-resident table
         self._n_calls = 0
         # statistics buffers of the data-parallel path are OWNED by this step function: a deferred
         # update reads them a whole call later, so another step function of the same shape (two
@@ -131,6 +132,78 @@ class StepFunction(object):
         if self.input_fn is not None:
             return self.input_fn()
         return self.engine.as_matrix(self.train_set_x)
+
+    # -- host-resident training table (shared.HostTable): the minibatch rows are gathered over PCIe into one of two
+    #    device staging buffers, on a side stream, ONE MINIBATCH AHEAD of the step that consumes them
+    def _host_table(self):
+        return self.train_set_x if (self.input_fn is None and isinstance(self.train_set_x, HostTable)) else None
+
+    @staticmethod
+    def _same_indexes(a, b):
+        if a is b:
+            return True
+        if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor):
+            # the prefetched view is kept alive, so its storage cannot have been reused: equal address, length and
+            # type mean the same (never mutated) index list
+            return a.data_ptr() == b.data_ptr() and a.numel() == b.numel() and a.dtype == b.dtype and a.device == b.device
+        if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
+            return False
+        a, b = numpy.asarray(a), numpy.asarray(b)
+        return a.shape == b.shape and bool((a == b).all())
+
+    def _stage_rows(self, table, indexes, slot, stream):
+        """Enqueue the gather of ``table[shard of indexes]`` into staging buffer ``slot`` on ``stream``."""
+        eng = self.engine
+        n_global = len(table) if indexes is None else len(indexes)
+        lo, hi = (0, n_global) if self.group is None else self.group.shard(n_global)
+        idx = torch.arange(lo, hi, dtype=torch.int64, device=eng.device) if indexes is None else \
+            eng.index_tensor(indexes, len(table))[lo:hi]
+        st = self._staging
+        buf = st["bufs"][slot]
+        if buf is None or buf.shape[0] != hi - lo:
+            buf = st["bufs"][slot] = eng.alloc_matrix(hi - lo, table.cols, table.host.stride(0))
+        with torch.cuda.stream(stream):
+            if st["free"][slot] is not None:
+                stream.wait_event(st["free"][slot])          # the step that last read this buffer has been enqueued
+            idx.record_stream(stream)
+            buf.record_stream(stream)
+            if hi > lo:
+                table.rows(idx, out=buf)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return buf, ev, n_global, lo, hi
+
+    def prefetch(self, indexes):
+        """Tell the step function which minibatch comes NEXT (the trainers know the epoch's order): with a host-resident
+        table its rows start moving now, beside the current step.  A no-op for device-resident data."""
+        table = self._host_table()
+        if table is None or not torch.cuda.is_available():
+            return
+        if self._staging is None:
+            self._staging = {"bufs": [None, None], "free": [None, None], "slot": 0, "side": torch.cuda.Stream(self.engine.device),
+                             "next": None}
+        st = self._staging
+        slot = 1 - st["slot"]
+        st["side"].wait_stream(torch.cuda.current_stream(self.engine.device))       # (index tensors made on the compute stream)
+        st["next"] = (indexes, slot) + self._stage_rows(table, indexes, slot, st["side"])
+
+    def _staged(self, table, indexes):
+        """Device rows of this step's minibatch shard: the prefetched buffer if ``indexes`` is what was announced,
+        else gathered now."""
+        if self._staging is None:
+            self._staging = {"bufs": [None, None], "free": [None, None], "slot": 0, "side": torch.cuda.Stream(self.engine.device),
+                             "next": None}
+        st = self._staging
+        cur = torch.cuda.current_stream(self.engine.device)
+        nxt, st["next"] = st["next"], None
+        if nxt is not None and self._same_indexes(nxt[0], indexes):
+            _, slot, buf, ev, n_global, lo, hi = nxt
+            cur.wait_event(ev)
+        else:
+            slot = 1 - st["slot"]
+            buf, ev, n_global, lo, hi = self._stage_rows(table, indexes, slot, cur)
+        st["slot"] = slot
+        return buf, slot, n_global, lo, hi
 
     # -- deferred half of an overlapped step: speeds (and cost) from the reduced statistics
     def _complete_pending(self):
@@ -163,20 +236,27 @@ class StepFunction(object):
             lr = p.lr
         if isinstance(lr, Scalar):
             raise TypeError("step function needs lr= (learning rate is a symbolic input)")
-        data = self._data()
-        n_global = data.shape[0] if indexes is None else len(indexes)
-        batch_size = p.batch_size if (p.batch_size is not None and not p.symbolic_grad) else n_global
+        table = self._host_table()
         distributed = self.group is not None and self.group.world_size > 1
-
-        # data-parallel shard of the minibatch: contiguous rows [lo, hi) of `indexes`
-        lo, hi = 0, n_global
-        if self.group is not None:
-            lo, hi = self.group.shard(n_global)
-        if indexes is None:
-            idx = None if (lo == 0 and hi == data.shape[0]) else \
-                torch.arange(lo, hi, dtype=torch.int64, device=data.device)
+        staged_slot = None
+        if table is not None and torch.cuda.is_available():
+            # host-resident table: the shard's rows arrive in a staging buffer (prefetched one step ahead when the
+            # trainer announced them); the step then runs on that buffer with the identity index
+            data, staged_slot, n_global, lo, hi = self._staged(table, indexes)
+            idx = None
         else:
-            idx = eng.index_tensor(indexes, data.shape[0])[lo:hi]
+            data = self._data()
+            n_global = data.shape[0] if indexes is None else len(indexes)
+            # data-parallel shard of the minibatch: contiguous rows [lo, hi) of `indexes`
+            lo, hi = 0, n_global
+            if self.group is not None:
+                lo, hi = self.group.shard(n_global)
+            if indexes is None:
+                idx = None if (lo == 0 and hi == data.shape[0]) else \
+                    torch.arange(lo, hi, dtype=torch.int64, device=data.device)
+            else:
+                idx = eng.index_tensor(indexes, data.shape[0])[lo:hi]
+        batch_size = p.batch_size if (p.batch_size is not None and not p.symbolic_grad) else n_global
         step = rbm._take_step()
         persistent = None
         if p.persistent is not None:

@@ -36,5 +36,14 @@ for k in sorted(set(fetch) | set(write)):
     if "gemm" in k:
         gemm_bytes += (f + w) * n; gemm_n += n
 out["gemm_avg_bytes_per_launch"] = gemm_bytes / max(gemm_n, 1)
+# bytes per CD STEP over every kernel of the step: the profiled command runs ONE path (bench.py --default-only), whose
+# steps each launch the plane gather once; kernels launched less than once per two steps (one-off splits, the free-energy
+# check) are not part of the step
+steps = out["per_launch_bytes"].get("mdbn::gather_planes_kernel", {}).get("launches", 0)
+if steps:
+    out["steps_profiled"] = steps
+    out["step_kernels"] = {k: {"launches_per_step": v["launches"] / steps, "bytes_per_step": v["total"] * v["launches"] / steps}
+                           for k, v in out["per_launch_bytes"].items() if v["launches"] * 2 >= steps}
+    out["step_bytes"] = sum(v["bytes_per_step"] for v in out["step_kernels"].values())
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

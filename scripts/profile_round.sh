@@ -7,7 +7,8 @@ TAG=${1:-r02x}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline"
+# the profiled command runs the DEFAULT path only (no exact-f32 / bf16-input re-runs): per-step sums are then plain sums
+CMD="python3 bench.py --steps 100 --warmup 10 --windows 5 --default-only"
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- $CMD > $OUT/${TAG}_stats.log 2>&1 || exit 2
 STATS=$(find $OUT/${TAG}_stats -name '*kernel_stats.csv' | head -1)

@@ -12,6 +12,7 @@ from oracle import rbm_np
 from oracle.philox_np import PhiloxDraws
 
 pytestmark = pytest.mark.gpu
+INKERNEL_REDUCE_DEFAULT = 0          # the library default of mdbn_set_option("inkernel_reduce")
 
 
 def planes_to_f32(P):
@@ -68,6 +69,8 @@ def _run_steps(eng, gauss, planes, V, H, B, k, steps=3, seed=0, mfma=16):
     import mdbn_amd
     eng.set_option("gemm_planes", int(planes))
     eng.set_option("planes_mfma", mfma)
+    if planes:          # a shape the library does not serve on planes would compare the f32-operand path with itself
+        assert eng.plane_shape(B, V, H, V, H), "test shape is not on the plane path: %r" % ((B, V, H),)
     keep, eng.keep_f32 = eng.keep_f32, bool(seed & 1)        # the product default (no float32 copies) on even seeds
     rs = np.random.RandomState(seed)
     N = 4 * B
@@ -88,7 +91,7 @@ def _run_steps(eng, gauss, planes, V, H, B, k, steps=3, seed=0, mfma=16):
 
 
 @pytest.mark.parametrize("gauss,V,H,B,k", [(True, 4096, 1024, 512, 1), (False, 1024, 512, 512, 1), (True, 1024, 768, 256, 3),
-                                           (False, 2048, 1024, 384, 2)])
+                                           (False, 2048, 1024, 256, 2)])
 def test_plane_step_equals_f32_operand_step_bit_for_bit(hip_engine, gauss, V, H, B, k):
     """With the 32x32x16 MFMA shape the plane GEMMs issue the products of gemm_bf16x6_kernel in the same order and follow
     the same split-K plans: every parameter, speed and sample equals the f32-operand step bit for bit.  The default
@@ -178,33 +181,32 @@ def test_plane_step_against_oracle_teacher_forced(hip_engine):
 
 @pytest.mark.parametrize("gauss,V,H,B,k", [(True, 4096, 1024, 512, 1), (False, 1024, 512, 512, 2), (True, 2048, 1024, 128, 1)])
 def test_in_launch_splitk_reduction_is_bitwise_and_repeatable(hip_engine, gauss, V, H, B, k):
-    """Split-K forward passes reduced inside the GEMM launch (last-arriving block per tile, write-through slabs,
-    agent-scope ticket) against the two-launch path (slabs + act_epilogue_kernel): identical parameters, speeds and
-    samples bit for bit -- the partials are summed in slab order whichever block arrives last -- and identical from
-    run to run (a race between publishing and reducing would show as run-to-run differences)."""
+    """Split-K forward passes reduced inside the GEMM launch by the XCD-local scheme (a tile's split-K workgroups on one
+    XCD, plain slab stores that stay in its L2, every workgroup finishes its own rows) against the two-launch path
+    (slabs + act_epilogue_kernel): identical parameters, speeds and samples bit for bit -- the partials are summed in
+    slab order -- and identical from run to run (a race between publishing and reducing, or a stale line, would show as
+    run-to-run differences or as the NaN poison of a failed placement check)."""
     eng = hip_engine
     runs = []
-    # 1: the last arriver of a tile finishes it; 2: every workgroup of the tile waits for all partials and finishes its own
-    # rows (same slab order, same activation code: same bits); 0: the two-launch path
-    for inside in (1, 0, 2, 1, 2, 2):
+    for inside in (1, 0, 1, 1):
         eng.set_option("inkernel_reduce", inside)
         try:
             out, _, _, _ = _run_steps(eng, gauss, True, V, H, B, k, steps=12, seed=3)
         finally:
-            eng.set_option("inkernel_reduce", 0)         # the library default (measured slower, DESIGN.md)
+            eng.set_option("inkernel_reduce", INKERNEL_REDUCE_DEFAULT)
         runs.append(out)
+    assert np.isfinite(runs[0]["costs"]).all() and np.isfinite(runs[0]["W"]).all()
     for other in runs[1:]:
         for key in runs[0]:
             if key == "costs":
                 np.testing.assert_allclose(runs[0][key], other[key], rtol=2e-6)
             else:
                 assert np.array_equal(runs[0][key], other[key]), key
-    assert np.array_equal(runs[0]["costs"], runs[3]["costs"])                    # variant 1 repeats
-    assert np.array_equal(runs[2]["costs"], runs[4]["costs"]) and np.array_equal(runs[2]["costs"], runs[5]["costs"])    # variant 2 repeats
+    assert np.array_equal(runs[0]["costs"], runs[2]["costs"]) and np.array_equal(runs[0]["costs"], runs[3]["costs"])
 
 
 @pytest.mark.parametrize("gauss,V,H,B,k,comm_cus", [(True, 4096, 1024, 512, 1, 32), (True, 4096, 1024, 512, 1, 1),
-                                                    (False, 1024, 512, 512, 2, 192), (True, 2048, 1024, 384, 1, 100),
+                                                    (False, 1024, 512, 512, 2, 192), (True, 2048, 1024, 256, 1, 100),
                                                     # forward passes with MORE tiles than workgroups: whole tiles + shared rest
                                                     (False, 1024, 2048, 2048, 1, 32), (True, 2048, 2048, 1152, 1, 57)])
 def test_balanced_launches_match_and_repeat(hip_engine, gauss, V, H, B, k, comm_cus):
