@@ -122,6 +122,36 @@ def rccl_summary(path):
     return out
 
 
+def capi_collective_alive(group, eng, td, deadline_s=20.0):
+    """One small all-reduce through the library's own RCCL communicator (mdbn_comm_init_rank / mdbn_allreduce_stats), on
+    its side stream, polled against a deadline -- so that a communicator that cannot be built or never completes keeps
+    the C-ABI collective out of the sweep instead of hanging the benchmark.  All ranks take the same decision."""
+    import torch
+    ok = 1
+    try:
+        group.native = True
+        buf = torch.ones(1024, dtype=torch.float32, device=eng.device)
+        work = group.all_reduce_sum_async(buf, eng)
+        ev = getattr(work, "event", None)
+        t0 = time.perf_counter()
+        while ev is not None and not ev.query():
+            if time.perf_counter() - t0 > deadline_s:
+                ok = 0
+                break
+            time.sleep(0.01)
+        if ok:
+            work.wait()
+            torch.cuda.synchronize(eng.device)
+            ok = int(abs(float(buf[0]) - group.world_size) < 0.5)
+    except Exception:
+        ok = 0
+    finally:
+        group.native = False
+    flag = torch.tensor([ok], dtype=torch.int32, device=eng.device)
+    td.all_reduce(flag, op=td.ReduceOp.MIN)              # through torch's own communicator
+    return bool(int(flag.item()))
+
+
 def _blas_threads():
     try:
         from threadpoolctl import threadpool_info
@@ -313,9 +343,17 @@ def main():
         settings = [(ov, cus, nat) for nat in (False, True) for ov, cus in ((True, 0), (True, 8), (True, 16), (True, 32),
                                                                              (True, 64), (False, 0))]
         nxt0 = args.warmup
+        capi_ok = None
         for ov, cus, nat in settings:
             if nat and backend_name != "nccl":
                 continue                                  # the C-ABI communicator is RCCL: needs one GPU per rank
+            if nat and capi_ok is None:
+                capi_ok = capi_collective_alive(step_fn.group, eng, td)
+                if not capi_ok:
+                    sweep.append({"collective": "capi", "error": "mdbn_allreduce_stats did not complete a small all-reduce "
+                                                                   "within 20 s on every rank: C-ABI collective not swept"})
+            if nat and not capi_ok:
+                continue
             step_fn.flush()
             step_fn.overlap, step_fn.comm_cus, step_fn.group.native = ov, (cus if ov else 0), nat
             try:
@@ -328,7 +366,7 @@ def main():
                 ms, err = None, repr(exc)[:200]
             sweep.append({"overlap": ov, "comm_cus": cus if ov else 0, "collective": "capi" if nat else "torch",
                           "ms_per_step": ms, "windows": len(w) if ms else 0, "error": err})
-        ok = [r for r in sweep if r["ms_per_step"]]
+        ok = [r for r in sweep if r.get("ms_per_step")]
         best = min(ok, key=lambda r: r["ms_per_step"])
         step_fn.flush()
         step_fn.overlap, step_fn.comm_cus = best["overlap"], best["comm_cus"]
@@ -408,6 +446,41 @@ def main():
                            "because BASELINE configs[1] names bf16/fp32"}
         run(args.warmup, 0)               # back on the f32-grade path before the parity check below
 
+    # The boundary also takes a HOST-resident training table (mdbn_amd.shared(x, resident="host"): pinned memory, each
+    # minibatch's rows gathered over PCIe into a double buffer one step ahead of the step that uses them).  Its rate is
+    # reported beside `value`, never as `value` (the metric is defined with inputs resident in HBM).
+    pcie = None
+    if world == 1 and not args.default_only:
+        try:
+            host_x = mdbn_amd.shared(data.cpu().numpy(), engine=eng, resident="host")
+            rbm_h = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123), engine=eng)
+            _, up_h = rbm_h.get_cost_updates(lr=LR, k=K_GIBBS, lambda_1=LAMBDA_1, lambda_2=LAMBDA_2, batch_size=B_global)
+            fn_h = mdbn_amd.function(up_h, host_x)
+
+            def run_host(n, announce):
+                for it in range(n):
+                    mb = it % n_mb
+                    fn_h(indexes=perm[mb * B_global:(mb + 1) * B_global], momentum=0.0)
+                    if announce:
+                        nb = (it + 1) % n_mb
+                        fn_h.prefetch(perm[nb * B_global:(nb + 1) * B_global])
+            res = {}
+            for announce in (True, False):
+                run_host(args.warmup, announce)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                run_host(10 * args.steps, announce)
+                torch.cuda.synchronize(dev)
+                res[announce] = 1e3 * (time.perf_counter() - t0) / (10 * args.steps)
+            pcie = {"ms_per_step": res[True], "samples_per_s": B_global * 1e3 / res[True],
+                    "ms_per_step_without_prefetch": res[False],
+                    "minibatch_bytes": 4 * B_global * V,
+                    "note": "training table in pinned host memory; minibatch rows gathered over PCIe by the library's gather "
+                            "kernel on a side stream, one step ahead (StepFunction.prefetch); NOT `value`"}
+            del host_x, fn_h, rbm_h
+        except Exception as exc:                    # reporting figure only
+            pcie = {"error": repr(exc)[:200]}
+
     # free-energy parity of the trained model vs the float64 oracle (north star: <= 1e-4 rel)
     fe_rel = fe_rel_elem = None
     if rank == 0:
@@ -459,6 +532,7 @@ def main():
         "exact_f32_mfma_value": (B_global * K_GIBBS * 1e3 / exact_ms) if exact_ms else None,
         "exact_f32_mfma_kernels": exact_rows,
         "bf16_input_mode": bf16_in,
+        "pcie_inclusive_host_resident_table": pcie,
         "config": {"workload": "GRBM 4096->1024 CD-1, batch %d per GPU, fp32, N(0,1) rows resident in HBM "
                                "(BASELINE configs[%d])" % (B_PER_GPU, 1 if world == 1 else 2),
                    "global_batch": B_global, "k": K_GIBBS, "n_data": N_DATA,

@@ -158,9 +158,8 @@ int  mdbn_ctx_destroy(mdbn_ctx *ctx);
  *   block streams alone, "skinny_max_macs" (default 32 Mi) size limit above 64 rows.
  * "gemm_planes" (default 1): use the bf16 plane path of mdbn_cd_args when its buffers are given and the
  *   shape qualifies.  "planes_mfma" (default 16): its MFMA shape, 16 = v_mfma_f32_16x16x32_bf16, 32 =
- *   v_mfma_f32_32x32x16_bf16 (bit-identical to the f32-operand path).  "inkernel_reduce" (default 0): sum the
- *   split-K partials of its forward passes inside the GEMM launch (1: the last arriver of a tile finishes it, 2: every
- *   workgroup finishes its own rows; same bits; both measured slower).  "planes_min_work" (default
+ *   v_mfma_f32_32x32x16_bf16 (bit-identical to the f32-operand path). 
+ *  "planes_min_work" (default
  *   2^30): smallest B * V * H the plane path serves (smaller whole-tile layers are faster on the f32-operand kernels).
  * "comm_cus" (default 0): CUs left to a collective that runs beside the step when mdbn_cd_args.comm_cus is 0 (see
  *   there); "bal_blocks" (tests): the number of workgroups of a balanced launch itself.

@@ -17,7 +17,6 @@ using namespace mdbn;
 struct mdbn_ctx {
     int device;
     int num_cu;
-    int* counters = nullptr;   // arrival counters of the in-launch split-K reduction (mdbn_planes.hip), kept at zero
     void* comm = nullptr;      // ncclComm_t of mdbn_comm_init_rank (RCCL), or NULL
     int comm_ranks = 0;
     // side stream + events for mdbn_cd_train_step (memory-bound update work overlapped with the
@@ -197,10 +196,6 @@ static int g_opt_gemm_bf16x6 = 3;
 // mdbn_set_option("gemm_planes"): the CD step runs on pre-split bf16 planes (mdbn_planes.hip) when the caller
 // supplies the plane buffers and the shape is made of whole 128-row / 128-column tiles (default on)
 static int g_opt_gemm_planes = 1;
-// mdbn_set_option("inkernel_reduce"): split-K forward passes of the plane path are reduced INSIDE the GEMM launch by the
-// XCD-local scheme of mdbn_planes.hip (FUSED == 3) instead of a second, epilogue launch: same bits, three launches fewer
-// per CD-1 step.  Single-device steps only (never with comm_cus > 0).
-static int g_opt_inkernel_reduce = 0;
 // mdbn_set_option("planes_mfma"): MFMA shape of the plane GEMMs: 16 = v_mfma_f32_16x16x32_bf16 (default: the chip holds
 // a higher clock on it), 32 = v_mfma_f32_32x32x16_bf16 (the products and order of gemm_bf16x6_kernel: same bits as the
 // f32-operand path)
@@ -214,7 +209,6 @@ static int g_opt_bf16_inputs = 0;
 // cheaper GEMMs gain (c4's second layer 1024 -> 256 at B = 512: 69.2 us on the f32-operand kernels, 77.3 on planes;
 // 2048 -> 1024: 122.9 vs 118.9; c2: 158.7 vs 150).  0: every whole-tile shape (tests).
 static int64_t g_opt_planes_min_work = (int64_t)1 << 30;
-constexpr int kMaxReduceTiles = 1024;
 // mdbn_set_option("comm_cus"): CUs left to a collective that runs beside the step (data-parallel mode).  > 0: the plane
 // GEMMs of mdbn_cd_step are launched BALANCED on (CUs - comm_cus) workgroups (mdbn_planes.hip, "BALANCED launches"):
 // a collective's kernel takes whole CUs, and a one-workgroup-per-CU grid on fewer CUs needs a second round (measured:
@@ -592,14 +586,7 @@ int run_affine_planes(mdbn_ctx* ctx, int comm_cus, const unsigned short* A, int6
         if ((int64_t)bal_slabs * rows * e.ld * 4 >= (int64_t)1 << 31) bal = 0;  // 32-bit buffer offsets
     }
     const bool fuse = !bal && g_opt_fused_epilogue && g.splitk == 1;
-    // XCD-local in-launch reduction (mdbn_planes.hip, FUSED == 3): the split-K workgroups of a tile on one XCD, every one
-    // of them resident (one workgroup per CU), each finishing its own rows.  Never beside a collective (bal / comm_cus).
-    const int jobs = g.tiles_m * g.tiles_n * g.splitk;
-    const bool reduce_inside = !bal && comm_cus <= 0 && g_opt_comm_cus <= 0 && !fuse && g_opt_inkernel_reduce && g_opt_planes_mfma == 16 &&
-                               (g.splitk == 2 || g.splitk == 4 || g.splitk == 8 || g.splitk == 16 || g.splitk == 32) &&
-                               (g.tiles_m * g.tiles_n) % 8 == 0 && jobs <= ctx->num_cu && 4 * g.tiles_m * g.tiles_n <= kMaxReduceTiles &&
-                               (int64_t)g.splitk * rows * e.ld * 4 < ((int64_t)1 << 31);
-    const int nb = reduce_inside ? jobs : fuse ? g.tiles_m * g.tiles_n : epilogue_blocks(rows, e.ld);
+    const int nb = fuse ? g.tiles_m * g.tiles_n : epilogue_blocks(rows, e.ld);
     e.rows = (int)rows; e.cols = (int)Ndim;
     e.cost_partials = nullptr;
     if (want_cost) {
@@ -627,11 +614,6 @@ int run_affine_planes(mdbn_ctx* ctx, int comm_cus, const unsigned short* A, int6
         HIP_OK(launch_act_epilogue(e, s));
     } else if (fuse) {
         g.fused = 1; g.epi = e;
-        HIP_OK(timed_gemm_planes(LAY_K, lb, g, s));
-    } else if (reduce_inside) {
-        REQUIRE((int64_t)g.splitk * rows * e.ld <= ws.slab_floats, "internal: plane GEMM slabs exceed the workspace");
-        g.fused = 3; g.C = ws.slabs; g.ldc = e.ld; g.slab_stride = rows * e.ld; g.counters = ctx->counters;
-        g.epi = e;
         HIP_OK(timed_gemm_planes(LAY_K, lb, g, s));
     } else {
         REQUIRE((int64_t)g.splitk * rows * e.ld <= ws.slab_floats, "internal: plane GEMM slabs exceed the workspace");
@@ -823,11 +805,6 @@ int mdbn_ctx_create(mdbn_ctx** out, int device)
     mdbn_ctx* c = new mdbn_ctx;
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
-    {   // context creation is the one place that allocates: 1024 tile counters, zeroed once (every launch leaves them zero)
-        HIP_OK(hipSetDevice(device));
-        HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->counters), kMaxReduceTiles * sizeof(int)));
-        HIP_OK(hipMemset(c->counters, 0, kMaxReduceTiles * sizeof(int)));
-    }
     *out = c;
     return MDBN_OK;
 }
@@ -840,7 +817,6 @@ int mdbn_ctx_destroy(mdbn_ctx* ctx)
         if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
         if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
         if (ctx->side) (void)hipStreamDestroy(ctx->side);
-        if (ctx->counters) (void)hipFree(ctx->counters);
         if (ctx->comm) (void)mdbn_comm_destroy(ctx);
     }
     delete ctx;
@@ -927,11 +903,6 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "planes_mfma") == 0) {
         if (value != 16 && value != 32) return fail(MDBN_EINVAL, "planes_mfma must be 16 or 32");
         g_opt_planes_mfma = (int)value;
-        return MDBN_OK;
-    }
-    if (strcmp(name, "inkernel_reduce") == 0) {
-        if (value < 0 || value > 1) return fail(MDBN_EINVAL, "inkernel_reduce must be 0 or 1");
-        g_opt_inkernel_reduce = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "bal_blocks") == 0) {

@@ -115,7 +115,6 @@ struct PlaneGemmArgs {
                            // | 3 split-K with the reduction INSIDE the launch: every block publishes its partial tile
                            //   (write-through stores), the last block to arrive at a tile sums the partials in slab
                            //   order and runs the activation epilogue (epi)
-    int* counters;         // fused == 3: 16 bytes per output tile [64-bit arrival word, departures, -], zero on entry and on exit
     // balanced launches (launch_gemm_planes_bal): `bal` workgroups share tiles x (K / 32) stages evenly;
     // fused = 0: slabs, one per piece of a tile; fused = 4: result in place, pieces of shared tiles through `scratch`
     unsigned long long* stamps;   // diagnostic builds only (-DMDBN_STAMP): 8 wall-clock stamps per workgroup (propup)

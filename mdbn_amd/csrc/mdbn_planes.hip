@@ -316,29 +316,15 @@ __device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int w
 
 // FUSED: 0 = split-K slab / plain C store; 1 = activation + sampling epilogue on the parked tile (unsplit
 // forward pass); 2 = statistics GEMM: finalize units on the ramp-up, parameter update (+ W planes) on the
-// parked tile; 3 = split-K forward pass reduced INSIDE the launch (below).  AP = planes of A (3, or 1 for 0/1 samples).
+// parked tile.  AP = planes of A (3, or 1 for 0/1 samples).
 //
-// FUSED == 3, the XCD-LOCAL in-launch split-K reduction (round 3; option "inkernel_reduce").  The split-K workgroups of
-// one output tile are placed on ONE XCD (hardware deals workgroup ids round-robin over the 8 XCDs: ids b and b + 8 share
-// one), so their partial tiles never have to leave that XCD's L2:
-//   * every workgroup parks its 128x128 partial in LDS and publishes the rows it does NOT own to slab ks with PLAIN
-//     16-byte stores (they stop in the XCD's L2; no write-through, no release fence, no L2 write-back);
-//   * every storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, lane 0 adds its arrival
-//     AND its XCC id to the tile's arrival word in ONE relaxed agent-scope atomic;
-//   * lane 0 polls the counter (relaxed sc1 loads, s_sleep) until all splitk workgroups of the tile have arrived -- the
-//     grid is one workgroup per CU, every workgroup of it resident, so they arrive within the skew of one launch; the
-//     wait is bounded (2 s) -- then the workgroup reduces ITS OWN 128 / splitk rows: the other workgroups' partials come
-//     from their slabs with sc1 loads (L1 bypassed, served by the shared L2), its own from LDS, summed in SLAB ORDER
-//     (the order of act_epilogue_kernel: bit-identical to the two-launch path), and runs the activation epilogue on
-//     them.  Reduction and activation thus run on all CUs at once, and nothing crosses an XCD.
-// Correctness must not rest on a placement the programming model does not promise: the arrival word proves, in every
-// launch, that all workgroups of the tile ran on one XCD; if it ever shows two (or the wait times out) the tile's rows are
-// poisoned with NaN instead of being computed from possibly stale lines.  The last workgroup to leave a tile puts its
-// counters back to zero.  Data-parallel steps (comm_cus > 0: a collective shares the chip) never take this path: their
-// balanced launches wait for nobody.
-// (Rounds 1-2 built the placement-independent forms -- write-through slabs + last-arriver reduce, and write-through
-// slabs + every workgroup reduces its rows -- both bit-identical and both SLOWER than GEMM + epilogue launch: 222.9 /
-// 178.6 against 152.0 us per step, DESIGN.md.  They are gone from the tree.)
+// (An in-launch split-K reduction of the forward passes was built three times and measured slower each time -- rounds 1-2:
+// write-through slabs + last-arriver reduce / every workgroup reduces its rows, 222.9 / 178.6 against 152.0 us per step;
+// round 3: the XCD-local form, a tile's split-K workgroups on one XCD, plain slab stores that stay in its L2, a per-launch
+// placement proof, 173.9 against 154.7 us (profiles/r03a_xcd_local_inkernel_reduce_ab.log; the code is in the history at
+// commit 23f393d).  The chain store -> drain -> arrive -> poll -> load -> activate costs what the kernel boundary costs,
+// and the activation then runs on 512 threads per CU instead of 2048.  No kernel of this library waits for another
+// workgroup.)
 template <int LA, int LB, int AP, int FUSED, int MS>
 __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemmArgs g)
 {
@@ -349,12 +335,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
     const int qq = nwg >> 3, rem = nwg & 7;
     const int w = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + slot;
     const int tiles = g.tiles_m * g.tiles_n;
-    int ks = w / tiles, t = w - ks * tiles;
-    if constexpr (FUSED == 3) {      // all split-K workgroups of a tile on ONE XCD (host: tiles % 8 == 0)
-        const int tpx = tiles >> 3;
-        t = xcd * tpx + slot / g.splitk;
-        ks = slot - (slot / g.splitk) * g.splitk;
-    }
+    const int ks = w / tiles, t = w - ks * tiles;
     int tm, tn;
     if (g.tiles_m <= g.tiles_n) { tn = t / g.tiles_m; tm = t - tn * g.tiles_m; }
     else { tm = t / g.tiles_n; tn = t - tm * g.tiles_n; }
@@ -571,87 +552,9 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
     if constexpr (FUSED != 0) {     // all 8 waves work on the parked tile (every DMA has landed: the loaders drained vmcnt)
         __syncthreads();
         float* T = reinterpret_cast<float*>(smem);
-        constexpr int NT = 64 * (4 + PL_LW), LDT = 128 + 8;
+        constexpr int NT = 64 * (4 + PL_LW);
         if constexpr (FUSED == 1) fused_tile_epilogue<128, 128, NT>(g.epi, T, m0, n0);
-        else if constexpr (FUSED == 2) fused_update_epilogue<128, 128, NT>(g.upd, T, m0, n0);
-        else {
-            typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
-            // one descriptor for all slabs (< 4 GiB: checked by the host); offsets are bytes
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                g.C, 0, (int)((int64_t)g.splitk * g.slab_stride * 4), 0x00020000);
-            const int tile = t;
-            const int bms = 128 / g.splitk, r_first = ks * bms;          // this workgroup's rows of the tile
-            // 1. publish the rows other workgroups will reduce: parked tile -> slab ks, 16 bytes per lane, PLAIN stores
-#pragma unroll 4
-            for (int idx = threadIdx.x; idx < 128 * 32; idx += NT) {
-                const int row = idx >> 5, c4 = idx & 31;
-                if (row >= r_first && row < r_first + bms) continue;      // own rows stay in LDS
-                const pu32x4 v = *reinterpret_cast<const pu32x4*>(T + row * LDT + 4 * c4);
-                const int off = (int)(((int64_t)ks * g.slab_stride + (int64_t)(m0 + row) * g.ldc + n0 + 4 * c4) * 4);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave: its stores have reached L2
-            __syncthreads();
-            int* flag = reinterpret_cast<int*>(T + 128 * LDT + 32);      // beyond the tile and block_sum's scratch
-            // per tile 16 bytes: one 64-bit arrival word (bits 0-7: arrivals; bits 8 + 6 x .. 13 + 6 x: arrivals from XCC x --
-            // count and placement travel in ONE atomic, so no ordering between two atomics is assumed), one departure count
-            unsigned long long* arr = reinterpret_cast<unsigned long long*>(g.counters + 4 * tile);
-            int* dep = g.counters + 4 * tile + 2;
-            if (threadIdx.x == 0) {
-                const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;     // HW_REG_XCC_ID[3:0]
-                __hip_atomic_fetch_add(arr, 1ull + (1ull << (8 + 6 * xcc)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const long long t0 = wall_clock64();
-                int ok = 1;
-                unsigned long long seen;
-                while (((seen = __hip_atomic_load(arr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffull) < (unsigned)g.splitk) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (wall_clock64() - t0 > 200000000ll) { ok = 0; break; }       // 2 s at 100 MHz
-                }
-                // all splitk arrivals came from THIS XCC: one L2 holds every partial of the tile
-                if ((seen >> 8) != ((unsigned long long)g.splitk << (6 * xcc))) ok = 0;
-                *flag = ok;
-            }
-            __syncthreads();
-            const bool ok = *flag != 0;
-            // 2. own rows: the others' partials by sc1 loads (L1 bypassed), ours from LDS, summed in slab order
-#pragma unroll 1
-            for (int idx = threadIdx.x; idx < bms * 32; idx += NT) {
-                const int lr = idx >> 5, c4 = idx & 31;
-                const int64_t base = (int64_t)(m0 + r_first + lr) * g.ldc + n0 + 4 * c4;
-                const pf32x4 own = *reinterpret_cast<const pf32x4*>(T + (r_first + lr) * LDT + 4 * c4);
-                pf32x4 a = {0.f, 0.f, 0.f, 0.f};
-                for (int s0 = 0; s0 < g.splitk; s0 += 8) {
-                    pu32x4 v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        int sl = s0 + u < g.splitk ? s0 + u : g.splitk - 1;        // clamped: value unused
-                        if (sl == ks) sl = ks ? 0 : (g.splitk > 1 ? 1 : 0);        // own slab is not published: value unused
-                        v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((int64_t)sl * g.slab_stride + base) * 4), 0, 16);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (s0 + u < g.splitk) a += (s0 + u == ks) ? own : __builtin_bit_cast(pf32x4, v[u]);
-                }
-                if (!ok) a = pf32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-                *reinterpret_cast<pf32x4*>(T + lr * LDT + 4 * c4) = a;      // rows 0 .. bms-1 (== the own rows when ks == 0)
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {      // the last to leave puts the counters back to zero (nobody can still be waiting)
-                const int left = __hip_atomic_fetch_add(dep, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (left == g.splitk - 1) {
-                    __hip_atomic_store(arr, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(dep, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            const int rows0 = m0 + r_first, cslot = (int)blockIdx.x;
-            switch (g.splitk) {
-                case 2: fused_tile_epilogue<64, 128, NT>(g.epi, T, rows0, n0, cslot); break;
-                case 4: fused_tile_epilogue<32, 128, NT>(g.epi, T, rows0, n0, cslot); break;
-                case 8: fused_tile_epilogue<16, 128, NT>(g.epi, T, rows0, n0, cslot); break;
-                case 16: fused_tile_epilogue<8, 128, NT>(g.epi, T, rows0, n0, cslot); break;
-                default: fused_tile_epilogue<4, 128, NT>(g.epi, T, rows0, n0, cslot); break;
-            }
-        }
+        else fused_update_epilogue<128, 128, NT>(g.upd, T, m0, n0);
     }
 }
 
@@ -683,14 +586,10 @@ hipError_t launch_gemm_planes(int la, int lb, const PlaneGemmArgs& g, hipStream_
         g.tiles_n != g.N / 128 || (g.lda & 7) || (g.ldb & 7) || ((g.fused == 1 || g.fused == 2) && g.splitk != 1) ||
         (g.ap != 0 && g.ap != 1 && g.ap != 3))
         return hipErrorInvalidValue;
-    if (g.fused == 3 && (g.counters == nullptr || (int64_t)g.splitk * g.slab_stride * 4 >= (int64_t)1 << 31 ||
-                         (g.tiles_m * g.tiles_n) % 8 != 0 || g.splitk < 2 || 128 % g.splitk != 0 || g.splitk > 32))
-        return hipErrorInvalidValue;
 #define PL_CASE(LAV, LBV, APV, FV) \
     if (la == LAV && lb == LBV && g.ap == APV && g.fused == FV) return launch_planes_t<LAV, LBV, APV, FV>(g, s)
     // propup: x planes (ROW) x W planes (COL)
     PL_CASE(LAY_K, LAY_MN, 3, 0); PL_CASE(LAY_K, LAY_MN, 3, 1); PL_CASE(LAY_K, LAY_MN, 1, 0); PL_CASE(LAY_K, LAY_MN, 1, 1);
-    PL_CASE(LAY_K, LAY_MN, 3, 3); PL_CASE(LAY_K, LAY_MN, 1, 3); PL_CASE(LAY_K, LAY_K, 3, 3); PL_CASE(LAY_K, LAY_K, 1, 3);
     // propdown: h planes (ROW) x W planes (ROW)
     PL_CASE(LAY_K, LAY_K, 3, 0); PL_CASE(LAY_K, LAY_K, 3, 1); PL_CASE(LAY_K, LAY_K, 1, 0); PL_CASE(LAY_K, LAY_K, 1, 1);
     // statistics: [v0; nv]^T planes (COL) x [ph; -nh] planes (COL)

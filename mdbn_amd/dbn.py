@@ -20,7 +20,7 @@ from .engine import get_engine
 from .mlp import HiddenLayer
 from .rbm import GRBM, RBM, Scalar, function
 from .rng import RandomStreams
-from .shared import SharedArray, shared
+from .shared import HostTable, SharedArray, shared
 from .utils import get_minibatches_idx
 
 
@@ -117,8 +117,24 @@ class DBN(object):
         '''[n_ins] + stacked layer sizes (dbn.py:206-212)'''
         return [self.n_ins] + self.stacked_layers_sizes
 
+    host_chunk_rows = 16384     # rows of a host-resident table forwarded per chunk (dbn.py:146's activations)
+
     def _forward(self, input, layer):
-        """Device activations of ``sigmoid_layers[layer]`` for a data matrix."""
+        """Device activations of ``sigmoid_layers[layer]`` for a data matrix.  A host-resident table (HostTable) is
+        streamed through in row chunks -- the pinned rows are gathered over PCIe, forwarded, and only the (narrower)
+        activations stay on the device -- so the table itself is never uploaded whole."""
+        if isinstance(input, HostTable) and input._mirror is None and len(input) > self.host_chunk_rows:
+            import torch
+            out = None
+            for lo in range(0, len(input), self.host_chunk_rows):
+                hi = min(len(input), lo + self.host_chunk_rows)
+                act = self.sigmoid_layers[layer].output.eval(input.rows(slice(lo, hi)))
+                if out is None:
+                    out = self.engine.alloc_matrix(len(input), act.shape[1], act.stride(0))
+                out[lo:hi].copy_(act)
+            return out
+        if isinstance(input, HostTable) and input._mirror is None:
+            return self.sigmoid_layers[layer].output.eval(input.rows(slice(0, len(input))))
         return self.sigmoid_layers[layer].output.eval(getattr(input, "tensor", input))
 
     def get_output(self, input, layer=-1):
@@ -140,7 +156,7 @@ class DBN(object):
             # their parameters (SharedArray.set_value, e.g. weights loaded into an existing DBN) and
             # in-place writes to the data tensor
             version = tuple((r._n_updates, r.W.version, r.hbias.version) for r in self.rbm_layers[:i]) + \
-                (train_set_x.version, getattr(train_set_x.tensor, "_version", 0))
+                (train_set_x.version, 0 if isinstance(train_set_x, HostTable) else getattr(train_set_x.tensor, "_version", 0))
             hit = self._lower_cache.get(i)
             if self.cache_lower and hit is not None and hit[0] == version and hit[1] is train_set_x:
                 return hit[2]
@@ -200,6 +216,7 @@ class DBN(object):
         bernoulli = not isinstance(self.rbm_layers[i], GRBM)
         stop = _Patience(epoch_budget, n_batches)
         self._print('Validation frequency: %d' % stop.every)
+        announce = getattr(step_fn, "prefetch", None)      # step functions are duck-typed: fn(indexes=, momentum=, lr=)
         records = []
         for epoch in range(1, epoch_budget + 1):
             # Gaussian layer: no momentum at all; Bernoulli layers 0.6, 0.9 from the sixth epoch (dbn.py:430-433,452-453)
@@ -209,6 +226,8 @@ class DBN(object):
             bounds = numpy.cumsum([0] + [len(b) for b in batches])
             for mb in range(len(batches)):
                 cost = step_fn(indexes=order[bounds[mb]:bounds[mb + 1]], momentum=momentum, lr=lr)
+                if announce is not None and mb + 1 < len(batches):     # a host-resident table starts moving the next rows now
+                    announce(order[bounds[mb + 1]:bounds[mb + 2]])
                 it = (epoch - 1) * n_batches + mb
                 if stop.due(it):
                     cost = float(cost)
@@ -232,10 +251,11 @@ class DBN(object):
         """mean F(validation) - mean F(first n_val training rows), both seen through the layers below
         layer i (dbn.py:476-501)."""
         n_val = held_out.shape[0]
+        first = data.rows(slice(0, n_val)) if isinstance(data, HostTable) else data.tensor[:n_val]
         if i == 0:
-            below_train, below_val = data, held_out
+            below_train, below_val = first, held_out
         else:
-            below_train = self._forward(data.tensor[:n_val], i - 1)
+            below_train = self._forward(first, i - 1)
             below_val = self._forward(held_out, i - 1)
         f_train, f_val = energy_fn(below_train, below_val)
         return float(f_val.mean() - f_train.mean())

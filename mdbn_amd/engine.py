@@ -413,10 +413,13 @@ class HipEngine(object):
         a.stats = stats.data_ptr()
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         a.rng = rng.c()
-        if sc.planes is not None:
-            wp, valid = self.w_planes(W, create=True)
-            a.planes, a.planes_bytes = sc.planes.data_ptr(), sc.planes.numel() * 2
+        # W's planes travel with W whenever they exist (the update that follows rewrites them, and a step that finds them
+        # stale re-splits them, whichever path it takes); the plane scratch only for shapes the library serves on planes
+        wp, valid = self.w_planes(W, create=sc.planes is not None)
+        if wp is not None:
             a.W_planes, a.W_planes_valid = wp.data_ptr(), int(valid)
+        if sc.planes is not None:
+            a.planes, a.planes_bytes = sc.planes.data_ptr(), sc.planes.numel() * 2
         a.comm_cus = int(comm_cus)
         if self.trace_chain:
             if sc.trace_h is None or sc.trace_h.shape[0] != k + 1:

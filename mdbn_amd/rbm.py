@@ -151,20 +151,25 @@ class StepFunction(object):
         a, b = numpy.asarray(a), numpy.asarray(b)
         return a.shape == b.shape and bool((a == b).all())
 
+    def _staging_state(self):
+        if self._staging is None:
+            self._staging = {"bufs": [None, None], "slot": 0, "side": torch.cuda.Stream(self.engine.device), "next": None,
+                             "before_step": None}
+        return self._staging
+
     def _stage_rows(self, table, indexes, slot, stream):
-        """Enqueue the gather of ``table[shard of indexes]`` into staging buffer ``slot`` on ``stream``."""
+        """Enqueue the gather of ``table[shard of indexes]`` into staging buffer ``slot`` on ``stream`` (the index list is
+        brought to the device on that stream too)."""
         eng = self.engine
         n_global = len(table) if indexes is None else len(indexes)
         lo, hi = (0, n_global) if self.group is None else self.group.shard(n_global)
-        idx = torch.arange(lo, hi, dtype=torch.int64, device=eng.device) if indexes is None else \
-            eng.index_tensor(indexes, len(table))[lo:hi]
-        st = self._staging
+        st = self._staging_state()
         buf = st["bufs"][slot]
         if buf is None or buf.shape[0] != hi - lo:
             buf = st["bufs"][slot] = eng.alloc_matrix(hi - lo, table.cols, table.host.stride(0))
         with torch.cuda.stream(stream):
-            if st["free"][slot] is not None:
-                stream.wait_event(st["free"][slot])          # the step that last read this buffer has been enqueued
+            idx = torch.arange(lo, hi, dtype=torch.int64, device=eng.device) if indexes is None else \
+                eng.index_tensor(indexes, len(table))[lo:hi]
             idx.record_stream(stream)
             buf.record_stream(stream)
             if hi > lo:
@@ -175,31 +180,36 @@ class StepFunction(object):
 
     def prefetch(self, indexes):
         """Tell the step function which minibatch comes NEXT (the trainers know the epoch's order): with a host-resident
-        table its rows start moving now, beside the current step.  A no-op for device-resident data."""
+        table its rows start moving now, on a side stream, beside the step that was just enqueued.  A no-op for
+        device-resident data."""
         table = self._host_table()
         if table is None or not torch.cuda.is_available():
             return
-        if self._staging is None:
-            self._staging = {"bufs": [None, None], "free": [None, None], "slot": 0, "side": torch.cuda.Stream(self.engine.device),
-                             "next": None}
-        st = self._staging
+        st = self._staging_state()
         slot = 1 - st["slot"]
-        st["side"].wait_stream(torch.cuda.current_stream(self.engine.device))       # (index tensors made on the compute stream)
+        # The side stream waits for everything enqueued BEFORE the current step -- the index tensors of the epoch and
+        # the step that last read this buffer (two steps ago) -- but not for the current step itself.
+        if st["before_step"] is not None:
+            st["side"].wait_event(st["before_step"])
+        else:
+            st["side"].wait_stream(torch.cuda.current_stream(self.engine.device))
         st["next"] = (indexes, slot) + self._stage_rows(table, indexes, slot, st["side"])
 
     def _staged(self, table, indexes):
         """Device rows of this step's minibatch shard: the prefetched buffer if ``indexes`` is what was announced,
         else gathered now."""
-        if self._staging is None:
-            self._staging = {"bufs": [None, None], "free": [None, None], "slot": 0, "side": torch.cuda.Stream(self.engine.device),
-                             "next": None}
-        st = self._staging
+        st = self._staging_state()
         cur = torch.cuda.current_stream(self.engine.device)
+        ev0 = torch.cuda.Event()
+        ev0.record(cur)                      # "before this step": what a prefetch issued after it may rely on
+        st["before_step"] = ev0
         nxt, st["next"] = st["next"], None
         if nxt is not None and self._same_indexes(nxt[0], indexes):
             _, slot, buf, ev, n_global, lo, hi = nxt
             cur.wait_event(ev)
         else:
+            if nxt is not None:
+                cur.wait_event(nxt[3])       # an abandoned prefetch still owns its buffer until it has finished
             slot = 1 - st["slot"]
             buf, ev, n_global, lo, hi = self._stage_rows(table, indexes, slot, cur)
         st["slot"] = slot
@@ -616,13 +626,14 @@ class RBM(object):
                 momentum = final_momentum
             _, minibatches = get_minibatches_idx(n_train_data, batch_size, shuffle=True, rng=shuffle_rng)
             dev_idx = self.engine.index_tensor(numpy.concatenate(minibatches))
-            # costs are views into the engine's ring of device scalars: fold them into a
-            # running sum well before the ring wraps, without synchronising
+            # costs are 0-d device scalars: fold them into a running sum every 256 steps, without synchronising
             costs, start, total = [], 0, 0.0
-            for batch_indexes in minibatches:
+            for b_i, batch_indexes in enumerate(minibatches):
                 n = len(batch_indexes)
                 costs.append(train_rbm(dev_idx[start:start + n], momentum))
                 start += n
+                if b_i + 1 < len(minibatches):      # a host-resident table starts moving the next rows now
+                    train_rbm.prefetch(dev_idx[start:start + len(minibatches[b_i + 1])])
                 if len(costs) >= 256:
                     total = total + torch.stack([c.reshape(()) for c in costs]).sum()
                     costs = []

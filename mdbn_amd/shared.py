@@ -137,6 +137,15 @@ class HostTable(SharedArray):
         """Device matrix of ``table[indexes]`` (index list / tensor, or a slice): the gather kernel reads the pinned
         rows over PCIe on the current stream."""
         eng = self.engine
+        if not hasattr(eng, "gather_host_rows") or not self.host.is_pinned():
+            # an engine without a device (the CPU checker of the tests): plain host indexing
+            if not isinstance(indexes, slice):
+                indexes = torch.as_tensor(numpy.asarray(getattr(indexes, "cpu", lambda: indexes)()), dtype=torch.int64)
+            got = eng.to_device(self.host[indexes][:, :self.cols])
+            if out is not None:
+                out.copy_(got)
+                return out
+            return got
         if isinstance(indexes, slice):
             lo, hi, step = indexes.indices(len(self))
             indexes = torch.arange(lo, hi, step, dtype=torch.int64, device=eng.device)

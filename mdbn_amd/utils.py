@@ -64,14 +64,16 @@ def preprocess_table(data, holdout=0.1, clip=None, transform_fn=None, exponent=1
 
 
 def load_n_preprocess_data(datafile, dtype='float32', holdout=0.1, clip=None, transform_fn=None,
-                           exponent=1.0, repeats=10, shuffle=True, datadir='data', rng=None):
-    """reference utils.py:77-119: load the table, preprocess, and return device-resident
-    ``(train_set, validation_set)`` (SharedArray; validation None without hold-out)."""
+                           exponent=1.0, repeats=10, shuffle=True, datadir='data', rng=None, resident="device"):
+    """reference utils.py:77-119: load the table, preprocess, and return ``(train_set, validation_set)``
+    (SharedArray; validation None without hold-out).  ``resident``: where the TRAINING table lives -- "device"
+    (as the reference's theano.shared, utils.py:113-115), "host" (pinned memory, minibatch rows gathered over PCIe
+    one step ahead: shared.HostTable) or "auto"; the validation set is always device-resident."""
     from .shared import shared
     n_data, n_cols, data = import_TCGA_data(datafile, datadir, dtype)
     train, validation = preprocess_table(data, holdout=holdout, clip=clip, transform_fn=transform_fn,
                                          exponent=exponent, repeats=repeats, shuffle=shuffle, rng=rng)
-    return shared(train, borrow=True), (shared(validation, borrow=True) if validation is not None else None)
+    return shared(train, borrow=True, resident=resident), (shared(validation, borrow=True) if validation is not None else None)
 
 
 # Class post-processing of the joint layer's output (reference utils.py:121-176)

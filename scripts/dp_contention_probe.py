@@ -18,7 +18,7 @@ ap.add_argument("--blocks", default="0,16,32,64")
 ap.add_argument("--us", type=float, default=120.0)
 ap.add_argument("--threads", type=int, default=512)
 ap.add_argument("--opt", action="append", default=[])
-ap.add_argument("--events", default="torch", help="torch | hip:<flags hex> -- who owns the fork / join events")
+ap.add_argument("--events", default="torch", help="torch | hip:<flags hex> | value -- who owns the fork / join: torch events, HIP events with flags, or stream memory operations")
 ap.add_argument("--reserve", default="0", help="comma list of comm_cus settings to try for every occupier size")
 args = ap.parse_args()
 
@@ -30,6 +30,8 @@ occ = C.CDLL(so)
 occ.occupier_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_double]
 occ.occupier_fork.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_double]
 occ.occupier_join.argtypes = [C.c_void_p, C.c_int]
+occ.occupier_fork_value.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_double]
+occ.occupier_join_value.argtypes = [C.c_void_p, C.c_uint]
 
 eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
 for o in args.opt:
@@ -43,12 +45,18 @@ buf_b = torch.zeros(16 << 20, dtype=torch.uint8, device=eng.device)
 class _Work:
     def __init__(self, ev): self.ev = ev
     def wait(self):
-        if isinstance(self.ev, int):
+        if isinstance(self.ev, tuple):
+            assert occ.occupier_join_value(C.c_void_p(torch.cuda.current_stream().cuda_stream), self.ev[0]) == 0
+        elif isinstance(self.ev, int):
             assert occ.occupier_join(C.c_void_p(torch.cuda.current_stream().cuda_stream), self.ev) == 0
         elif self.ev is not None:
             torch.cuda.current_stream().wait_event(self.ev)
 
 
+value_ops = args.events == "value"           # stream memory operations (hipStreamWriteValue32 / hipStreamWaitValue32)
+if value_ops:
+    rc = occ.occupier_values_init()
+    assert rc == 0, "stream value operations unavailable (%d)" % rc
 hip_events = args.events.startswith("hip:")
 if hip_events:
     assert occ.occupier_events(C.c_uint(int(args.events[4:], 16))) == 0
@@ -62,6 +70,13 @@ class OccupierGroup:
     def all_reduce_sum_async(self, t, engine=None):
         if not self.blocks:
             return _Work(None)
+        if value_ops:
+            self.n = getattr(self, "n", 0) + 1
+            rc = occ.occupier_fork_value(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(side.cuda_stream), self.n,
+                                         self.blocks, args.threads, C.c_void_p(buf_a.data_ptr()), C.c_void_p(buf_b.data_ptr()),
+                                         C.c_longlong(buf_a.numel()), C.c_double(args.us))
+            assert rc == 0, rc
+            return _Work((self.n,))
         if hip_events:
             self.n = getattr(self, "n", 0) + 1
             rc = occ.occupier_fork(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(side.cuda_stream), self.n,

@@ -62,3 +62,39 @@ extern "C" int occupier_fork(void* compute, void* side, int slot, int blocks, in
     return (int)hipEventRecord(g_join[slot & 1], (hipStream_t)side);
 }
 extern "C" int occupier_join(void* compute, int slot) { return (int)hipStreamWaitEvent((hipStream_t)compute, g_join[slot & 1], 0); }
+
+// The same fork / join through STREAM MEMORY OPERATIONS instead of events: the producer stream writes a sequence number
+// to signal memory when its preceding work is done (hipStreamWriteValue32), the consumer stream's command processor
+// polls it (hipStreamWaitValue32, >=) -- no inter-queue signal machinery.  Priced against the event forms by
+// scripts/dp_contention_probe.py --events value.
+static uint32_t* g_sig_fork = nullptr;
+static uint32_t* g_sig_join = nullptr;
+extern "C" int occupier_values_init(void)
+{
+    int ok = 0;
+    hipError_t rc = hipDeviceGetAttribute(&ok, hipDeviceAttributeCanUseStreamWaitValue, 0);
+    if (rc != hipSuccess) return (int)rc;
+    if (!ok) return -1;
+    for (uint32_t** p : {&g_sig_fork, &g_sig_join}) {
+        rc = hipExtMallocWithFlags(reinterpret_cast<void**>(p), 8, hipMallocSignalMemory);
+        if (rc != hipSuccess) return (int)rc;
+        rc = hipMemset(*p, 0, 8);
+        if (rc != hipSuccess) return (int)rc;
+    }
+    return 0;
+}
+extern "C" int occupier_fork_value(void* compute, void* side, unsigned seq, int blocks, int threads, const void* src, void* dst,
+                                   long long n_bytes, double microseconds)
+{
+    hipError_t rc = hipStreamWriteValue32((hipStream_t)compute, g_sig_fork, seq, 0);
+    if (rc != hipSuccess) return (int)rc;
+    rc = hipStreamWaitValue32((hipStream_t)side, g_sig_fork, seq, hipStreamWaitValueGte, 0xffffffffu);
+    if (rc != hipSuccess) return (int)rc;
+    int r = occupier_launch(side, blocks, threads, src, dst, n_bytes, microseconds);
+    if (r) return r;
+    return (int)hipStreamWriteValue32((hipStream_t)side, g_sig_join, seq, 0);
+}
+extern "C" int occupier_join_value(void* compute, unsigned seq)
+{
+    return (int)hipStreamWaitValue32((hipStream_t)compute, g_sig_join, seq, hipStreamWaitValueGte, 0xffffffffu);
+}

@@ -413,3 +413,74 @@ def test_config5_three_modality_mdbn_at_batch_512(shadow):
     assert shadow.steps >= 2 * (3 + 6 + 6), shadow.steps
     _verdict(shadow, "c5 MDBN at B = 512, CD-5", [r for net in nets + [top] for r in net.rbm_layers], cost_tol=2e-4,
              param_tol=5e-5)
+
+
+def _write_table(path, data):
+    with open(path, "w") as f:
+        f.write("gene\t" + "\t".join("p%d" % i for i in range(data.shape[1])) + "\n")
+        for i, row in enumerate(data):
+            f.write("g%d\t" % i + "\t".join("%.6f" % v for v in row) + "\n")
+
+
+def test_loader_to_dbn_training_host_resident_equals_device_resident(shadow, tmp_path):
+    """f3 on the device (utils.py:78-119 -> dbn.py:334-517): a TSV table goes through load_n_preprocess_data into
+    DBN.training twice -- device-resident (the reference's theano.shared) and host-resident (pinned memory; every
+    minibatch's rows gathered over PCIe into a double buffer one step ahead, lower-layer activations streamed in
+    chunks) -- on the ShadowEngine, so every CD step is also replayed by the float64 oracle.  Same records, same
+    parameters, same outputs, bit for bit."""
+    import mdbn_amd
+    from mdbn_amd import utils
+    mdbn_amd.DBN.verbose = False
+    rs = np.random.RandomState(2)
+    raw = rs.normal(4, 2, size=(260, 300))                       # 260 features x 300 persons
+    raw[7] = 2.0                                                 # zero variance: dropped by the z-score (utils.py:97)
+    _write_table(str(tmp_path / "ge.tsv"), raw)
+    runs = []
+    for resident in ("device", "host"):
+        tr, va = utils.load_n_preprocess_data("ge.tsv", holdout=0.1, repeats=1, clip=(-3, 3), shuffle=True,
+                                              datadir=str(tmp_path), rng=np.random.RandomState(1), resident=resident)
+        assert tr.shape == (270, 259) and va.shape == (30, 259)
+        assert isinstance(tr, mdbn_amd.HostTable) == (resident == "host")
+        dbn = mdbn_amd.DBN(numpy_rng=np.random.RandomState(123), n_ins=259, hidden_layers_sizes=[64], n_outs=16,
+                           engine=shadow)
+        dbn.shuffle_rng = np.random.RandomState(5)
+        dbn.host_chunk_rows = 100
+        steps0 = shadow.steps
+        hist = dbn.training(tr, batch_size=32, k=1, pretraining_epochs=[40, 40], pretrain_lr=[0.005, 0.1],
+                            lambda_2=0.1, validation_set_x=va)
+        assert shadow.steps - steps0 >= 16
+        if resident == "host":
+            assert tr._mirror is None, "the training path must not upload the whole table"
+        runs.append((hist, [p.get_value() for p in dbn.params], dbn.get_output(tr), dbn.rbm_layers))
+    assert runs[0][0] == runs[1][0]
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(runs[0][2], runs[1][2])
+    _verdict(shadow, "TSV -> DBN.training (259 -> 64 -> 16)", [r for run in runs for r in run[3]], cost_tol=2e-4, param_tol=2e-5)
+
+
+def test_host_table_prefetch_announces_the_next_minibatch(hip_engine):
+    """StepFunction.prefetch: announced rows are staged beside the current step, an unannounced or different minibatch is
+    gathered on the spot -- either way the step sees exactly table[indexes] (bitwise equal to the device-resident run)."""
+    import mdbn_amd
+    V, H, B, N = 256, 128, 64, 1024
+    rs = np.random.RandomState(9)
+    x = rs.normal(size=(N, V)).astype(np.float32)
+    outs = []
+    for resident in ("device", "host"):
+        rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123),
+                            theano_rng=mdbn_amd.RandomStreams(4), engine=hip_engine)
+        _, up = rbm.get_cost_updates(lr=0.002, k=1, lambda_2=0.1, batch_size=B)
+        fn = mdbn_amd.function(up, mdbn_amd.shared(x, engine=hip_engine, resident=resident), data_parallel=None)
+        r2 = np.random.RandomState(1)
+        batches = [r2.permutation(N)[:B] for _ in range(8)]
+        costs = []
+        for t, idx in enumerate(batches):
+            costs.append(float(fn(indexes=idx, momentum=0.2)))
+            if t in (0, 1, 4):
+                fn.prefetch(batches[t + 1])                      # announced correctly
+            elif t == 2:
+                fn.prefetch(batches[0])                          # announced WRONG: must be ignored
+        outs.append((costs, rbm.W.get_value(), rbm.vbias_speed.get_value()))
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])

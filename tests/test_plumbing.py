@@ -189,3 +189,48 @@ def test_bad_minibatch_index_raises(oracle_engine):
     with pytest.raises(IndexError):
         HipEngine.index_tensor(oracle_engine, [-13], 12)
     assert HipEngine.index_tensor(oracle_engine, np.array([-12, 11]), 12).tolist() == [-12, 11]
+
+
+def test_host_resident_table_on_the_checker_engine(tmp_path, oracle_engine):
+    """shared(x, resident="host") (shared.HostTable): the matrix protocol the trainers use, row gathers, and
+    load_n_preprocess_data -> DBN.training giving the same network as the device-resident default (on the CPU checker
+    there is no PCIe path: this covers the host logic; tests/test_gpu_surface.py covers the streamed path)."""
+    DBN.verbose = False
+    rs = np.random.RandomState(3)
+    x = rs.normal(size=(37, 10)).astype(np.float32)
+    t = mdbn_amd.shared(x, resident="host")
+    assert isinstance(t, mdbn_amd.HostTable) and t.shape == (37, 10) and len(t) == 37 and t.ndim == 2
+    assert t.host.stride(0) == 12 and not t.host[:, 10:].any()           # padded leading dimension, zero padding
+    np.testing.assert_array_equal(t.get_value(), x)
+    np.testing.assert_array_equal(np.asarray(t[np.array([5, 0, 36])]), x[[5, 0, 36]])
+    np.testing.assert_array_equal(oracle_engine.to_numpy(t.rows(slice(3, 9))), x[3:9])
+    t.set_value(x[::-1].copy())
+    np.testing.assert_array_equal(t.get_value(), x[::-1])
+    assert mdbn_amd.shared(t) is t
+    assert isinstance(mdbn_amd.shared(x, resident="auto"), mdbn_amd.SharedArray) and \
+        not isinstance(mdbn_amd.shared(x, resident="auto"), mdbn_amd.HostTable)
+    os.environ["MDBN_HOST_TABLE_BYTES"] = "100"
+    try:
+        assert isinstance(mdbn_amd.shared(x, resident="auto"), mdbn_amd.HostTable)
+    finally:
+        del os.environ["MDBN_HOST_TABLE_BYTES"]
+    with pytest.raises(ValueError):
+        mdbn_amd.shared(x, resident="nowhere")
+
+    raw = rs.normal(3, 2, size=(14, 40))
+    write_table(str(tmp_path / "ge.tsv"), raw)
+    nets = []
+    for resident in ("device", "host"):
+        tr, va = utils.load_n_preprocess_data("ge.tsv", holdout=0.2, repeats=1, shuffle=True, datadir=str(tmp_path),
+                                              rng=np.random.RandomState(1), resident=resident)
+        assert isinstance(tr, mdbn_amd.HostTable) == (resident == "host")
+        dbn = DBN(numpy_rng=np.random.RandomState(123), n_ins=14, hidden_layers_sizes=[9], n_outs=4)
+        dbn.shuffle_rng = np.random.RandomState(5)
+        dbn.host_chunk_rows = 8                         # several chunks through the lower-layer forward
+        hist = dbn.training(tr, batch_size=8, k=1, pretraining_epochs=[6, 6], pretrain_lr=[0.005, 0.1],
+                            validation_set_x=va)
+        nets.append((hist, [p.get_value() for p in dbn.params], dbn.get_output(tr)))
+    assert nets[0][0] == nets[1][0]
+    for a, b in zip(nets[0][1], nets[1][1]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(nets[0][2], nets[1][2])
