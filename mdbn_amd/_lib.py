@@ -94,6 +94,18 @@ SIGNATURES = {
 }
 
 _lib = None
+_diagnostic = False
+
+
+def use_diagnostic_library(path):
+    """Experiments only (scripts/): load ``path`` -- a library built with diagnostic -D flags from the sources on disk --
+    instead of the in-tree one.  Its embedded hash is not compared with the sources (the flags differ by design); the
+    ctypes layouts are those of the current header, so it must be built from the CURRENT sources."""
+    global LIB_PATH, _diagnostic, _lib
+    if _lib is not None:
+        raise MdbnError("a library is already loaded in this process")
+    LIB_PATH, _diagnostic = path, True
+
 
 
 def load():
@@ -102,7 +114,7 @@ def load():
     if _lib is not None:
         return _lib
     from . import build as _build
-    if _build.is_stale():
+    if not _diagnostic and _build.is_stale():
         # missing, or built from other sources than the ones on disk (content hash, not mtime)
         try:
             _build.build_lib(force=True)
@@ -120,7 +132,7 @@ def load():
         raise MdbnError("libmdbn_hip.so version mismatch")
     buf = C.create_string_buffer(80)
     lib.mdbn_source_hash(buf, 80)
-    if buf.value.decode() != _build.source_hash():
+    if not _diagnostic and buf.value.decode() != _build.source_hash():
         # the mapped code is not what the ctypes layouts above describe (e.g. the path was dlopen'ed before a
         # rebuild in this process): refuse to run kernels that would be attributed to the wrong sources
         raise MdbnError("%s is loaded with source hash %s but the sources on disk hash to %s; rebuild "

@@ -345,9 +345,18 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
 
+// How a split-K partial tile (FUSED == 0) reaches its slab: 0 = straight from the accumulator registers (64 dword stores
+// per lane, 64-byte segments); 1 = through the LDS-parked tile, whole rows, 16 bytes per lane, by all 8 waves; 2 = the same
+// with WRITE-THROUGH (sc1) stores: the partials stream to memory while the tail of the launch still issues stores, instead
+// of sitting dirty in L2 until the end-of-kernel write-back (16.8 MB per forward pass at c2: ~3.5 us of the launch,
+// scripts/experiments/fixed_cost_probe.py; MI355X_MICROARCH.md "publish-large")
+#ifndef PL_SLAB_STORE
+#define PL_SLAB_STORE 0
+#endif
+    constexpr bool parked_slab = FUSED == 0 && PL_SLAB_STORE != 0 && MS == 16;
     if (wave >= 4) {
         pl_loader<LA, LB, AP, MS>(g, smem, wave - 4, lane, m0, n0, kbeg, nt);
-        if constexpr (FUSED == 0) return;
+        if constexpr (FUSED == 0 && !parked_slab) return;
     } else {
         const int r = lane & 31, h = lane >> 5;
         const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
 #endif
             // accumulator (16x16): col = lane & 15, row = 4 * (lane >> 4) + e
             const int c16 = lane & 15, q4 = lane >> 4;
-            if constexpr (FUSED != 0) {
+            if constexpr (FUSED != 0 || parked_slab) {
                 float* T = reinterpret_cast<float*>(smem);
                 constexpr int LDT = 128 + 8;
 #pragma unroll
@@ -406,14 +415,20 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
                         for (int e = 0; e < 4; ++e)
                             T[(wm + 16 * a + 4 * q4 + e) * LDT + wn + 16 * b + c16] = acc[a][b][e];
             } else {
-                float* C = g.C + (int64_t)ks * g.slab_stride;
+                // diagnostic builds (wrong results; scripts/experiments/fixed_cost_probe.py): PL_DIAG_DIRTY = 1: every split
+                // stores into slab 0 (an eighth of the dirty bytes at the end of the launch), 2: no stores at all
+#ifndef PL_DIAG_DIRTY
+#define PL_DIAG_DIRTY 0
+#endif
+                float* C = g.C + (PL_DIAG_DIRTY ? (int64_t)0 : (int64_t)ks * g.slab_stride);
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            C[(int64_t)(m0 + wm + 16 * a + 4 * q4 + e) * g.ldc + n0 + wn + 16 * b + c16] = acc[a][b][e];
+                            if (PL_DIAG_DIRTY != 2 || acc[a][b][e] == 12345.678f)
+                                C[(int64_t)(m0 + wm + 16 * a + 4 * q4 + e) * g.ldc + n0 + wn + 16 * b + c16] = acc[a][b][e];
                 PL_MSTAMP(11);
 #ifdef MDBN_STAMP
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -548,6 +563,23 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
             return;
         }
             }
+    }
+    if constexpr (parked_slab) {    // whole rows of the parked partial tile -> slab ks, 16 bytes per lane, all 8 waves
+        __syncthreads();
+        typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
+        const float* T = reinterpret_cast<const float*>(smem);
+        constexpr int NT = 64 * (4 + PL_LW), LDT = 128 + 8;
+        // descriptor over this tile's 128 rows (128 x ldc floats: far below 2 GiB for any ldc this path accepts)
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            g.C + (int64_t)ks * g.slab_stride + (int64_t)m0 * g.ldc + n0, 0, (int)(128 * g.ldc * 4), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 128 * 32 / NT; ++i) {
+            const int idx = threadIdx.x + i * NT, row = idx >> 5, c4 = idx & 31;
+            const pu32x4 v = *reinterpret_cast<const pu32x4*>(T + row * LDT + 4 * c4);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)((row * g.ldc + 4 * c4) * 4), 0,
+                                                   PL_SLAB_STORE == 2 ? 16 /* sc1 */ : 0);
+        }
+        return;
     }
     if constexpr (FUSED != 0) {     // all 8 waves work on the parked tile (every DMA has landed: the loaders drained vmcnt)
         __syncthreads();

@@ -58,6 +58,8 @@ class DBN(object):
 
     verbose = True          # the reference prints progress; set False to silence
     cache_lower = True      # cache frozen lower-layer activations while layer i trains
+    data_parallel = "auto"  # step functions shard minibatches over the ranks of an initialised process group ("auto"),
+                            # or None: this network trains in this process alone (modality-parallel placement, MDBN.py)
 
     def __init__(self, numpy_rng=None, theano_rng=None, n_ins=784, gauss=True,
                  hidden_layers_sizes=[400], n_outs=40, W_list=None, b_list=None, engine=None):
@@ -181,8 +183,8 @@ class DBN(object):
             else:
                 cost, updates = rbm.get_cost_updates(learning_rate, weightcost=0.0002,
                                                      batch_size=batch_size, persistent=None, k=k)
-            train_fns.append(function(updates, train_set_x,
-                                      input_fn=self._layer_input_fn(i, train_set_x)))
+            train_fns.append(function(updates, train_set_x, input_fn=self._layer_input_fn(i, train_set_x),
+                                      data_parallel=self.data_parallel))
             free_energy_gap_fns.append(rbm.free_energies)
         return train_fns, free_energy_gap_fns
 

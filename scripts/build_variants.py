@@ -12,7 +12,7 @@ for i, flags in enumerate(sys.argv[1:]):
 import sys, time; sys.path.insert(0, %r)
 import numpy as np, torch, mdbn_amd
 from mdbn_amd import _lib
-_lib.LIB_PATH = %r
+_lib.use_diagnostic_library(%r)
 eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
 V, H, B, N = 4096, 1024, 512, 32768
 g = torch.Generator(device="cpu").manual_seed(0)

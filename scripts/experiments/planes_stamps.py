@@ -12,7 +12,7 @@ src = [os.path.join(ROOT, "mdbn_amd", "csrc", f) for f in ("mdbn_kernels.hip", "
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DMDBN_STAMP"] + src + ["-o", so])
 import numpy as np, torch
 from mdbn_amd import _lib
-_lib.LIB_PATH = so
+_lib.use_diagnostic_library(so)
 import mdbn_amd
 eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
 V, H, B, N = 4096, 1024, 512, 32768

@@ -3,7 +3,7 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mdbn_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("STAMP_LIB", "libmdbn_stamp.so"))
+_lib.use_diagnostic_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("STAMP_LIB", "libmdbn_stamp.so")))
 import mdbn_amd
 eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
 lib = eng.lib

@@ -20,7 +20,7 @@ from mdbn_amd import _lib
 ''' % (ROOT,)
     # run in a subprocess so that each library is loaded fresh
     prog = code + r'''
-_lib.LIB_PATH = %r          # diagnostic library instead of the product build
+_lib.use_diagnostic_library(%r)          # diagnostic library instead of the product build
 eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
 eng.set_option("fused_epilogue", 0)
 V, H = 4096, 1024

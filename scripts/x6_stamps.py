@@ -9,7 +9,7 @@ so = os.path.join(out, "libmdbn_stamp.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DMDBN_STAMP"] + src + ["-o", so])
 import numpy as np, torch
 from mdbn_amd import _lib
-_lib.LIB_PATH = so
+_lib.use_diagnostic_library(so)
 import mdbn_amd
 eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
 eng.set_option("fused_epilogue", 0)

@@ -105,6 +105,42 @@ def run_mdbn(group_mode):
     return {"p%d" % i: w for i, w in enumerate(Ws)} | {"out": top.get_output(joint)}
 
 
+def run_modalities(group_mode):
+    """configs[4]'s three modalities placed MODALITY-PARALLEL (MDBN.train_modalities): rank i % N trains modality i alone,
+    parameters are broadcast once, the joint layer follows on the concatenated outputs."""
+    import mdbn_amd
+    from mdbn_amd import MDBN
+    from _oracle_engine import OracleEngine
+    mdbn_amd.set_engine(OracleEngine())
+    mdbn_amd.DBN.verbose = False
+    rs = np.random.RandomState(0)
+    rng = np.random.RandomState(123)
+    specs = []
+    for width, sizes, k in ((16, [5], 3), (20, [8, 4], 1), (10, [6, 3], 1)):
+        x = rs.normal(size=(24, width))
+        specs.append(dict(train_set=x, validation_set=x[:6], batch_size=8, k=k, layers_sizes=sizes,
+                          pretraining_epochs=[4] * len(sizes), pretrain_lr=[0.005] + [0.1] * (len(sizes) - 1),
+                          lambda_1=0.01, lambda_2=0.1))
+    trained = MDBN.train_modalities(specs, rng, group="auto" if group_mode else None, shuffle_seed=0)
+    out = {}
+    for m, (net, out_t, out_v) in enumerate(trained):
+        for i, p in enumerate(net.params):
+            out["m%d_p%d" % (m, i)] = p.get_value()
+        for i, r in enumerate(net.rbm_layers):
+            out["m%d_vb%d" % (m, i)] = r.vbias.get_value()
+            out["m%d_ws%d" % (m, i)] = r.W_speed.get_value()
+            out["m%d_ctr%d" % (m, i)] = np.array([r._rng_step, r.bit_i_idx])
+        out["m%d_out" % m], out["m%d_val" % m] = out_t, out_v
+    joint = np.concatenate([t[1] for t in trained], axis=1)
+    top = mdbn_amd.DBN(numpy_rng=rng, n_ins=joint.shape[1], gauss=False, hidden_layers_sizes=[6], n_outs=3)
+    top.shuffle_rng = np.random.RandomState(99)
+    top.training(mdbn_amd.shared(joint), batch_size=8, k=1, pretraining_epochs=[3, 3], pretrain_lr=[0.1, 0.1])
+    for i, p in enumerate(top.params):
+        out["top_p%d" % i] = p.get_value()
+    out["classes"] = top.get_output(joint)
+    return out
+
+
 def run_interleaved(overlap, group_mode):
     """Two step functions of the SAME shape (two equal-sized modalities) called alternately: with the
     all-reduce of each deferred by one call, neither may see the other's pending statistics."""
@@ -144,6 +180,8 @@ def worker(rank, world, port, outdir, gauss, overlap):
         out = run_pcd(True)
     elif gauss == 4:
         out = run_mdbn(True)
+    elif gauss == 5:
+        out = run_modalities(True)
     else:
         out = run_interleaved(overlap, True) if gauss == 2 else run_steps(gauss, overlap, True)
     np.savez(os.path.join(outdir, "rank%d_%d_%d.npz" % (rank, gauss, overlap)), **out)
@@ -155,8 +193,9 @@ def worker(rank, world, port, outdir, gauss, overlap):
 def dp_results():
     res = {}
     with tempfile.TemporaryDirectory() as d:
-        for gauss in (1, 0, 2, 3, 4):       # 2 = two step functions interleaved, 3 = PCD (synchronous only), 4 = MDBN stack
-            for overlap in ((0,) if gauss in (3, 4) else (0, 1)):
+        # 2 = two step functions interleaved, 3 = PCD (synchronous only), 4 = MDBN stack (row-sharded), 5 = modality-parallel
+        for gauss in (1, 0, 2, 3, 4, 5):
+            for overlap in ((0,) if gauss in (3, 4, 5) else (0, 1)):
                 mp.spawn(worker, args=(2, free_port(), d, gauss, overlap), nprocs=2, join=True)
                 res[(gauss, overlap)] = [dict(np.load(os.path.join(d, "rank%d_%d_%d.npz" % (r, gauss, overlap))))
                                          for r in range(2)]
@@ -212,6 +251,22 @@ def test_mdbn_stack_under_data_parallelism(dp_results):
     for k in single:
         assert np.array_equal(r0[k], r1[k]), k
         np.testing.assert_allclose(r0[k], single[k], rtol=2e-5, atol=1e-7, err_msg=k)      # float32 get_value round trips
+
+
+def test_modality_parallel_placement_equals_sequential(dp_results):
+    """SURVEY 8e's alternative for configs[4]: three modalities over two ranks (rank 0 trains modalities 0 and 2, rank 1
+    modality 1), no collective per step, one parameter broadcast per modality -- every array, counter and output equals
+    the single-process sequential run with the same per-modality shuffle streams BIT FOR BIT; the joint layer on top
+    (row-sharded over the ranks again) agrees to summation order."""
+    sys.path.insert(0, HERE)
+    single = run_modalities(False)
+    r0, r1 = dp_results[(5, 0)]
+    for k in single:
+        assert np.array_equal(r0[k], r1[k]), "replicas differ: " + k
+        if k.startswith("m"):
+            assert np.array_equal(r0[k], single[k]), k
+        else:
+            np.testing.assert_allclose(r0[k], single[k], rtol=2e-5, atol=1e-7, err_msg=k)
 
 
 def test_shard_bounds():

@@ -444,7 +444,6 @@ def test_loader_to_dbn_training_host_resident_equals_device_resident(shadow, tmp
         dbn = mdbn_amd.DBN(numpy_rng=np.random.RandomState(123), n_ins=259, hidden_layers_sizes=[64], n_outs=16,
                            engine=shadow)
         dbn.shuffle_rng = np.random.RandomState(5)
-        dbn.host_chunk_rows = 100
         steps0 = shadow.steps
         hist = dbn.training(tr, batch_size=32, k=1, pretraining_epochs=[40, 40], pretrain_lr=[0.005, 0.1],
                             lambda_2=0.1, validation_set_x=va)
@@ -456,6 +455,12 @@ def test_loader_to_dbn_training_host_resident_equals_device_resident(shadow, tmp
     for a, b in zip(runs[0][1], runs[1][1]):
         assert np.array_equal(a, b)
     assert np.array_equal(runs[0][2], runs[1][2])
+    # a table longer than DBN.host_chunk_rows streams through the lower layers in row chunks: another GEMM plan per
+    # chunk (the split-K factor follows the row count), so the activations agree to fp32 summation order
+    dbn.host_chunk_rows = 100
+    tr._mirror = None
+    np.testing.assert_allclose(dbn.get_output(tr), runs[1][2], rtol=0, atol=2e-6)
+    assert tr._mirror is None
     _verdict(shadow, "TSV -> DBN.training (259 -> 64 -> 16)", [r for run in runs for r in run[3]], cost_tol=2e-4, param_tol=2e-5)
 
 
