@@ -161,6 +161,10 @@ int  mdbn_ctx_destroy(mdbn_ctx *ctx);
  *   v_mfma_f32_32x32x16_bf16 (bit-identical to the f32-operand path). 
  *  "planes_min_work" (default
  *   2^30): smallest B * V * H the plane path serves (smaller whole-tile layers are faster on the f32-operand kernels).
+ * "early_w" (default 1): in the plane statistics GEMM with the fused update the parameter half (W and its planes: it
+ *   needs only the old W and the old speed, rbm.py:364-365) is applied by the kernel's loader waves during the main loop,
+ *   the epilogue only forms the new speed; bitwise the same parameters and speeds (needs lambda_1 == 0 and weightcost == 0
+ *   or a frozen W0, else the whole rule stays in the epilogue).
  * "comm_cus" (default 0): CUs left to a collective that runs beside the step when mdbn_cd_args.comm_cus is 0 (see
  *   there); "bal_blocks" (tests): the number of workgroups of a balanced launch itself.
  * "epilogue_threads": threads per block of the activation epilogue launch, 0 = auto, 64, 128 or 256.

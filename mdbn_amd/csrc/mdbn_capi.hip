@@ -200,6 +200,9 @@ static int g_opt_gemm_planes = 1;
 // a higher clock on it), 32 = v_mfma_f32_32x32x16_bf16 (the products and order of gemm_bf16x6_kernel: same bits as the
 // f32-operand path)
 static int g_opt_planes_mfma = 16;
+// mdbn_set_option("early_w"): the statistics GEMM's loader waves apply the parameter half of the fused update during the
+// main loop (W' needs only the old W and the old speed), the epilogue only forms the new speed (default on; same bits)
+static int g_opt_early_w = 1;
 // mdbn_set_option("bf16_inputs"): REPORTING mode of BASELINE configs[1] ("bf16/fp32"): the plane GEMMs use only the
 // leading bf16 piece of every operand (inputs truncated to bf16, f32 accumulation, one product instead of six).
 // Probabilities then carry ~4e-3 of error: never used for a parity claim, off by default.
@@ -728,6 +731,10 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
         g.upd.lr = upd->lr; g.upd.l1 = upd->lambda_1; g.upd.l2 = upd->lambda_2; g.upd.wc = upd->weightcost;
         g.upd.mu = upd->momentum; g.upd.inv_bs = 1.0f / upd->batch_size;
         g.upd.Wp = Wp; g.upd.wp_stride = V * ldh;
+        // parameter half applied by the loader waves during the main loop (mdbn_planes.hip, EARLYW): needs the split-phase
+        // conditions of the update (no lambda_1; weight cost off or on a frozen snapshot) and >= 12 stages to spread over
+        g.upd.early = g_opt_early_w && upd->lambda_1 == 0.f && (upd->weightcost == 0.f || upd->W0 != nullptr) &&
+                      2 * B / 32 >= 12 && g_opt_planes_mfma == 16 && !g_opt_bf16_inputs;
         HIP_OK(timed_gemm_planes(LAY_MN, LAY_MN, g, s));
         return MDBN_OK;
     }
@@ -903,6 +910,10 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "planes_mfma") == 0) {
         if (value != 16 && value != 32) return fail(MDBN_EINVAL, "planes_mfma must be 16 or 32");
         g_opt_planes_mfma = (int)value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "early_w") == 0) {
+        g_opt_early_w = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "bal_blocks") == 0) {

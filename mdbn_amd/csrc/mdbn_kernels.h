@@ -50,6 +50,9 @@ struct UpdEpi {
     float lr, l1, l2, wc, mu, inv_bs;
     unsigned short* Wp;            // nullable: bf16 planes [3][rows][ld] of the NEW W, kept in step with it
     int64_t wp_stride;
+    int early;                     // plane statistics GEMM: the PARAMETER half (W, W planes: it needs only the old W and the old
+                                   // speed, rbm.py:364-365) is applied by the loader waves DURING the main loop; the epilogue
+                                   // then only forms the new speed from the finished tile (needs l1 == 0 and wc == 0 or W0)
 };
 
 // bias half of the update + monitoring cost, applied by finalize_stats_kernel
@@ -112,9 +115,6 @@ struct PlaneGemmArgs {
                            // 0 = bf16-input reporting mode: the leading plane of each operand, ONE product
     int ms;                // MFMA shape: 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16
     int fused;             // 0 | 1 activation epilogue (epi) | 2 parameter update (upd) + finalize units (fin)
-                           // | 3 split-K with the reduction INSIDE the launch: every block publishes its partial tile
-                           //   (write-through stores), the last block to arrive at a tile sums the partials in slab
-                           //   order and runs the activation epilogue (epi)
     // balanced launches (launch_gemm_planes_bal): `bal` workgroups share tiles x (K / 32) stages evenly;
     // fused = 0: slabs, one per piece of a tile; fused = 4: result in place, pieces of shared tiles through `scratch`
     unsigned long long* stamps;   // diagnostic builds only (-DMDBN_STAMP): 8 wall-clock stamps per workgroup (propup)

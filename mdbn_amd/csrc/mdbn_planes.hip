@@ -75,8 +75,15 @@ template <int MS> __device__ __forceinline__ int pl_col_swz(int k)
 #else
 #define PL_STAMP(SLOT) do {} while (0)
 #endif
-template <int LA, int LB, int AP, int MS>
-__device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, int w, int lane, int m0, int n0, int kbeg, int nt)
+// EARLYW (statistics GEMM with the fused update, UpdEpi.early): between their LDS-DMA issues the loader waves also apply
+// the PARAMETER half of the update to this workgroup's W tile, one 8-row chunk (CPI chunks) per stage -- see
+// early_w_load / early_w_apply in mdbn_device.h.  A chunk's loads are issued before the stage's DMAs and consumed after
+// them (same basic block: the compiler's own vmcnt(PER) before the first use lets the DMAs fly); its stores are younger
+// than the stage, so the counted waits below stay valid (they only become stricter).
+struct EarlySpeed { float4 sp[16], w0[16]; };      // a loader lane's share of the tile's old speed (+ frozen W0), rows 8 j + lt / 32
+template <int LA, int LB, int AP, int MS, bool EARLYW = false>
+__device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, int w, int lane, int m0, int n0, int kbeg, int nt,
+                                          EarlySpeed* es = nullptr)
 {
     PL_STAMP(0);
     // AP = planes of A (3 | 1); AP = 0 is the bf16-input REPORTING mode: one plane of each operand, one product
@@ -141,12 +148,49 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
     PL_STAMP(3);
     __builtin_amdgcn_s_barrier();                    // stage 0 landed
 #endif
+    int chunk = 0;                                   // EARLYW: next 8-row chunk of the W tile (16 in all)
+    const int lt = w * 64 + lane;
+    const int cpi = nt >= 20 ? 1 : 2;                // chunks per stage: all 16 done well before the loop ends (host: nt >= 12)
+    (void)chunk; (void)lt; (void)cpi;
     for (int it = 0; it < nt; ++it) {
         // stage it + 1 must have landed before the MFMA waves pass barrier `it`; stage it + 2 may still fly
         if (it + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                // every read of stage `it` is done: its slot is free
-        if (it + 3 < nt) { PL_ISSUE(it + 3); }
+        if (it + 3 < nt) {
+            if constexpr (EARLYW) {
+                if (g.upd.early && chunk < 16) {     // (wave-uniform)
+                    if (cpi == 1) {
+                        const EarlyW e0 = early_w_load(g.upd, m0, n0, chunk, lt);
+                        PL_ISSUE(it + 3);
+                        early_w_apply(g.upd, e0);
+                        chunk += 1;
+                    } else {
+                        const EarlyW e0 = early_w_load(g.upd, m0, n0, chunk, lt);
+                        const EarlyW e1 = early_w_load(g.upd, m0, n0, chunk + 1, lt);
+                        PL_ISSUE(it + 3);
+                        early_w_apply(g.upd, e0);
+                        early_w_apply(g.upd, e1);
+                        chunk += 2;
+                    }
+                    continue;
+                }
+            }
+            PL_ISSUE(it + 3);
+        }
+    }
+    if constexpr (EARLYW) {
+        if (g.upd.early) {
+            for (; chunk < 16; ++chunk) early_w_apply(g.upd, early_w_load(g.upd, m0, n0, chunk, lt));   // (never with nt >= 12)
+            // the MFMA waves are still on the last stage: fetch this lane's share of the old speed (and of the frozen W0)
+            // for the speed epilogue now, so that only its stores follow the main loop
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int64_t off = (int64_t)(m0 + 8 * j + (lt >> 5)) * g.upd.ld + n0 + 4 * (lt & 31);
+                es->sp[j] = *reinterpret_cast<const float4*>(g.upd.Ws + off);
+                es->w0[j] = g.upd.W0 ? *reinterpret_cast<const float4*>(g.upd.W0 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
     }
     PL_STAMP(4);
 #undef PL_ISSUE
@@ -354,8 +398,10 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
 #define PL_SLAB_STORE 0
 #endif
     constexpr bool parked_slab = FUSED == 0 && PL_SLAB_STORE != 0 && MS == 16;
+    EarlySpeed es;
+    (void)es;
     if (wave >= 4) {
-        pl_loader<LA, LB, AP, MS>(g, smem, wave - 4, lane, m0, n0, kbeg, nt);
+        pl_loader<LA, LB, AP, MS, FUSED == 2 && MS == 16>(g, smem, wave - 4, lane, m0, n0, kbeg, nt, &es);
         if constexpr (FUSED == 0 && !parked_slab) return;
     } else {
         const int r = lane & 31, h = lane >> 5;
@@ -586,6 +632,22 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
         float* T = reinterpret_cast<float*>(smem);
         constexpr int NT = 64 * (4 + PL_LW);
         if constexpr (FUSED == 1) fused_tile_epilogue<128, 128, NT>(g.epi, T, m0, n0);
+        else if (MS == 16 && g.upd.early) {          // W went early (pl_loader); the loader waves hold speed_old (+ W0)
+            if (wave >= 4) {
+                const int lt = (wave - 4) * 64 + lane;
+                constexpr int LDT = 128 + 8;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int row = 8 * j + (lt >> 5), c4 = lt & 31;
+                    const float4 st = *reinterpret_cast<const float4*>(T + row * LDT + 4 * c4);
+                    float4 sn;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        setc(sn, c, upd_speed(upd_grad(comp(st, c), g.upd.inv_bs, g.upd.wc, comp(es.w0[j], c)), comp(es.sp[j], c), g.upd.mu));
+                    *reinterpret_cast<float4*>(g.upd.Ws + (int64_t)(m0 + row) * g.upd.ld + n0 + 4 * c4) = sn;
+                }
+            }
+        }
         else fused_update_epilogue<128, 128, NT>(g.upd, T, m0, n0);
     }
 }

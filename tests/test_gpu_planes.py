@@ -314,3 +314,26 @@ def test_product_default_c2_statistics_against_forced_oracle(built_lib, gauss):
         assert flips <= 3
     finally:
         eng.set_planes_min_work(0)
+
+
+@pytest.mark.parametrize("gauss,V,H,B", [(True, 4096, 1024, 512), (False, 2048, 1024, 512), (True, 1024, 1024, 256)])
+def test_early_parameter_half_is_bitwise_the_epilogue_update(hip_engine, gauss, V, H, B):
+    """mdbn_set_option("early_w"): the statistics GEMM's loader waves apply W' = W * decay + speed_old * lr (and rewrite W's
+    planes) DURING the main loop, the epilogue only forms the new speed -- the same functions on the same operands as the
+    whole rule in the epilogue: every parameter, speed, cost and W plane bit for bit, for the GRBM (lambda_2 decay) and
+    the Bernoulli RBM (frozen weight-cost snapshot, momentum); B = 256 runs two chunks per stage."""
+    eng = hip_engine
+    runs = []
+    for early in (1, 0, 1):
+        eng.set_option("early_w", early)
+        try:
+            out, rbm, wp, valid = _run_steps(eng, gauss, True, V, H, B, 1, steps=6, seed=4)
+        finally:
+            eng.set_option("early_w", 1)
+        assert valid
+        p1, p2, p3 = planes_to_f32(wp)
+        assert torch.equal((p3 + p2) + p1, rbm.W.tensor), "W planes out of step with W"
+        runs.append(out)
+    for other in runs[1:]:
+        for key in runs[0]:
+            assert np.array_equal(runs[0][key], other[key]), key
