@@ -216,6 +216,14 @@ int  mdbn_gather_rows(mdbn_ctx *ctx, void *stream, const float *src, int64_t n_r
                       int64_t cols, int64_t ld_src, const void *indexes, int index_is_64,
                       int64_t n_idx, float *dst, int64_t ld_dst);
 
+/* The same gather for a source in PINNED HOST memory (device-accessible: hipHostMalloc / torch pin_memory), read over
+ * PCIe by a small-footprint kernel: `workgroups` (0 = 32) workgroups of `threads` (0 = 256; 64 | 128 | 256) threads walk
+ * the rows, four 16-byte loads in flight per thread, 20 VGPRs -- the streamed form of src/utils.py:113-115's table for
+ * data that is not uploaded whole; meant for a side stream, one minibatch ahead of the step.  dst is device memory. */
+int  mdbn_gather_rows_host(mdbn_ctx *ctx, void *stream, const float *src, int64_t n_rows,
+                           int64_t cols, int64_t ld_src, const void *indexes, int index_is_64,
+                           int64_t n_idx, float *dst, int64_t ld_dst, int workgroups, int threads);
+
 /* propup + sample_h_given_v (src/rbm.py:187-213), also HiddenLayer.output (src/mlp.py:103-107):
  * pre = v W + hbias ; mean = sigmoid(pre) ; sample = (u < mean).
  * pre / mean / sample may each be NULL; mean is stored multiplied by mean_scale. */

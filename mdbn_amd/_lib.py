@@ -67,6 +67,7 @@ SIGNATURES = {
     "mdbn_split_planes": [_vp, _vp, _vp, _i64, _i64, _vp],
     "mdbn_stats_floats": [_i64, _i64, _i64, C.POINTER(_i64)],
     "mdbn_gather_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _i64, _vp, _i64],
+    "mdbn_gather_rows_host": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _i64, _vp, _i64, _i32, _i32],
     "mdbn_propup_sample": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp,
                            _vp, _vp, _f32, _vp, _rngp, _vp, _i64],
     "mdbn_propdown_sample": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i32, _i32,

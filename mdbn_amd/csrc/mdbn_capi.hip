@@ -1047,6 +1047,22 @@ int mdbn_gather_rows(mdbn_ctx* ctx, void* stream, const float* src, int64_t n_ro
     return MDBN_OK;
 }
 
+int mdbn_gather_rows_host(mdbn_ctx* ctx, void* stream, const float* src, int64_t n_rows, int64_t cols, int64_t ld_src,
+                          const void* indexes, int index_is_64, int64_t n_idx, float* dst, int64_t ld_dst, int workgroups,
+                          int threads)
+{
+    REQUIRE(ctx != nullptr, "ctx is NULL");
+    CHECK(check_mat(src, ld_src, cols, "src"));
+    CHECK(check_mat(dst, ld_dst, cols, "dst"));
+    REQUIRE(n_rows > 0 && n_idx >= 0, "bad row counts");
+    REQUIRE(indexes != nullptr || n_idx <= n_rows, "identity gather longer than the source");
+    REQUIRE(workgroups >= 0 && workgroups <= 1024, "workgroups must be in [0, 1024] (0 = default 32)");
+    REQUIRE(threads == 0 || threads == 64 || threads == 128 || threads == 256, "threads must be 0 (= 256), 64, 128 or 256");
+    HIP_OK(launch_gather_slim(src, n_rows, ru4(cols), ld_src, indexes, index_is_64, n_idx, dst, ld_dst,
+                              workgroups ? workgroups : 32, threads ? threads : 256, (hipStream_t)stream));
+    return MDBN_OK;
+}
+
 int mdbn_propup_sample(mdbn_ctx* ctx, void* stream, const float* v, int64_t B, int64_t ldv, const float* W,
                        int64_t V, int64_t H, int64_t ldh, const float* hbias, float* pre, float* mean,
                        float mean_scale, float* sample, const mdbn_rng* rng, void* workspace,

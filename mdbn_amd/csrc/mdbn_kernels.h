@@ -166,6 +166,8 @@ hipError_t launch_gemm(int la, int lb, const GemmArgs& g, hipStream_t s);
 hipError_t launch_act_epilogue(const EpiArgs& e, hipStream_t s);
 hipError_t launch_sum_slabs(const float* slabs, int nsplit, int64_t slab_stride, int64_t n,
                             float* out, hipStream_t s);
+hipError_t launch_gather_slim(const float* src, int64_t n_rows, int64_t cols_ld, int64_t ld_src, const void* idx, int idx64,
+                              int64_t n_idx, float* dst, int64_t ld_dst, int blocks, int threads, hipStream_t s);
 hipError_t launch_gather(const float* src, int64_t n_rows, int64_t cols_ld, int64_t ld_src,
                          const void* idx, int idx64, int64_t n_idx, float* dst, int64_t ld_dst,
                          hipStream_t s);

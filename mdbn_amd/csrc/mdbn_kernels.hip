@@ -1431,6 +1431,46 @@ hipError_t launch_gather(const float* src, int64_t n_rows, int64_t cols_ld, int6
     return hipGetLastError();
 }
 
+// The same gather with a SMALL footprint, for sources in pinned host memory read over PCIe beside a running CD step
+// (shared.HostTable, StepFunction.prefetch): `blocks` workgroups (<= 64) of 256 threads walk the rows, four 16-byte loads
+// in flight per thread (64 KB per row pass of a block: more than enough to cover the ~2 us PCIe round trip at 55 GB/s),
+// at most 40 VGPRs -- so its waves fit beside a resident 144-KB GEMM workgroup (2 x 232 VGPRs per SIMD) instead of
+// filling every wave slot of the chip for the 150 us the transfer takes (the wide kernel above serialised with the step:
+// 321 us per step against 146 resident, profiles/r03g_bench.json).
+__global__ __launch_bounds__(256) void gather_rows_slim_kernel(const float* __restrict__ src, int64_t n_rows, int64_t ld_src,
+                                                               const void* __restrict__ idx, int idx64, int64_t ld4,
+                                                               int64_t n_idx, float* __restrict__ dst, int64_t ld_dst)
+{
+    const int nt = blockDim.x;
+    for (int64_t r = blockIdx.x; r < n_idx; r += gridDim.x) {
+        int64_t s = r;
+        if (idx) s = idx64 ? reinterpret_cast<const int64_t*>(idx)[r] : (int64_t)reinterpret_cast<const int32_t*>(idx)[r];
+        if (s < 0) s += n_rows;
+        s = s < 0 ? 0 : (s >= n_rows ? n_rows - 1 : s);
+        const float4* in = reinterpret_cast<const float4*>(src + s * ld_src);
+        float4* out = reinterpret_cast<float4*>(dst + r * ld_dst);
+        for (int64_t c0 = threadIdx.x; c0 < ld4; c0 += 4 * nt) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c0 + u * nt < ld4) v[u] = in[c0 + u * nt];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c0 + u * nt < ld4) out[c0 + u * nt] = v[u];
+        }
+    }
+}
+
+hipError_t launch_gather_slim(const float* src, int64_t n_rows, int64_t cols_ld, int64_t ld_src, const void* idx, int idx64,
+                              int64_t n_idx, float* dst, int64_t ld_dst, int blocks, int threads, hipStream_t s)
+{
+    if (n_idx <= 0) return hipSuccess;
+    blocks = (int)std::min<int64_t>(std::max(1, std::min(blocks, 1024)), n_idx);
+    hipLaunchKernelGGL(gather_rows_slim_kernel, dim3(blocks), dim3(threads), 0, s, src, n_rows, ld_src, idx, idx64, cols_ld >> 2,
+                       n_idx, dst, ld_dst);
+    return hipGetLastError();
+}
+
 // ----------------------------------------------------------------------------------
 // bias statistics / cost total / bias update as a kernel of its own (finalize_unit above): one unit
 // per wave.  The single-device fused step runs the same units inside the statistics GEMM instead.

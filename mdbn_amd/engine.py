@@ -144,6 +144,8 @@ class HipEngine(object):
     trace_chain = False         # True: every CD step also records the samples its Gibbs chain feeds onward
     keep_f32 = False            # True: the plane path also stores the float32 copies of ph / nh / nv / samples in the
                                 # CD scratch (CDScratch.P2, V2[B:], hs, vs) for inspection; nothing on the path reads them
+    host_gather_workgroups = 32     # workgroups x threads of the PCIe gather of a host-resident table (mdbn_gather_rows_host)
+    host_gather_threads = 256
     check_indexes = False       # True: also range-check index lists that already live on the device (one sync)
 
     def index_tensor(self, indexes, n_rows=None):
@@ -374,10 +376,10 @@ class HipEngine(object):
             out = self.alloc_matrix(idx.numel(), cols, host.stride(0))
         assert out.shape[0] == idx.numel() and out.shape[1] == cols
         if idx.numel():
-            _lib.check(self.lib.mdbn_gather_rows(
+            _lib.check(self.lib.mdbn_gather_rows_host(
                 self.ctx, self._stream(), C.c_void_p(host.data_ptr()), host.shape[0], cols, host.stride(0),
-                self._p(idx), int(idx.dtype == torch.int64), idx.numel(), self._p(out), out.stride(0)),
-                "mdbn_gather_rows (pinned host source)")
+                self._p(idx), int(idx.dtype == torch.int64), idx.numel(), self._p(out), out.stride(0),
+                int(self.host_gather_workgroups), int(self.host_gather_threads)), "mdbn_gather_rows_host")
         self._keep_alive = (host, idx)           # until the next call: the kernel reads them asynchronously
         return out
 
