@@ -294,10 +294,14 @@ def main():
     n_mb = N_DATA // B_global
 
     def run(n, first):
+        # every call also names the NEXT minibatch, as the reference's trainers can (the epoch's order is drawn up front,
+        # dbn.py:446-458): the single-device step then gathers those rows inside its statistics kernel instead of
+        # launching a gather first -- every step still gathers exactly one minibatch
         cost = None
         for it in range(first, first + n):
-            mb = it % n_mb
-            cost = step_fn(indexes=perm[mb * B_global:(mb + 1) * B_global], momentum=0.0)
+            mb, nb = it % n_mb, (it + 1) % n_mb
+            cost = step_fn(indexes=perm[mb * B_global:(mb + 1) * B_global], momentum=0.0,
+                           next_indexes=perm[nb * B_global:(nb + 1) * B_global])
         return cost
 
     def barrier():
@@ -459,11 +463,9 @@ def main():
 
             def run_host(n, announce):
                 for it in range(n):
-                    mb = it % n_mb
-                    fn_h(indexes=perm[mb * B_global:(mb + 1) * B_global], momentum=0.0)
-                    if announce:
-                        nb = (it + 1) % n_mb
-                        fn_h.prefetch(perm[nb * B_global:(nb + 1) * B_global])
+                    mb, nb = it % n_mb, (it + 1) % n_mb
+                    fn_h(indexes=perm[mb * B_global:(mb + 1) * B_global], momentum=0.0,
+                         next_indexes=perm[nb * B_global:(nb + 1) * B_global] if announce else None)
             res = {}
             for announce in (True, False):
                 run_host(args.warmup, announce)

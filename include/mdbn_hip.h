@@ -100,6 +100,17 @@ typedef struct mdbn_cd_args {
                                * GEMMs are launched balanced on (CUs - comm_cus) workgroups instead of one workgroup
                                * per CU (a collective's kernel takes whole CUs, and a full grid on fewer CUs needs a
                                * second round).  0: one workgroup per CU.  mdbn_set_option("comm_cus") overrides 0.  */
+    /* Gather-ahead (optional; single-device plane path of mdbn_cd_train_step).  A caller that knows the NEXT minibatch
+     * (the trainers do: the epoch's order is drawn up front, src/dbn.py:446-458) passes its indices and a second X2-plane
+     * buffer: the statistics kernel's loader waves then gather those rows into the other buffer beside the MFMA main loop,
+     * and the next call starts without a gather launch (x_buffer flipped, v0_ready = 1).  Same planes as the gather kernel
+     * writes: results are bit-identical with and without.  The library decides per call whether it does it (plane path,
+     * fused early update, keep_f32 = 0, <= 4 rows per workgroup) and reports through *ahead_done. */
+    const void  *next_indexes;   /* [B] indices of the next minibatch (device, same type as indexes), or NULL         */
+    void        *planes_alt;     /* second [3][2B][ldv] bf16 X2-plane buffer (mdbn_planes_alt_bytes), or NULL          */
+    int32_t      x_buffer;       /* X2 planes of THIS step: 0 = inside `planes`, 1 = `planes_alt`                      */
+    int32_t      v0_ready;       /* 1: rows 0..B-1 of that buffer already hold this minibatch (gathered ahead)         */
+    int32_t     *ahead_done;     /* host pointer (nullable): set to 1 when this call gathered next_indexes ahead, else 0 */
 } mdbn_cd_args;
 
 /* Parameter update of src/rbm.py:347-365 from (all-reduced) statistics. */
@@ -165,6 +176,8 @@ int  mdbn_ctx_destroy(mdbn_ctx *ctx);
  *   needs only the old W and the old speed, rbm.py:364-365) is applied by the kernel's loader waves during the main loop,
  *   the epilogue only forms the new speed; bitwise the same parameters and speeds (needs lambda_1 == 0 and weightcost == 0
  *   or a frozen W0, else the whole rule stays in the epilogue).
+ * "gather_ahead" (default 1): honour mdbn_cd_args.next_indexes (the next minibatch gathered inside the statistics
+ *   kernel); 0 = every step launches its own gather.
  * "comm_cus" (default 0): CUs left to a collective that runs beside the step when mdbn_cd_args.comm_cus is 0 (see
  *   there); "bal_blocks" (tests): the number of workgroups of a balanced launch itself.
  * "epilogue_threads": threads per block of the activation epilogue launch, 0 = auto, 64, 128 or 256.
@@ -200,6 +213,8 @@ int  mdbn_padded_ld(int64_t cols, int64_t *ld);
 /* bytes of plane scratch (mdbn_cd_args.planes) for a minibatch of B rows: planes of [v0; nv], [ph; -nh],
  * the hidden and the visible sample */
 int  mdbn_planes_bytes(int64_t B, int64_t ldv, int64_t ldh, int64_t *bytes);
+/* bytes of the second X2-plane buffer of the gather-ahead (mdbn_cd_args.planes_alt) */
+int  mdbn_planes_alt_bytes(int64_t B, int64_t ldv, int64_t *bytes);
 /* Does the plane path of mdbn_cd_step / mdbn_cd_train_step serve this shape under the CURRENT options (whole 128-row /
  * 128-column tiles, ldv == V, ldh == H, "gemm_planes" on, B * V * H >= "planes_min_work")?  The one statement of the
  * rule: a host allocates mdbn_cd_args.planes / W_planes for exactly these shapes.  (Per call the step also needs CD

@@ -27,7 +27,9 @@ class CdArgs(C.Structure):
                 ("stats", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
                 ("rng", Rng), ("trace_h", C.c_void_p), ("trace_v", C.c_void_p),
                 ("planes", C.c_void_p), ("planes_bytes", C.c_int64), ("W_planes", C.c_void_p),
-                ("W_planes_valid", C.c_int32), ("comm_cus", C.c_int32)]
+                ("W_planes_valid", C.c_int32), ("comm_cus", C.c_int32),
+                ("next_indexes", C.c_void_p), ("planes_alt", C.c_void_p), ("x_buffer", C.c_int32),
+                ("v0_ready", C.c_int32), ("ahead_done", C.POINTER(C.c_int32))]
 
 
 class UpdateArgs(C.Structure):
@@ -63,6 +65,7 @@ SIGNATURES = {
     "mdbn_workspace_bytes": [_i64, _i64, _i64, C.POINTER(_i64)],
     "mdbn_padded_ld": [_i64, C.POINTER(_i64)],
     "mdbn_planes_bytes": [_i64, _i64, _i64, C.POINTER(_i64)],
+    "mdbn_planes_alt_bytes": [_i64, _i64, C.POINTER(_i64)],
     "mdbn_planes_eligible": [_i64, _i64, _i64, _i64, _i64, C.POINTER(_i32)],
     "mdbn_split_planes": [_vp, _vp, _vp, _i64, _i64, _vp],
     "mdbn_stats_floats": [_i64, _i64, _i64, C.POINTER(_i64)],

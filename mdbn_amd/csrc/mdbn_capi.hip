@@ -203,6 +203,8 @@ static int g_opt_planes_mfma = 16;
 // mdbn_set_option("early_w"): the statistics GEMM's loader waves apply the parameter half of the fused update during the
 // main loop (W' needs only the old W and the old speed), the epilogue only forms the new speed (default on; same bits)
 static int g_opt_early_w = 1;
+// mdbn_set_option("gather_ahead"): honour mdbn_cd_args.next_indexes (default on; same bits)
+static int g_opt_gather_ahead = 1;
 // mdbn_set_option("bf16_inputs"): REPORTING mode of BASELINE configs[1] ("bf16/fp32"): the plane GEMMs use only the
 // leading bf16 piece of every operand (inputs truncated to bf16, f32 accumulation, one product instead of six).
 // Probabilities then carry ~4e-3 of error: never used for a parity claim, off by default.
@@ -634,13 +636,22 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
 {
     const int64_t B = a->B, V = a->V, H = a->H, ldv = V, ldh = H;
     PlaneBufs pb;
+    unsigned short* Xother = nullptr;        // the X2 buffer this step does NOT use (gather-ahead target)
     {
         unsigned short* p = reinterpret_cast<unsigned short*>(a->planes);
         pb.Xp = p; pb.px = 2 * B * ldv; p += 6 * B * ldv;
         pb.Pp = p; pb.pp = 2 * B * ldh; p += 6 * B * ldh;
         pb.hsp = p; p += B * ldh;
         pb.vsp = p;
+        if (a->planes_alt) {
+            REQUIRE(aligned16(a->planes_alt), "planes_alt not 16-byte aligned");
+            unsigned short* alt = reinterpret_cast<unsigned short*>(a->planes_alt);
+            if (a->x_buffer) { Xother = pb.Xp; pb.Xp = alt; } else Xother = alt;
+        } else {
+            REQUIRE(a->x_buffer == 0, "x_buffer = 1 needs planes_alt");
+        }
     }
+    if (a->ahead_done) *a->ahead_done = 0;
     unsigned short* Wp = reinterpret_cast<unsigned short*>(a->W_planes);    // (split on entry if stale: cd_step_impl)
     // float32 copies nobody on the path reads (the GEMMs take planes, the bias statistics their column partials)
     const bool keep = a->keep_f32 != 0 || a->trace_h != nullptr || a->trace_v != nullptr;
@@ -652,8 +663,10 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     // x = train_set_x[indexes] (dbn.py:307), as f32 (cost target, bias statistics) and as planes
     // (without `keep` the float32 copy of v0 is not made either: its one reader, the reconstruction-cost / bias-statistics
     // target of the last visible pass, reads the dataset rows through the index instead)
-    HIP_OK(launch_gather_planes(a->data, a->n_data, ldv, ldv, a->indexes, a->index_is_64, B, keep ? v0 : nullptr, ldv, pb.Xp,
-                                pb.px, s));
+    // (gathered ahead by the previous call's statistics kernel: the planes are already there)
+    if (!(a->v0_ready && !keep))
+        HIP_OK(launch_gather_planes(a->data, a->n_data, ldv, ldv, a->indexes, a->index_is_64, B, keep ? v0 : nullptr, ldv, pb.Xp,
+                                    pb.px, s));
 
     auto key = [&](uint32_t draw) { PhiloxKey k = make_key(a->rng, draw); return k; };
     {   // positive phase: ph_mean (+ planes), h0 sample (f32 for the taps, plane for the chain)   (rbm.py:303)
@@ -735,6 +748,19 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
         // conditions of the update (no lambda_1; weight cost off or on a frozen snapshot) and >= 12 stages to spread over
         g.upd.early = g_opt_early_w && upd->lambda_1 == 0.f && (upd->weightcost == 0.f || upd->W0 != nullptr) &&
                       2 * B / 32 >= 12 && g_opt_planes_mfma == 16 && !g_opt_bf16_inputs;
+        // gather-ahead of the next minibatch by the same loader waves, after their W chunks: one 256-octet pass of one row
+        // per stage; every workgroup takes rpw consecutive rows
+        if (g.upd.early && g_opt_gather_ahead && a->next_indexes && Xother && !keep) {
+            const int nwg = g.tiles_m * g.tiles_n, nt = (int)(2 * B / 32);
+            const int rpw = (int)((B + nwg - 1) / nwg), passes = (int)((ldv / 8 + 255) / 256);
+            if (rpw <= 4 && 16 / (nt >= 20 ? 1 : 2) + rpw * passes <= nt - 3) {
+                g.ga.src = a->data; g.ga.n_rows = a->n_data; g.ga.ld_src = ldv;
+                g.ga.idx = a->next_indexes; g.ga.idx64 = a->index_is_64;
+                g.ga.B = (int)B; g.ga.rpw = rpw; g.ga.passes = passes;
+                g.ga.P = Xother; g.ga.plane_stride = pb.px; g.ga.ld = ldv;
+                if (a->ahead_done) *a->ahead_done = 1;
+            }
+        }
         HIP_OK(timed_gemm_planes(LAY_MN, LAY_MN, g, s));
         return MDBN_OK;
     }
@@ -912,6 +938,10 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
         g_opt_planes_mfma = (int)value;
         return MDBN_OK;
     }
+    if (strcmp(name, "gather_ahead") == 0) {
+        g_opt_gather_ahead = value != 0;
+        return MDBN_OK;
+    }
     if (strcmp(name, "early_w") == 0) {
         g_opt_early_w = value != 0;
         return MDBN_OK;
@@ -1015,6 +1045,13 @@ int mdbn_planes_eligible(int64_t B, int64_t V, int64_t H, int64_t ldv, int64_t l
 {
     REQUIRE(eligible != nullptr, "eligible is NULL");
     *eligible = plane_shape_ok(B, V, H, ldv, ldh) ? 1 : 0;
+    return MDBN_OK;
+}
+
+int mdbn_planes_alt_bytes(int64_t B, int64_t ldv, int64_t* bytes)
+{
+    REQUIRE(bytes != nullptr && B > 0 && ldv > 0, "bad arguments");
+    *bytes = 2 * 6 * B * ldv;
     return MDBN_OK;
 }
 
@@ -1332,6 +1369,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
     Workspace ws;
     CHECK(carve(a->workspace, a->workspace_bytes, B, V, H, ws, true));
     hipStream_t s = (hipStream_t)stream;
+    if (a->ahead_done) *a->ahead_done = 0;
     if (upd) {
         REQUIRE(upd->stats == a->stats && upd->W == a->W && upd->ldh == ldh && upd->ldv == ldv && upd->V == V && upd->H == H,
                 "update arguments do not match the step's buffers");

@@ -106,6 +106,15 @@ struct GemmArgs {
 
 
 // GEMM on pre-split bf16 planes (mdbn_planes.hip): whole 128x128 tiles and 32-deep stages only
+// Gather-ahead (statistics GEMM with the early parameter half): the loader waves also gather the NEXT minibatch's rows
+// into the planes of the other X2 buffer, so the next step starts without a gather launch.
+struct GatherAhead {
+    const float* src; int64_t n_rows, ld_src;      // the training matrix
+    const void* idx; int idx64;                    // [B] indices of the next minibatch (device); NULL = off
+    int B, rpw, passes;                            // rows; rows per workgroup (<= 4); 256-octet passes per row
+    unsigned short* P; int64_t plane_stride, ld;   // destination planes [3][.][ld] (rows 0..B-1 of the other buffer)
+};
+
 struct PlaneGemmArgs {
     const unsigned short* A; int64_t lda, pa;   // planes [ap][.][lda]; pa = elements between planes
     const unsigned short* B; int64_t ldb, pb;   // planes [3][.][ldb]
@@ -126,6 +135,7 @@ struct PlaneGemmArgs {
     UpdEpi upd;
     int fin_enabled;
     FinArgs fin;
+    GatherAhead ga;
 };
 
 // balanced launches (mdbn_planes.hip): U units in (tile, stage) order, workgroup w of P takes [w U / P, (w + 1) U / P)

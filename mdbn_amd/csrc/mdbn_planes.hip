@@ -151,7 +151,25 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
     int chunk = 0;                                   // EARLYW: next 8-row chunk of the W tile (16 in all)
     const int lt = w * 64 + lane;
     const int cpi = nt >= 20 ? 1 : 2;                // chunks per stage: all 16 done well before the loop ends (host: nt >= 12)
-    (void)chunk; (void)lt; (void)cpi;
+    // gather-ahead: this workgroup's rows of the NEXT minibatch, one 256-octet pass of one row per stage
+    int unit = 0, nunits = 0;
+    int64_t srow[4] = {0, 0, 0, 0};
+    if constexpr (EARLYW) {
+        if (g.ga.idx) {
+            nunits = g.ga.rpw * g.ga.passes;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = (int)blockIdx.x * g.ga.rpw + i;
+                if (i < g.ga.rpw && r < g.ga.B) {
+                    int64_t sidx = g.ga.idx64 ? reinterpret_cast<const int64_t*>(g.ga.idx)[r]
+                                              : (int64_t)reinterpret_cast<const int32_t*>(g.ga.idx)[r];
+                    if (sidx < 0) sidx += g.ga.n_rows;
+                    srow[i] = sidx < 0 ? 0 : (sidx >= g.ga.n_rows ? g.ga.n_rows - 1 : sidx);     // as gather_planes_kernel
+                }
+            }
+        }
+    }
+    (void)chunk; (void)lt; (void)cpi; (void)unit; (void)nunits; (void)srow;
     for (int it = 0; it < nt; ++it) {
         // stage it + 1 must have landed before the MFMA waves pass barrier `it`; stage it + 2 may still fly
         if (it + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
@@ -175,6 +193,34 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
                     }
                     continue;
                 }
+                if (unit < nunits) {                 // (wave-uniform) one pass of one row of the next minibatch
+                    const int i = unit / g.ga.passes, pass = unit - i * g.ga.passes;
+                    const int r = (int)blockIdx.x * g.ga.rpw + i;
+                    const int64_t c = (int64_t)pass * 256 + lt, ld8 = g.ga.ld >> 3;
+                    const bool live = r < g.ga.B && c < ld8;
+                    const int64_t sr = i == 0 ? srow[0] : i == 1 ? srow[1] : i == 2 ? srow[2] : srow[3];
+                    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                    if (live) {
+                        v0 = reinterpret_cast<const float4*>(g.ga.src + sr * g.ga.ld_src)[2 * c];
+                        v1 = reinterpret_cast<const float4*>(g.ga.src + sr * g.ga.ld_src)[2 * c + 1];
+                    }
+                    PL_ISSUE(it + 3);
+                    if (live) {
+                        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                        unsigned short q[3][8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) split3(x[j], q[0][j], q[1][j], q[2][j]);
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            uint4 wv;
+                            wv.x = q[p][0] | ((unsigned)q[p][1] << 16); wv.y = q[p][2] | ((unsigned)q[p][3] << 16);
+                            wv.z = q[p][4] | ((unsigned)q[p][5] << 16); wv.w = q[p][6] | ((unsigned)q[p][7] << 16);
+                            *reinterpret_cast<uint4*>(g.ga.P + p * g.ga.plane_stride + (int64_t)r * g.ga.ld + 8 * c) = wv;
+                        }
+                    }
+                    ++unit;
+                    continue;
+                }
             }
             PL_ISSUE(it + 3);
         }
@@ -182,6 +228,18 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
     if constexpr (EARLYW) {
         if (g.upd.early) {
             for (; chunk < 16; ++chunk) early_w_apply(g.upd, early_w_load(g.upd, m0, n0, chunk, lt));   // (never with nt >= 12)
+            for (; unit < nunits; ++unit) {          // (the host sizes the units to fit the loop; kept for safety)
+                const int i = unit / g.ga.passes, pass = unit - i * g.ga.passes;
+                const int r = (int)blockIdx.x * g.ga.rpw + i;
+                const int64_t c = (int64_t)pass * 256 + lt;
+                if (r < g.ga.B && c < (g.ga.ld >> 3)) {
+                    const int64_t sr = i == 0 ? srow[0] : i == 1 ? srow[1] : i == 2 ? srow[2] : srow[3];
+                    const float4 v0 = reinterpret_cast<const float4*>(g.ga.src + sr * g.ga.ld_src)[2 * c];
+                    const float4 v1 = reinterpret_cast<const float4*>(g.ga.src + sr * g.ga.ld_src)[2 * c + 1];
+                    store_planes4(g.ga.P, g.ga.plane_stride, (int64_t)r * g.ga.ld + 8 * c, v0);
+                    store_planes4(g.ga.P, g.ga.plane_stride, (int64_t)r * g.ga.ld + 8 * c + 4, v1);
+                }
+            }
             // the MFMA waves are still on the last stage: fetch this lane's share of the old speed (and of the frozen W0)
             // for the speed epilogue now, so that only its stores follow the main loop
 #pragma unroll

@@ -218,7 +218,7 @@ class DBN(object):
         bernoulli = not isinstance(self.rbm_layers[i], GRBM)
         stop = _Patience(epoch_budget, n_batches)
         self._print('Validation frequency: %d' % stop.every)
-        announce = getattr(step_fn, "prefetch", None)      # step functions are duck-typed: fn(indexes=, momentum=, lr=)
+        hinted = getattr(step_fn, "accepts_next_indexes", False)     # step functions are duck-typed: fn(indexes=, momentum=, lr=)
         records = []
         for epoch in range(1, epoch_budget + 1):
             # Gaussian layer: no momentum at all; Bernoulli layers 0.6, 0.9 from the sixth epoch (dbn.py:430-433,452-453)
@@ -227,9 +227,10 @@ class DBN(object):
             order = self.engine.index_tensor(numpy.concatenate(batches))
             bounds = numpy.cumsum([0] + [len(b) for b in batches])
             for mb in range(len(batches)):
-                cost = step_fn(indexes=order[bounds[mb]:bounds[mb + 1]], momentum=momentum, lr=lr)
-                if announce is not None and mb + 1 < len(batches):     # a host-resident table starts moving the next rows now
-                    announce(order[bounds[mb + 1]:bounds[mb + 2]])
+                hint = {}
+                if hinted and mb + 1 < len(batches):    # the next minibatch of the epoch (a pure hint: StepFunction.__call__)
+                    hint["next_indexes"] = order[bounds[mb + 1]:bounds[mb + 2]]
+                cost = step_fn(indexes=order[bounds[mb]:bounds[mb + 1]], momentum=momentum, lr=lr, **hint)
                 it = (epoch - 1) * n_batches + mb
                 if stop.due(it):
                     cost = float(cost)

@@ -74,6 +74,18 @@ class CDScratch(object):
             n = C.c_int64()
             _lib.check(engine.lib.mdbn_planes_bytes(B, ldv, ldh, C.byref(n)), "mdbn_planes_bytes")
             self.planes = torch.empty(n.value // 2, dtype=torch.int16, device=engine.device)
+        # gather-ahead (mdbn_cd_args.next_indexes): second X2-plane buffer (made on first use), the buffer the current
+        # step uses, and what the last step gathered ahead: (data pointer, data version, index tensor kept alive, buffer)
+        self.planes_alt = None
+        self.x_buffer = 0
+        self.ahead = None
+
+    def alt_planes(self, engine, ldv):
+        if self.planes_alt is None:
+            n = C.c_int64()
+            _lib.check(engine.lib.mdbn_planes_alt_bytes(self.B, ldv, C.byref(n)), "mdbn_planes_alt_bytes")
+            self.planes_alt = torch.empty(n.value // 2, dtype=torch.int16, device=engine.device)
+        return self.planes_alt
 
 
 class HipEngine(object):
@@ -384,8 +396,13 @@ class HipEngine(object):
         return out
 
     # ------------------------------------------------------------------ CD-k
+    @staticmethod
+    def _same_index_tensor(a, b):
+        return (a is b) or (a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.numel() == b.numel()
+                            and a.dtype == b.dtype)
+
     def _cd_args(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent, add_noise, stats_slot,
-                 sample_stats=False, stats=None, comm_cus=0):
+                 sample_stats=False, stats=None, comm_cus=0, next_indexes=None):
         data = self.as_matrix(data)
         V, H = W.shape
         assert data.shape[1] == V, "data has %d columns, RBM has %d visibles" % (data.shape[1], V)
@@ -423,13 +440,33 @@ class HipEngine(object):
         if sc.planes is not None:
             a.planes, a.planes_bytes = sc.planes.data_ptr(), sc.planes.numel() * 2
         a.comm_cus = int(comm_cus)
+        # gather-ahead: was this minibatch gathered by the previous step's statistics kernel?  (same matrix, unchanged since,
+        # same index list: the announced tensor has been kept alive, so an equal address means the same list)
+        ahead, sc.ahead = sc.ahead, None
+        keep = [data, idx, ws]
+        if sc.planes is not None and idx is not None and not self.keep_f32 and not self.trace_chain:
+            if ahead is not None and ahead[0] == data.data_ptr() and ahead[1] == data._version and \
+                    self._same_index_tensor(ahead[2], idx):
+                sc.x_buffer = ahead[3]
+                a.v0_ready = 1
+            if sc.planes_alt is not None or next_indexes is not None:
+                a.planes_alt = sc.alt_planes(self, ldv).data_ptr()
+                a.x_buffer = sc.x_buffer
+            if next_indexes is not None:
+                nxt = self.index_tensor(next_indexes, data.shape[0])
+                if nxt.numel() == B and nxt.dtype == idx.dtype:
+                    a.next_indexes = nxt.data_ptr()
+                    self._ahead_flag = C.c_int32(0)
+                    a.ahead_done = C.pointer(self._ahead_flag)
+                    keep.append(nxt)
+                    sc._announce = (data.data_ptr(), data._version, nxt, 1 - sc.x_buffer)
         if self.trace_chain:
             if sc.trace_h is None or sc.trace_h.shape[0] != k + 1:
                 sc.trace_h = torch.zeros((k + 1, B, ldh), dtype=torch.float32, device=self.device)
                 sc.trace_v = None if gauss else torch.zeros((k, B, ldv), dtype=torch.float32, device=self.device)
             a.trace_h = sc.trace_h.data_ptr()
             a.trace_v = sc.trace_v.data_ptr() if sc.trace_v is not None else None
-        return a, stats, sc, (data, idx, ws)        # keep the tensors alive until enqueued
+        return a, stats, sc, keep                   # keep the tensors alive until enqueued
 
     def cd_step(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent=None, add_noise=False,
                 stats_slot=0, sample_stats=False, stats=None, comm_cus=0):
@@ -474,18 +511,21 @@ class HipEngine(object):
 
     def cd_train_step(self, data, indexes, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, gauss, k,
                       rng, lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale,
-                      sample_stats=False):
+                      sample_stats=False, next_indexes=None):
         """The whole single-device step function (mdbn_cd_train_step): cd_step + update, with the
         finalize / parameter half of the update overlapped under the statistics GEMM.  Returns the
         monitoring cost (0-d device tensor)."""
         a, stats, sc, _keep = self._cd_args(data, indexes, W, hbias, vbias, gauss, k, rng, None, False, 0,
-                                            sample_stats)
+                                            sample_stats, next_indexes=next_indexes)
+        sc._announce, announce = None, getattr(sc, "_announce", None)
         u, cost = self._update_args(W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats, lr,
                                     lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale,
                                     0, a.ldv)
         _lib.check(self.lib.mdbn_cd_train_step(self.ctx, self._stream(), C.byref(a), C.byref(u)),
                    "mdbn_cd_train_step")
         self._w_planes_written(W)
+        if announce is not None and a.ahead_done and self._ahead_flag.value:
+            sc.ahead = announce              # the next call finds its rows in the other X2 buffer
         return cost
 
     def apply_update(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats,

@@ -92,6 +92,8 @@ class StepFunction(object):
     value stays bit-identical to the synchronous order.  ``flush()`` completes the deferred
     part (called automatically when speeds or the cost are read)."""
 
+    accepts_next_indexes = True         # fn(indexes=, momentum=, lr=, next_indexes=): the trainers pass the hint when they can
+
     def __init__(self, updates, train_set_x, input_fn=None, name=None, data_parallel="auto", overlap=True):
         self.plan = updates
         self.rbm = updates.rbm
@@ -240,7 +242,10 @@ class StepFunction(object):
         """Complete the deferred speed update of the last overlapped step (no-op otherwise)."""
         self._complete_pending()
 
-    def __call__(self, indexes=None, momentum=0.0, lr=None):
+    def __call__(self, indexes=None, momentum=0.0, lr=None, next_indexes=None):
+        """``next_indexes``: the minibatch of the NEXT call, when the caller knows it (the trainers do: the epoch's order
+        is drawn up front, dbn.py:446-458) -- a pure hint: the single-device plane path then gathers those rows inside
+        this step's statistics kernel, a host-resident table starts moving them over PCIe; results never change."""
         p, rbm, eng = self.plan, self.rbm, self.engine
         if lr is None:
             lr = p.lr
@@ -288,8 +293,12 @@ class StepFunction(object):
                                     rbm.vbias_speed.tensor, rbm.gauss, p.k,
                                     RngAddr(rbm.theano_rng.seed, rbm.stream_id, step, 0, lo),
                                     lr, p.lambda_1, p.lambda_2, p.weightcost, momentum, batch_size,
-                                    n_global, cost_scale, sample_stats=p.symbolic_grad)
+                                    n_global, cost_scale, sample_stats=p.symbolic_grad,
+                                    **({"next_indexes": next_indexes} if (next_indexes is not None and idx is not None
+                                                                          and staged_slot is None) else {}))
             rbm._n_updates += 1
+            if next_indexes is not None and staged_slot is not None:
+                self.prefetch(next_indexes)
             if self.nan_guard:
                 self._check_finite(out)
             return out
@@ -630,10 +639,11 @@ class RBM(object):
             costs, start, total = [], 0, 0.0
             for b_i, batch_indexes in enumerate(minibatches):
                 n = len(batch_indexes)
-                costs.append(train_rbm(dev_idx[start:start + n], momentum))
+                # the next minibatch of the epoch as a hint (gathered inside this step's statistics kernel, or started
+                # over PCIe for a host-resident table)
+                nxt = dev_idx[start + n:start + n + len(minibatches[b_i + 1])] if b_i + 1 < len(minibatches) else None
+                costs.append(train_rbm(dev_idx[start:start + n], momentum, next_indexes=nxt))
                 start += n
-                if b_i + 1 < len(minibatches):      # a host-resident table starts moving the next rows now
-                    train_rbm.prefetch(dev_idx[start:start + len(minibatches[b_i + 1])])
                 if len(costs) >= 256:
                     total = total + torch.stack([c.reshape(()) for c in costs]).sum()
                     costs = []

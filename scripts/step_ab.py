@@ -20,8 +20,8 @@ fn = mdbn_amd.function(up, data)
 perm = torch.from_numpy(np.random.RandomState(1).permutation(N)).to(eng.device)
 def run(n):
     for it in range(n):
-        mb = it % (N // B)
-        fn(indexes=perm[mb * B:(mb + 1) * B], momentum=0.0)
+        mb, nb = it % (N // B), (it + 1) % (N // B)
+        fn(indexes=perm[mb * B:(mb + 1) * B], momentum=0.0, next_indexes=perm[nb * B:(nb + 1) * B])
 res = {v: [] for v in values}
 run(20); eng.synchronize()
 for rnd in range(5):

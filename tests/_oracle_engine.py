@@ -169,7 +169,7 @@ class OracleEngine(object):
 
     def cd_train_step(self, data, indexes, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, gauss, k,
                       rng, lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale,
-                      sample_stats=False):
+                      sample_stats=False, next_indexes=None):
         stats, _ = self.cd_step(data, indexes, W, hbias, vbias, gauss, k, rng, sample_stats=sample_stats)
         return self.apply_update(W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats, lr, lambda_1,
                                  lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale)

@@ -337,3 +337,41 @@ def test_early_parameter_half_is_bitwise_the_epilogue_update(hip_engine, gauss, 
     for other in runs[1:]:
         for key in runs[0]:
             assert np.array_equal(runs[0][key], other[key]), key
+
+
+@pytest.mark.parametrize("gauss,V,H,B", [(True, 4096, 1024, 512), (False, 2048, 2048, 512)])
+def test_gather_ahead_is_bitwise_the_gather_launch(built_lib, gauss, V, H, B):
+    """fn(indexes=, next_indexes=): the statistics kernel's loader waves gather the next minibatch into the other X2-plane
+    buffer, the next step starts without a gather launch.  A product-default engine, 10 steps: with the hint every step,
+    with a WRONG hint every third step (the step must then gather for itself), and without hints -- identical parameters,
+    speeds and costs bit for bit; and the hinted run really took the ahead path."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import mdbn_amd
+    eng = mdbn_amd.HipEngine()
+    eng.set_planes_min_work(1 << 30)
+    try:
+        runs, took = [], []
+        for mode in ("hint", "wrong", "none"):
+            rs = np.random.RandomState(11)
+            N = 4 * B
+            data = rs.normal(size=(N, V)).astype(np.float32) if gauss else (rs.uniform(size=(N, V)) < 0.3).astype(np.float32)
+            cls = mdbn_amd.GRBM if gauss else mdbn_amd.RBM
+            rbm = cls(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123), theano_rng=mdbn_amd.RandomStreams(5), engine=eng)
+            hp = dict(lr=0.001, lambda_2=0.1) if gauss else dict(lr=0.05, weightcost=2e-4)
+            _, up = rbm.get_cost_updates(k=1, batch_size=B, **hp)
+            fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=eng), data_parallel=None)
+            batches = [eng.index_tensor(rs.permutation(N)[:B]) for _ in range(11)]
+            costs, ahead = [], 0
+            for t in range(10):
+                nxt = None if mode == "none" else (batches[(t + 5) % 11] if (mode == "wrong" and t % 3 == 1) else batches[t + 1])
+                costs.append(float(fn(indexes=batches[t], momentum=0.5, next_indexes=nxt)))
+                ahead += int(eng.last_scratch.ahead is not None)
+            took.append(ahead)
+            runs.append(dict(costs=np.array(costs), W=rbm.W.get_value(), Ws=rbm.W_speed.get_value(), vb=rbm.vbias.get_value()))
+        assert took[0] == 10 and took[1] == 10 and took[2] == 0, took       # (a wrong hint is still gathered, just not used)
+        for other in runs[1:]:
+            for key in runs[0]:
+                assert np.array_equal(runs[0][key], other[key]), key
+    finally:
+        eng.set_planes_min_work(0)
