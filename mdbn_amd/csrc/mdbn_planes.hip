@@ -148,98 +148,156 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
     PL_STAMP(3);
     __builtin_amdgcn_s_barrier();                    // stage 0 landed
 #endif
-    int chunk = 0;                                   // EARLYW: next 8-row chunk of the W tile (16 in all)
+    // EARLYW side work, one ITEM per stage: first the chunk items of the W tile (CPI 8-row chunks each, 16 / CPI items),
+    // then the gather-ahead units (one 256-octet pass of one row of the next minibatch each).  An item's loads are issued
+    // ONE STAGE BEFORE it is applied, ahead of that stage's DMAs, so a whole MFMA stage (~1.1 us) hides their HBM latency;
+    // they are applied after the DMAs of the following stage.  hipcc cannot express that: with loads, stores and LDS-DMA
+    // pending together its waitcnt insertion falls back to vmcnt(0) before the first use (seen in the ISA: every apply then
+    // waited for the loads just issued and for the stage's DMAs).  So the item loads are inline-asm loads hipcc does not
+    // count, each consumed behind a counted wait statement that names its destination registers "+v"
+    // (cdna_hip_programming.md 5.7, form (ii)): vmcnt(PER + younger item loads) = this stage's DMAs and the next item's
+    // loads may fly, everything older -- the item's own loads, issued a stage ago -- has landed (VMEM operations retire in
+    // issue order).  The phases are straight-line code (fully unrolled, loads unconditional at valid addresses), so no
+    // register that a load is still writing is ever copied or merged; its stores are compiler-visible and younger than the
+    // stage they follow, so the counted waits of the DMA ring stay valid.  The host sizes the items to fit the stages that
+    // issue a DMA.
     const int lt = w * 64 + lane;
-    const int cpi = nt >= 20 ? 1 : 2;                // chunks per stage: all 16 done well before the loop ends (host: nt >= 12)
-    // gather-ahead: this workgroup's rows of the NEXT minibatch, one 256-octet pass of one row per stage
-    int unit = 0, nunits = 0;
-    int64_t srow[4] = {0, 0, 0, 0};
+    int it = 0;
+#define LD_SYNC()                                                                             \
+    do {                                                                                      \
+        if (it + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");          \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 \
+        __builtin_amdgcn_s_barrier();                /* every read of stage `it` is done: its slot is free */ \
+    } while (0)
+#define ASM_LOAD4(DST, PTR) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(DST) : "v"(PTR) : "memory")
+// the counted wait ahead of an item's first consumer: a wait-only statement + a scheduling barrier (5.7, form (iii)).
+// (Form (ii), naming the destinations "+v", made hipcc COPY them into fresh registers ahead of the wait on one path --
+// reading registers whose load had not landed; found by the ISA audit, scripts/experiments/audit_asm_loads.py.)
+#define ASM_WAIT(N) do { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
     if constexpr (EARLYW) {
-        if (g.ga.idx) {
-            nunits = g.ga.rpw * g.ga.passes;
+        if (g.upd.early) {
+            const float decay = upd_decay(g.upd.lr, g.upd.l2);
+            const int64_t lane_off = (int64_t)(m0 + (lt >> 5)) * g.upd.ld + n0 + 4 * (lt & 31);
+#define CW_STORE(WV, SV, CH)                                                                  \
+    do {                                                                                      \
+        const int64_t off_ = lane_off + (int64_t)8 * (CH) * g.upd.ld;                         \
+        const float4 w4_ = make_float4(WV[0], WV[1], WV[2], WV[3]), s4_ = make_float4(SV[0], SV[1], SV[2], SV[3]); \
+        float4 wn_;                                                                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) setc(wn_, j_, upd_param(comp(w4_, j_), decay, comp(s4_, j_), g.upd.lr)); \
+        *reinterpret_cast<float4*>(g.upd.W + off_) = wn_;                                     \
+        if (g.upd.Wp) store_planes4(g.upd.Wp, g.upd.wp_stride, off_, wn_);                    \
+    } while (0)
+            if (nt >= 20) {                          // one chunk per stage: 16 items
+                pf32x4 cw[17], cs[17];
+                ASM_LOAD4(cw[0], g.upd.W + lane_off); ASM_LOAD4(cs[0], g.upd.Ws + lane_off);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = (int)blockIdx.x * g.ga.rpw + i;
-                if (i < g.ga.rpw && r < g.ga.B) {
+                for (int i = 0; i < 16; ++i) {
+                    LD_SYNC();
+                    if (i + 1 < 16) {
+                        ASM_LOAD4(cw[i + 1], g.upd.W + lane_off + (int64_t)8 * (i + 1) * g.upd.ld);
+                        ASM_LOAD4(cs[i + 1], g.upd.Ws + lane_off + (int64_t)8 * (i + 1) * g.upd.ld);
+                    }
+                    PL_ISSUE(it + 3);
+                    if (i + 1 < 16) ASM_WAIT(PER + 2); else ASM_WAIT(PER);
+                    CW_STORE(cw[i], cs[i], i);
+                    ++it;
+                }
+            } else {                                 // two chunks per stage: 8 items (host: nt >= 12)
+                pf32x4 cw[18], cs[18];
+                ASM_LOAD4(cw[0], g.upd.W + lane_off); ASM_LOAD4(cs[0], g.upd.Ws + lane_off);
+                ASM_LOAD4(cw[1], g.upd.W + lane_off + (int64_t)8 * g.upd.ld); ASM_LOAD4(cs[1], g.upd.Ws + lane_off + (int64_t)8 * g.upd.ld);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    LD_SYNC();
+                    if (i + 1 < 8) {
+                        ASM_LOAD4(cw[2 * i + 2], g.upd.W + lane_off + (int64_t)8 * (2 * i + 2) * g.upd.ld);
+                        ASM_LOAD4(cs[2 * i + 2], g.upd.Ws + lane_off + (int64_t)8 * (2 * i + 2) * g.upd.ld);
+                        ASM_LOAD4(cw[2 * i + 3], g.upd.W + lane_off + (int64_t)8 * (2 * i + 3) * g.upd.ld);
+                        ASM_LOAD4(cs[2 * i + 3], g.upd.Ws + lane_off + (int64_t)8 * (2 * i + 3) * g.upd.ld);
+                    }
+                    PL_ISSUE(it + 3);
+                    if (i + 1 < 8) ASM_WAIT(PER + 4); else ASM_WAIT(PER);
+                    CW_STORE(cw[2 * i], cs[2 * i], 2 * i);
+                    CW_STORE(cw[2 * i + 1], cs[2 * i + 1], 2 * i + 1);
+                    ++it;
+                }
+            }
+#undef CW_STORE
+            if (g.ga.idx) {
+                // gather-ahead: rows blockIdx * rpw .. of the next minibatch, <= 4 units (host); source rows resolved once
+                // (as gather_planes_kernel).  The loads are unconditional at clamped, valid addresses: only stores are predicated.
+                int64_t srow[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int r = (int)blockIdx.x * g.ga.rpw + (i < g.ga.rpw ? i : 0);
+                    r = r < g.ga.B ? r : g.ga.B - 1;
                     int64_t sidx = g.ga.idx64 ? reinterpret_cast<const int64_t*>(g.ga.idx)[r]
                                               : (int64_t)reinterpret_cast<const int32_t*>(g.ga.idx)[r];
                     if (sidx < 0) sidx += g.ga.n_rows;
-                    srow[i] = sidx < 0 ? 0 : (sidx >= g.ga.n_rows ? g.ga.n_rows - 1 : sidx);     // as gather_planes_kernel
+                    srow[i] = sidx < 0 ? 0 : (sidx >= g.ga.n_rows ? g.ga.n_rows - 1 : sidx);
                 }
+                const int64_t ld8 = g.ga.ld >> 3;
+                const int nunits = g.ga.rpw * g.ga.passes;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the index loads above are hipcc's: settle them before counting again)
+                pf32x4 ga[4], gb[4];
+#define GU_ADDR(U)                                                                            \
+    const int i_r = (U) / g.ga.passes, pass_ = (U) - i_r * g.ga.passes;                       \
+    const int64_t c_ = (int64_t)pass_ * 256 + lt, cc_ = c_ < ld8 ? c_ : ld8 - 1;              \
+    const int64_t sr_ = i_r == 0 ? srow[0] : i_r == 1 ? srow[1] : i_r == 2 ? srow[2] : srow[3]; \
+    const float* p_ = g.ga.src + sr_ * g.ga.ld_src + 8 * cc_;
+#define GU_LOAD(K, U) do { GU_ADDR(U) ASM_LOAD4(ga[K], p_); ASM_LOAD4(gb[K], p_ + 4); } while (0)
+#define GU_APPLY(K, U)                                                                        \
+    do {                                                                                      \
+        const int i_r = (U) / g.ga.passes, pass_ = (U) - i_r * g.ga.passes;                   \
+        const int r_ = (int)blockIdx.x * g.ga.rpw + i_r;                                      \
+        const int64_t c_ = (int64_t)pass_ * 256 + lt;                                         \
+        if (r_ < g.ga.B && c_ < ld8) {                                                        \
+            const float v_[8] = {ga[K][0], ga[K][1], ga[K][2], ga[K][3], gb[K][0], gb[K][1], gb[K][2], gb[K][3]}; \
+            unsigned short q_[3][8];                                                          \
+            _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) split3(v_[j_], q_[0][j_], q_[1][j_], q_[2][j_]); \
+            _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) {                                \
+                uint4 wv_;                                                                    \
+                wv_.x = q_[p_][0] | ((unsigned)q_[p_][1] << 16); wv_.y = q_[p_][2] | ((unsigned)q_[p_][3] << 16); \
+                wv_.z = q_[p_][4] | ((unsigned)q_[p_][5] << 16); wv_.w = q_[p_][6] | ((unsigned)q_[p_][7] << 16); \
+                *reinterpret_cast<uint4*>(g.ga.P + p_ * g.ga.plane_stride + (int64_t)r_ * g.ga.ld + 8 * c_) = wv_; \
+            }                                                                                 \
+        }                                                                                     \
+    } while (0)
+                // stage 0 of the phase only issues unit 0's loads; stage k + 1 issues unit k + 1's and applies unit k.
+                // Nested, so that every load dominates its wait.  NO load is ever issued whose result is not consumed: a
+                // register hipcc considers dead is reused at once, and the load landing later would overwrite its new
+                // content (a surplus load did exactly that in the first version: memory fault from a clobbered address).
+                LD_SYNC(); GU_LOAD(0, 0); PL_ISSUE(it + 3); ++it;
+#define GU_STEP(K, INNER)                                                                     \
+    if ((K) < nunits) {                                                                       \
+        LD_SYNC();                                                                            \
+        if ((K) + 1 < nunits) { GU_LOAD((K) + 1, (K) + 1); }                                  \
+        PL_ISSUE(it + 3);                                                                     \
+        if ((K) + 1 < nunits) ASM_WAIT(PER + 2); else ASM_WAIT(PER);                          \
+        GU_APPLY(K, K); ++it;                                                                 \
+        INNER                                                                                 \
+    }
+#define GU_LAST(K)                                   /* the deepest level: no further unit to load */ \
+    if ((K) < nunits) { LD_SYNC(); PL_ISSUE(it + 3); ASM_WAIT(PER); GU_APPLY(K, K); ++it; }
+                GU_STEP(0, GU_STEP(1, GU_STEP(2, GU_LAST(3))))
+#undef GU_STEP
+#undef GU_LAST
+#undef GU_LOAD
+#undef GU_APPLY
+#undef GU_ADDR
             }
         }
     }
-    (void)chunk; (void)lt; (void)cpi; (void)unit; (void)nunits; (void)srow;
-    for (int it = 0; it < nt; ++it) {
+    for (; it < nt; ++it) {
         // stage it + 1 must have landed before the MFMA waves pass barrier `it`; stage it + 2 may still fly
-        if (it + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                // every read of stage `it` is done: its slot is free
-        if (it + 3 < nt) {
-            if constexpr (EARLYW) {
-                if (g.upd.early && chunk < 16) {     // (wave-uniform)
-                    if (cpi == 1) {
-                        const EarlyW e0 = early_w_load(g.upd, m0, n0, chunk, lt);
-                        PL_ISSUE(it + 3);
-                        early_w_apply(g.upd, e0);
-                        chunk += 1;
-                    } else {
-                        const EarlyW e0 = early_w_load(g.upd, m0, n0, chunk, lt);
-                        const EarlyW e1 = early_w_load(g.upd, m0, n0, chunk + 1, lt);
-                        PL_ISSUE(it + 3);
-                        early_w_apply(g.upd, e0);
-                        early_w_apply(g.upd, e1);
-                        chunk += 2;
-                    }
-                    continue;
-                }
-                if (unit < nunits) {                 // (wave-uniform) one pass of one row of the next minibatch
-                    const int i = unit / g.ga.passes, pass = unit - i * g.ga.passes;
-                    const int r = (int)blockIdx.x * g.ga.rpw + i;
-                    const int64_t c = (int64_t)pass * 256 + lt, ld8 = g.ga.ld >> 3;
-                    const bool live = r < g.ga.B && c < ld8;
-                    const int64_t sr = i == 0 ? srow[0] : i == 1 ? srow[1] : i == 2 ? srow[2] : srow[3];
-                    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-                    if (live) {
-                        v0 = reinterpret_cast<const float4*>(g.ga.src + sr * g.ga.ld_src)[2 * c];
-                        v1 = reinterpret_cast<const float4*>(g.ga.src + sr * g.ga.ld_src)[2 * c + 1];
-                    }
-                    PL_ISSUE(it + 3);
-                    if (live) {
-                        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                        unsigned short q[3][8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) split3(x[j], q[0][j], q[1][j], q[2][j]);
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) {
-                            uint4 wv;
-                            wv.x = q[p][0] | ((unsigned)q[p][1] << 16); wv.y = q[p][2] | ((unsigned)q[p][3] << 16);
-                            wv.z = q[p][4] | ((unsigned)q[p][5] << 16); wv.w = q[p][6] | ((unsigned)q[p][7] << 16);
-                            *reinterpret_cast<uint4*>(g.ga.P + p * g.ga.plane_stride + (int64_t)r * g.ga.ld + 8 * c) = wv;
-                        }
-                    }
-                    ++unit;
-                    continue;
-                }
-            }
-            PL_ISSUE(it + 3);
-        }
+        LD_SYNC();
+        if (it + 3 < nt) { PL_ISSUE(it + 3); }
     }
+#undef ASM_LOAD4
+#undef ASM_WAIT
+#undef LD_SYNC
     if constexpr (EARLYW) {
         if (g.upd.early) {
-            for (; chunk < 16; ++chunk) early_w_apply(g.upd, early_w_load(g.upd, m0, n0, chunk, lt));   // (never with nt >= 12)
-            for (; unit < nunits; ++unit) {          // (the host sizes the units to fit the loop; kept for safety)
-                const int i = unit / g.ga.passes, pass = unit - i * g.ga.passes;
-                const int r = (int)blockIdx.x * g.ga.rpw + i;
-                const int64_t c = (int64_t)pass * 256 + lt;
-                if (r < g.ga.B && c < (g.ga.ld >> 3)) {
-                    const int64_t sr = i == 0 ? srow[0] : i == 1 ? srow[1] : i == 2 ? srow[2] : srow[3];
-                    const float4 v0 = reinterpret_cast<const float4*>(g.ga.src + sr * g.ga.ld_src)[2 * c];
-                    const float4 v1 = reinterpret_cast<const float4*>(g.ga.src + sr * g.ga.ld_src)[2 * c + 1];
-                    store_planes4(g.ga.P, g.ga.plane_stride, (int64_t)r * g.ga.ld + 8 * c, v0);
-                    store_planes4(g.ga.P, g.ga.plane_stride, (int64_t)r * g.ga.ld + 8 * c + 4, v1);
-                }
-            }
             // the MFMA waves are still on the last stage: fetch this lane's share of the old speed (and of the frozen W0)
             // for the speed epilogue now, so that only its stores follow the main loop
 #pragma unroll

@@ -37,9 +37,11 @@ for k in sorted(set(fetch) | set(write)):
         gemm_bytes += (f + w) * n; gemm_n += n
 out["gemm_avg_bytes_per_launch"] = gemm_bytes / max(gemm_n, 1)
 # bytes per CD STEP over every kernel of the step: the profiled command runs ONE path (bench.py --default-only), whose
-# steps each launch the plane gather once; kernels launched less than once per two steps (one-off splits, the free-energy
+# steps each launch the statistics GEMM once; kernels launched less than once per two steps (one-off splits, the free-energy
 # check) are not part of the step
-steps = out["per_launch_bytes"].get("mdbn::gather_planes_kernel", {}).get("launches", 0)
+# (one statistics GEMM per step; with the gather-ahead the gather kernel itself is launched once per run)
+steps = max([v["launches"] for k, v in out["per_launch_bytes"].items() if k.startswith("mdbn::gemm_planes_kernel<1, 1")] or
+            [out["per_launch_bytes"].get("mdbn::gather_planes_kernel", {}).get("launches", 0)])
 if steps:
     out["steps_profiled"] = steps
     out["step_kernels"] = {k: {"launches_per_step": v["launches"] / steps, "bytes_per_step": v["total"] * v["launches"] / steps}

@@ -1,7 +1,9 @@
 """Parity tests proper: the HIP path (through the C-ABI) against the oracle on the same
 seeded inputs, plus size-independent properties at BASELINE's full size.  Tolerances are
 fp32-device vs float64-oracle: probabilities 2e-6 abs, free energy 1e-4 rel
-(north star), Bernoulli samples exact outside the near-tie mask |u - p| < 1e-6."""
+(north star), Bernoulli samples exact outside the near-tie mask |u - p| < 1e-6.  Every
+tolerance goes through tests/_margins.check, which records the worst value measured on the
+box next to it (profiles/r03k_tolerance_margins.json)."""
 import numpy as np
 import pytest
 import torch
@@ -58,7 +60,7 @@ def test_propup_sample(hip_engine, V, H, B):
     s = state64(W, hb, vb, True)
     pre_o, mean_o = rbm_np.propup(s, x.astype(np.float64))
     check("propup p [V=%d]" % V, np.abs(mean - mean_o).max(), ptol(V), "prob")
-    check("propup pre / max|pre| [V=%d]" % V, np.abs(pre - pre_o).max() / max(1.0, np.abs(pre_o).max()), 4 * ptol(V))
+    check("propup pre / max|pre| [V=%d]" % V, np.abs(pre - pre_o).max() / max(1.0, np.abs(pre_o).max()), ptol(V))
     u = philox_np.uniform(B, H, 77, 1, 5, 0, 8).astype(np.float64)
     want = (u < mean_o).astype(np.float32)
     bad = sample != want
@@ -84,8 +86,8 @@ def test_propdown_sample(hip_engine, V, H, B, gauss):
         z = philox_np.normal(B, V, 78, 2, 6, 3, 0)
         pre_o, mean_o, samp_o = rbm_np.sample_v_given_h(s, h64, z)
         check("propdown GRBM nv_mean / max|nv| [H=%d]" % H, np.abs(mean - mean_o).max() / max(1.0, np.abs(mean_o).max()),
-              4e-6, "nv_mean")
-        check("propdown GRBM noisy sample [H=%d]" % H, np.abs(sample - samp_o).max(), 5e-5)
+              2e-6, "nv_mean")
+        check("propdown GRBM noisy sample [H=%d]" % H, np.abs(sample - samp_o).max(), 1e-5)
         want_cost = ((rbm_np.sigmoid(mean_o) - x) ** 2).sum()
     else:
         u = philox_np.uniform(B, V, 78, 2, 6, 3, 0).astype(np.float64)
@@ -94,7 +96,7 @@ def test_propdown_sample(hip_engine, V, H, B, gauss):
         bad = sample != samp_o
         assert np.all(np.abs(u - mean_o)[bad] < 1e-6) and bad.sum() <= 2
         want_cost = (x * rbm_np.softplus(-pre_o) + (1 - x) * rbm_np.softplus(pre_o)).sum()
-    check("propdown recon cost rel [H=%d]" % H, abs(cost - want_cost) / (abs(want_cost) + 0.05), 2e-5)
+    check("propdown recon cost rel [H=%d]" % H, abs(cost - want_cost) / (abs(want_cost) + 0.05), 2e-6)
 
 
 @pytest.mark.parametrize("V,H,B", SHAPES)
@@ -110,7 +112,7 @@ def test_free_energy(hip_engine, V, H, B, gauss):
     # F is a difference of two O(V) terms: fp32-level accuracy is relative to their magnitude
     hid = rbm_np.softplus(x.astype(np.float64) @ s.W + s.hbias).sum(axis=1)
     scale = np.maximum(hid + np.abs(F_o + hid), 1.0)
-    check("free energy / term magnitude [V=%d]" % V, (np.abs(F - F_o) / scale).max(), 2e-6)
+    check("free energy / term magnitude [V=%d]" % V, (np.abs(F - F_o) / scale).max(), 5e-7)
 
 
 @pytest.mark.parametrize("V,H,B,k", [(6, 4, 3, 1), (64, 32, 8, 3), (130, 70, 37, 2), (784, 500, 20, 1),
@@ -156,8 +158,8 @@ def test_cd_step_statistics(hip_engine, V, H, B, k, gauss):
     pre_nv, nv_mean, nv_sample, pre_nh, nh_mean, nh_sample = out
     scale_v = max(1.0, np.abs(nv_mean).max())
     tag = "[V=%d %s]" % (V, "GRBM" if gauss else "RBM")
-    check("cd_step nv_mean / max|nv| " + tag, np.abs(sc.V2[B:].cpu().numpy() - nv_mean).max() / scale_v, 4e-6, "nv_mean")
-    check("cd_step nh_mean " + tag, np.abs(-sc.P2[B:].cpu().numpy() - nh_mean).max(), 3 * ptol(V), "prob")
+    check("cd_step nv_mean / max|nv| " + tag, np.abs(sc.V2[B:].cpu().numpy() - nv_mean).max() / scale_v, 2e-6, "nv_mean")
+    check("cd_step nh_mean " + tag, np.abs(-sc.P2[B:].cpu().numpy() - nh_mean).max(), 2 * ptol(V), "prob")      # two passes deep
     S_o, s_h_o, s_v_o = rbm_np.cd_statistics(v0, ph_mean, nv_mean, nh_mean)
     check("cd_step S / max|S| " + tag, np.abs(S - S_o).max() / max(1.0, np.abs(S_o).max()), 1e-5, "stats")
     check("cd_step s_h / max " + tag, np.abs(s_h - s_h_o).max() / max(1.0, np.abs(s_h_o).max()), 1e-5, "stats")
@@ -166,7 +168,7 @@ def test_cd_step_statistics(hip_engine, V, H, B, k, gauss):
         cost_o = ((rbm_np.sigmoid(pre_nv) - v0) ** 2).sum()
     else:
         cost_o = (v0 * rbm_np.softplus(-pre_nv) + (1 - v0) * rbm_np.softplus(pre_nv)).sum()
-    check("cd_step cost rel " + tag, abs(cost - cost_o) / abs(cost_o), 2e-5)
+    check("cd_step cost rel " + tag, abs(cost - cost_o) / abs(cost_o), 2e-6)
 
 
 @pytest.mark.parametrize("V,H", [(6, 4), (130, 70), (784, 500), (4096, 1024)])

@@ -310,7 +310,7 @@ def test_product_default_c2_statistics_against_forced_oracle(built_lib, gauss):
         pre_nv = out[0]
         cost_o = ((rbm_np.sigmoid(pre_nv) - v0) ** 2).sum() if gauss else \
             (v0 * rbm_np.softplus(-pre_nv) + (1 - v0) * rbm_np.softplus(pre_nv)).sum()
-        check(tag + ": cost rel", abs(cost - cost_o) / abs(cost_o), 2e-5)
+        check(tag + ": cost rel", abs(cost - cost_o) / abs(cost_o), 2e-6)
         assert flips <= 3
     finally:
         eng.set_planes_min_work(0)

@@ -132,9 +132,9 @@ def test_rbm_training_on_device(shadow, persistent):
         per_epoch = np.array(shadow.pl_costs).reshape(8, N // B).mean(axis=1)
         np.testing.assert_allclose([c for c, _ in history], per_epoch, rtol=2e-4)
         assert rbm.bit_i_idx == (8 * (N // B)) % V
-        _verdict(shadow, "RBM.training PCD-2 (100->60)", [rbm], stat_tol=1e-5, param_tol=2e-5)
+        _verdict(shadow, "RBM.training PCD-2 (100->60)", [rbm], stat_tol=1e-5, param_tol=5e-6)
     else:
-        _verdict(shadow, "RBM.training CD-2 (100->60)", [rbm], cost_tol=1e-4, param_tol=2e-5)
+        _verdict(shadow, "RBM.training CD-2 (100->60)", [rbm], cost_tol=2e-6, param_tol=5e-6)
 
 
 def test_grbm_training_on_device(shadow):
@@ -151,7 +151,7 @@ def test_grbm_training_on_device(shadow):
         history = rbm.training(data, data[:16], training_epochs=7, batch_size=B, learning_rate=0.005, k=1,
                                lambda_1=0.01, lambda_2=0.1, persistent=True)      # persistent is ignored (rbm.py:701-728)
     assert len(history) == 7 and shadow.steps == 7 * 3
-    _verdict(shadow, "GRBM.training (130->70, 21 steps)", [rbm], cost_tol=1e-4, param_tol=2e-5)
+    _verdict(shadow, "GRBM.training (130->70, 21 steps)", [rbm], cost_tol=2e-6, param_tol=5e-6)
 
 
 def test_mdbn_glue_on_device(shadow):
@@ -164,7 +164,7 @@ def test_mdbn_glue_on_device(shadow):
     N = 64
     rng = np.random.RandomState(123)
     np.random.seed(11)
-    shadow.tie = 5e-5            # thousands of steps: fp32 parameters drift from the float64 shadow by up to ~5e-5
+    shadow.tie = 4e-6            # thousands of steps: fp32 parameters drift from the float64 shadow (measured: no flipped draw at all)
     outs, nets = [], []
     for width, sizes in ((96, [24, 8]), (40, [6])):
         x = rs.normal(size=(N, width)).astype(np.float32)
@@ -180,7 +180,7 @@ def test_mdbn_glue_on_device(shadow):
     assert top.number_of_nodes() == [14, 24, 3]
     assert shadow.steps > 100
     _verdict(shadow, "MDBN glue (thousands of steps)", [r for net in nets + [top] for r in net.rbm_layers],
-             cost_tol=2e-4, param_tol=5e-5)
+             cost_tol=2e-6, param_tol=2e-5)
     assert top.get_output(joint).shape == (N, 3)
 
 
@@ -214,7 +214,7 @@ def test_cd_k_chain_teacher_forced(hip_engine, V, H, B, k, gauss):
     check(tag + ": s_h / max", np.abs(s_h - s_h_o).max() / max(1.0, np.abs(s_h_o).max()), 1e-5, "stats")
     check(tag + ": s_v / max", np.abs(s_v - s_v_o).max() / max(1.0, np.abs(s_v_o).max()), 1e-5, "stats")
     check(tag + ": nv_mean / max|nv|", np.abs(sc.V2[B:].cpu().numpy() - out[1]).max() / max(1.0, np.abs(out[1]).max()),
-          4e-6, "nv_mean")
+          2e-6, "nv_mean")
     assert flips <= 3
 
 
@@ -234,7 +234,7 @@ def test_hundred_step_drift_teacher_forced(shadow, V, H, B, gauss, hp):
               engine=shadow)
     _, up = rbm.get_cost_updates(k=1, batch_size=B, **hp)
     fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=shadow), data_parallel=None)
-    shadow.tie = 2e-5            # the allowed 1e-4 relative weight drift moves probabilities by up to ~1e-5
+    shadow.tie = 4e-6            # weights drifting from the float64 shadow move the probabilities (measured: flips up to 1.1e-6)
     for t in range(100):
         fn(indexes=rs.permutation(N)[:B], momentum=0.6 if t < 50 else 0.9)
     assert shadow.steps == 100
@@ -242,7 +242,7 @@ def test_hundred_step_drift_teacher_forced(shadow, V, H, B, gauss, hp):
     W, W_o = rbm.W.get_value(), st.W
     tag = "100 steps %d->%d" % (V, H)
     check(tag + ": W drift rel", np.abs(W - W_o).max() / np.abs(W_o).max(), 1e-4, "drift100")
-    _verdict(shadow, tag, cost_tol=1e-4)
+    _verdict(shadow, tag, cost_tol=2e-6)
     F = rbm.free_energy(data[:B]).get_value()
     F_o = rbm_np.free_energy(st, data[:B].astype(np.float64))
     check(tag + ": free energy rel", np.abs(F - F_o).max() / np.abs(F_o).max(), 1e-4, "free_energy")   # the north star's parity quantity
@@ -399,7 +399,7 @@ def test_config5_three_modality_mdbn_at_batch_512(shadow):
     sm = ((sm - sm.mean(0)) / (sm.std(0) + 1e-3)).astype(np.float32)
     rng = np.random.RandomState(123)
     np.random.seed(3)
-    shadow.tie = 2e-5
+    shadow.tie = 4e-6
     outs, nets = [], []
     for data, sizes, lr in ((me, [40], [0.002]), (ge, [400, 40], [0.001, 0.1]), (sm, [200, 20], [0.002, 0.1])):
         net, out_t, _ = MDBN.train_bottom_layer(data, None, batch_size=B, k=5, layers_sizes=sizes,
@@ -411,8 +411,8 @@ def test_config5_three_modality_mdbn_at_batch_512(shadow):
     top = mdbn_amd.DBN(numpy_rng=rng, n_ins=100, gauss=False, hidden_layers_sizes=[128], n_outs=3, engine=shadow)
     top.training(mdbn_amd.shared(joint, engine=shadow), batch_size=B, k=1, pretraining_epochs=[4, 4], pretrain_lr=[0.1, 0.1])
     assert shadow.steps >= 2 * (3 + 6 + 6), shadow.steps
-    _verdict(shadow, "c5 MDBN at B = 512, CD-5", [r for net in nets + [top] for r in net.rbm_layers], cost_tol=2e-4,
-             param_tol=5e-5)
+    _verdict(shadow, "c5 MDBN at B = 512, CD-5", [r for net in nets + [top] for r in net.rbm_layers], cost_tol=2e-6,
+             param_tol=5e-6)
 
 
 def _write_table(path, data):
@@ -461,7 +461,7 @@ def test_loader_to_dbn_training_host_resident_equals_device_resident(shadow, tmp
     tr._mirror = None
     np.testing.assert_allclose(dbn.get_output(tr), runs[1][2], rtol=0, atol=2e-6)
     assert tr._mirror is None
-    _verdict(shadow, "TSV -> DBN.training (259 -> 64 -> 16)", [r for run in runs for r in run[3]], cost_tol=2e-4, param_tol=2e-5)
+    _verdict(shadow, "TSV -> DBN.training (259 -> 64 -> 16)", [r for run in runs for r in run[3]], cost_tol=2e-6, param_tol=1e-5)
 
 
 def test_host_table_prefetch_announces_the_next_minibatch(hip_engine):
