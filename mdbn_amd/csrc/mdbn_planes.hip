@@ -200,6 +200,7 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
                     PL_ISSUE(it + 3);
                     if (i + 1 < 16) ASM_WAIT(PER + 2); else ASM_WAIT(PER);
                     CW_STORE(cw[i], cs[i], i);
+                    es->sp[i] = make_float4(cs[i][0], cs[i][1], cs[i][2], cs[i][3]);      // kept for the speed epilogue
                     ++it;
                 }
             } else {                                 // two chunks per stage: 8 items (host: nt >= 12)
@@ -219,6 +220,8 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
                     if (i + 1 < 8) ASM_WAIT(PER + 4); else ASM_WAIT(PER);
                     CW_STORE(cw[2 * i], cs[2 * i], 2 * i);
                     CW_STORE(cw[2 * i + 1], cs[2 * i + 1], 2 * i + 1);
+                    es->sp[2 * i] = make_float4(cs[2 * i][0], cs[2 * i][1], cs[2 * i][2], cs[2 * i][3]);
+                    es->sp[2 * i + 1] = make_float4(cs[2 * i + 1][0], cs[2 * i + 1][1], cs[2 * i + 1][2], cs[2 * i + 1][3]);
                     ++it;
                 }
             }
@@ -298,12 +301,12 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
 #undef LD_SYNC
     if constexpr (EARLYW) {
         if (g.upd.early) {
-            // the MFMA waves are still on the last stage: fetch this lane's share of the old speed (and of the frozen W0)
-            // for the speed epilogue now, so that only its stores follow the main loop
+            // the old speed of this lane's 16 chunks is still in registers (es->sp, from the chunk phase); the MFMA waves are
+            // on the last stages: fetch the frozen W0 (when there is one) for the speed epilogue now, so that only its
+            // stores follow the main loop
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int64_t off = (int64_t)(m0 + 8 * j + (lt >> 5)) * g.upd.ld + n0 + 4 * (lt & 31);
-                es->sp[j] = *reinterpret_cast<const float4*>(g.upd.Ws + off);
                 es->w0[j] = g.upd.W0 ? *reinterpret_cast<const float4*>(g.upd.W0 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
