@@ -344,11 +344,13 @@ def main():
     sweep = None
     if world > 1 and not args.no_sweep and getattr(step_fn, "overlap", False):
         sweep = []
-        settings = [(ov, cus, nat) for nat in (False, True) for ov, cus in ((True, 0), (True, 8), (True, 16), (True, 32),
-                                                                             (True, 64), (False, 0))]
+        # (overlap, comm_cus, C-ABI collective, deferred update inside the statistics GEMM [comm_cus 0 only])
+        settings = [(ov, cus, nat, fu) for nat in (False, True)
+                    for ov, cus, fu in ((True, 0, True), (True, 0, False), (True, 8, False), (True, 16, False), (True, 32, False),
+                                        (True, 64, False), (False, 0, False))]
         nxt0 = args.warmup
         capi_ok = None
-        for ov, cus, nat in settings:
+        for ov, cus, nat, fu in settings:
             if nat and backend_name != "nccl":
                 continue                                  # the C-ABI communicator is RCCL: needs one GPU per rank
             if nat and capi_ok is None:
@@ -360,6 +362,7 @@ def main():
                 continue
             step_fn.flush()
             step_fn.overlap, step_fn.comm_cus, step_fn.group.native = ov, (cus if ov else 0), nat
+            step_fn.fuse_deferred = fu
             try:
                 run(max(5, args.warmup // 2), nxt0)
                 w, _, nxt0 = measure(nxt0, min_total=0.15)
@@ -369,11 +372,12 @@ def main():
             except Exception as exc:                      # a setting that cannot run is reported, not fatal
                 ms, err = None, repr(exc)[:200]
             sweep.append({"overlap": ov, "comm_cus": cus if ov else 0, "collective": "capi" if nat else "torch",
-                          "ms_per_step": ms, "windows": len(w) if ms else 0, "error": err})
+                          "update_inside_statistics_gemm": fu, "ms_per_step": ms, "windows": len(w) if ms else 0, "error": err})
         ok = [r for r in sweep if r.get("ms_per_step")]
         best = min(ok, key=lambda r: r["ms_per_step"])
         step_fn.flush()
         step_fn.overlap, step_fn.comm_cus = best["overlap"], best["comm_cus"]
+        step_fn.fuse_deferred = best["update_inside_statistics_gemm"]
         step_fn.group.native = best["collective"] == "capi"
         run(args.warmup, nxt0)
     wins, cost, nxt = measure(args.warmup)
@@ -550,6 +554,7 @@ def main():
                         "allreduce_bytes": 4 * (V * H + H + V + 4) if world > 1 else 0,
                         "overlap": bool(getattr(step_fn, "overlap", False)),
                         "comm_cus": int(getattr(step_fn, "comm_cus", 0)),
+                        "update_inside_statistics_gemm": bool(getattr(step_fn, "fuse_deferred", False)) and not getattr(step_fn, "comm_cus", 0),
                         "collective": step_fn.group.collective if getattr(step_fn, "group", None) is not None else None,
                         "sweep": sweep, "rccl": rccl_info},
         # achieved = FLOPs ISSUED on the matrix pipe the GEMM kernels execute on (six / three bf16 products per

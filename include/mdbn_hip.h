@@ -295,6 +295,18 @@ int  mdbn_apply_update(mdbn_ctx *ctx, void *stream, const mdbn_update_args *a);
  * all-reduce in data-parallel runs). */
 int  mdbn_cd_step(mdbn_ctx *ctx, void *stream, const mdbn_cd_args *a);
 
+/* mdbn_cd_step in two calls, for the overlapped data-parallel order: mdbn_cd_forward = gather + positive phase + Gibbs
+ * chain (everything that reads the parameters), mdbn_cd_statistics = bias statistics + the statistics GEMM (reads only the
+ * step's own buffers).  In between the caller waits for the all-reduce of the PREVIOUS step and hands its deferred update
+ * (`deferred`: mdbn_update_args with phase 3 and the reduced statistics of step t-1; NULL = none) to the statistics call:
+ * nothing of that update depends on this step's statistics GEMM, so on the plane path its weight half is applied by that
+ * GEMM's loader waves during the main loop and its bias / cost half by the MFMA waves ahead of it -- no update launch;
+ * otherwise (f32-operand kernels, balanced launches, lambda_1 != 0, fewer than 20 stages) the library launches the update
+ * kernel itself right before the GEMM.  Bitwise the same parameters as mdbn_cd_step + mdbn_apply_update(phase 3).
+ * mdbn_cd_statistics must directly follow mdbn_cd_forward with the same arguments on the same context. */
+int  mdbn_cd_forward(mdbn_ctx *ctx, void *stream, const mdbn_cd_args *a);
+int  mdbn_cd_statistics(mdbn_ctx *ctx, void *stream, const mdbn_cd_args *a, const mdbn_update_args *deferred);
+
 /* The whole compiled step function for a single device (src/rbm.py:258-376): mdbn_cd_step
  * followed by the update, in one call; parameters, speeds and cost are bitwise identical to
  * mdbn_cd_step + mdbn_apply_update.  upd->phase is ignored.  With option "fused_update" (default)

@@ -84,6 +84,8 @@ SIGNATURES = {
     "mdbn_cd_stats": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _i64],
     "mdbn_apply_update": [_vp, _vp, C.POINTER(UpdateArgs)],
     "mdbn_cd_step": [_vp, _vp, C.POINTER(CdArgs)],
+    "mdbn_cd_forward": [_vp, _vp, C.POINTER(CdArgs)],
+    "mdbn_cd_statistics": [_vp, _vp, C.POINTER(CdArgs), C.POINTER(UpdateArgs)],
     "mdbn_cd_train_step": [_vp, _vp, C.POINTER(CdArgs), C.POINTER(UpdateArgs)],
     "mdbn_free_energy": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i32, _vp,
                          _vp, _i64],

@@ -17,6 +17,9 @@ using namespace mdbn;
 struct mdbn_ctx {
     int device;
     int num_cu;
+    // mdbn_cd_forward -> mdbn_cd_statistics hand-over (host side only): the cost partials the chain's last visible pass left
+    int pending_n_cost = -1;
+    const void* pending_stats = nullptr;
     void* comm = nullptr;      // ncclComm_t of mdbn_comm_init_rank (RCCL), or NULL
     int comm_ranks = 0;
     // side stream + events for mdbn_cd_train_step (memory-bound update work overlapped with the
@@ -632,7 +635,11 @@ int run_affine_planes(mdbn_ctx* ctx, int comm_cus, const unsigned short* A, int6
 
 // The CD-k step on planes (same sequence, draws and outputs as cd_step_impl below; GRBM without noise and
 // Bernoulli RBM, CD only).  upd != NULL: single-device step with the update fused into the statistics GEMM.
-int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const mdbn_update_args* upd, const Workspace& ws)
+// mode: 0 = the whole step, 1 = everything before the statistics GEMM (mdbn_cd_forward), 2 = the statistics GEMM only
+// (mdbn_cd_statistics).  defer (modes 0 / 2, upd == NULL): the previous step's deferred update (phase 3), applied by the
+// statistics GEMM's loader waves when it qualifies, else launched as update_kernel right before that GEMM.
+int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const mdbn_update_args* upd, const Workspace& ws,
+                   int mode = 0, const mdbn_update_args* defer = nullptr)
 {
     const int64_t B = a->B, V = a->V, H = a->H, ldv = V, ldh = H;
     PlaneBufs pb;
@@ -663,6 +670,8 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     // x = train_set_x[indexes] (dbn.py:307), as f32 (cost target, bias statistics) and as planes
     // (without `keep` the float32 copy of v0 is not made either: its one reader, the reconstruction-cost / bias-statistics
     // target of the last visible pass, reads the dataset rows through the index instead)
+    int n_cost = 0;
+    if (mode != 2) {
     // (gathered ahead by the previous call's statistics kernel: the planes are already there)
     if (!(a->v0_ready && !keep))
         HIP_OK(launch_gather_planes(a->data, a->n_data, ldv, ldv, a->indexes, a->index_is_64, B, keep ? v0 : nullptr, ldv, pb.Xp,
@@ -677,7 +686,6 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
         CHECK(run_affine_planes(ctx, a->comm_cus, pb.Xp, ldv, pb.px, 3, 0, Wp, V, H, B, e, false, ws, s, nullptr));
         if (a->trace_h) HIP_OK(hipMemcpyAsync(a->trace_h, a->hs, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
     }
-    int n_cost = 0;
     for (int t = 1; t <= a->k; ++t) {                                  // gibbs_hvh x k (rbm.py:318-336)
         const bool last = t == a->k;
         {   // v_t | h_{t-1}: the chain state is our own 0/1 sample: one plane, three products
@@ -714,6 +722,13 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
         }
     }
 
+    }       // mode != 2
+    if (mode == 1) {
+        ctx->pending_n_cost = n_cost; ctx->pending_stats = a->stats;
+        return MDBN_OK;
+    }
+    if (mode == 2) n_cost = ctx->pending_n_cost;
+
     float* S = a->stats;
     float* s_h = a->stats + V * ldh;
     float* s_v = s_h + ldh;
@@ -731,6 +746,21 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     int bal = sp.splitk == 1 ? bal_blocks(ctx, a->comm_cus, (int64_t)g.tiles_m * g.tiles_n, 2 * B / 32) : 0;
     if (bal && ((int64_t)bal * 2 * 16384 > ws.slab_floats || V * ldh * 4 >= (int64_t)1 << 31)) bal = 0;
     const bool fuse_upd = !bal && upd != nullptr && g_opt_fused_update && sp.splitk == 1;
+    // gather-ahead of the next minibatch by the loader waves, after their W chunks (g.upd.early set): one 256-octet pass of
+    // one row per stage; every workgroup takes rpw consecutive rows
+    auto set_gather_ahead = [&]() {
+        if (g.upd.early && g_opt_gather_ahead && a->next_indexes && Xother && !keep) {
+            const int nwg = g.tiles_m * g.tiles_n, nt = (int)(2 * B / 32);
+            const int rpw = (int)((B + nwg - 1) / nwg), passes = (int)((ldv / 8 + 255) / 256);
+            if (rpw * passes <= 4 && 16 / (nt >= 20 ? 1 : 2) + rpw * passes + 1 <= nt - 3) {      // (the kernel unrolls <= 4 units)
+                g.ga.src = a->data; g.ga.n_rows = a->n_data; g.ga.ld_src = ldv;
+                g.ga.idx = a->next_indexes; g.ga.idx64 = a->index_is_64;
+                g.ga.B = (int)B; g.ga.rpw = rpw; g.ga.passes = passes;
+                g.ga.P = Xother; g.ga.plane_stride = pb.px; g.ga.ld = ldv;
+                if (a->ahead_done) *a->ahead_done = 1;
+            }
+        }
+    };
     if (fuse_upd) {
         BiasUpd bu;
         bu.hb = upd->hbias; bu.hbs = upd->hbias_speed; bu.vb = upd->vbias; bu.vbs = upd->vbias_speed;
@@ -748,19 +778,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
         // conditions of the update (no lambda_1; weight cost off or on a frozen snapshot) and >= 12 stages to spread over
         g.upd.early = g_opt_early_w && upd->lambda_1 == 0.f && (upd->weightcost == 0.f || upd->W0 != nullptr) &&
                       2 * B / 32 >= 12 && g_opt_planes_mfma == 16 && !g_opt_bf16_inputs;
-        // gather-ahead of the next minibatch by the same loader waves, after their W chunks: one 256-octet pass of one row
-        // per stage; every workgroup takes rpw consecutive rows
-        if (g.upd.early && g_opt_gather_ahead && a->next_indexes && Xother && !keep) {
-            const int nwg = g.tiles_m * g.tiles_n, nt = (int)(2 * B / 32);
-            const int rpw = (int)((B + nwg - 1) / nwg), passes = (int)((ldv / 8 + 255) / 256);
-            if (rpw * passes <= 4 && 16 / (nt >= 20 ? 1 : 2) + rpw * passes + 1 <= nt - 3) {      // (the kernel unrolls <= 4 units)
-                g.ga.src = a->data; g.ga.n_rows = a->n_data; g.ga.ld_src = ldv;
-                g.ga.idx = a->next_indexes; g.ga.idx64 = a->index_is_64;
-                g.ga.B = (int)B; g.ga.rpw = rpw; g.ga.passes = passes;
-                g.ga.P = Xother; g.ga.plane_stride = pb.px; g.ga.ld = ldv;
-                if (a->ahead_done) *a->ahead_done = 1;
-            }
-        }
+        set_gather_ahead();
         HIP_OK(timed_gemm_planes(LAY_MN, LAY_MN, g, s));
         return MDBN_OK;
     }
@@ -777,6 +795,28 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     g.fused = 0; g.ldc = ldh; g.slab_stride = V * ldh;
     mdbn_update_args u;
     if (upd) { u = *upd; u.phase = 0; }
+    if (defer) {
+        // the previous step's deferred update: inside this GEMM's loader waves (one workgroup per tile, unsplit, >= 20 stages,
+        // the split-phase conditions), else as its own launch right here -- bitwise the same either way
+        const bool inside = !bal && sp.splitk == 1 && g_opt_early_w && g_opt_planes_mfma == 16 && !g_opt_bf16_inputs &&
+                            2 * B / 32 >= 20 && defer->phase == 3 && defer->lambda_1 == 0.f &&
+                            (defer->weightcost == 0.f || defer->W0 != nullptr) && defer->stats != a->stats;
+        if (inside) {
+            g.upd.W = defer->W; g.upd.Ws = defer->W_speed; g.upd.W0 = defer->W0; g.upd.ld = ldh; g.upd.rows = (int)V;
+            g.upd.lr = defer->lr; g.upd.l1 = 0.f; g.upd.l2 = defer->lambda_2; g.upd.wc = defer->weightcost;
+            g.upd.mu = defer->momentum; g.upd.inv_bs = 1.0f / defer->batch_size;
+            g.upd.Wp = reinterpret_cast<unsigned short*>(defer->W_planes); g.upd.wp_stride = V * ldh;
+            g.upd.Sprev = defer->stats; g.upd.early = 2;
+            const float* ps_h = defer->stats + V * ldh;
+            g.db.on = 1; g.db.hb = defer->hbias; g.db.hbs = defer->hbias_speed; g.db.vb = defer->vbias; g.db.vbs = defer->vbias_speed;
+            g.db.s_h = ps_h; g.db.s_v = ps_h + ldh; g.db.cost_sum = ps_h + ldh + ldv; g.db.H = H; g.db.V = V;
+            g.db.lr = defer->lr; g.db.mu = defer->momentum; g.db.inv_rows = 1.0f / defer->n_rows;
+            g.db.cost_scale = defer->cost_scale; g.db.cost_out = defer->cost_out;
+            set_gather_ahead();
+        } else {
+            HIP_OK(launch_update(*defer, s, nullptr, 1, 0, reinterpret_cast<unsigned short*>(defer->W_planes)));
+        }
+    }
     if (bal) {
         g.xcd_group = 1;
         g.C = S; g.bal = bal; g.fused = 4; g.kchunk = (int)(2 * B); g.c_bytes = V * ldh * 4;
@@ -1347,7 +1387,8 @@ static int check_update_args(const mdbn_update_args* a)
     return MDBN_OK;
 }
 
-static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, const mdbn_update_args* upd)
+static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, const mdbn_update_args* upd, int mode = 0,
+                        const mdbn_update_args* defer = nullptr)
 {
     REQUIRE(ctx != nullptr && a != nullptr, "NULL argument");
     const int64_t B = a->B, V = a->V, H = a->H, ldv = a->ldv, ldh = a->ldh;
@@ -1381,13 +1422,25 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         REQUIRE(aligned16(a->W_planes), "W_planes not 16-byte aligned");
         HIP_OK(launch_split_planes(a->W, V, ldh, reinterpret_cast<unsigned short*>(a->W_planes), V * ldh, s));
     }
-    if (planes_eligible(a) && !(upd && g_opt_update_overlap))
-        return cd_step_planes(ctx, s, a, upd, ws);
+    if (mode == 2)
+        REQUIRE(ctx->pending_stats == a->stats && ctx->pending_n_cost >= 0, "mdbn_cd_statistics must follow mdbn_cd_forward of the same step");
+    if (defer) {
+        REQUIRE(upd == nullptr && mode != 1, "a deferred update goes with the statistics half of a step without its own update");
+        REQUIRE(defer->W == a->W && defer->ldh == ldh && defer->ldv == ldv && defer->V == V && defer->H == H,
+                "deferred update does not match the step's parameters");
+    }
+    if (planes_eligible(a) && !(upd && g_opt_update_overlap)) {
+        const int rc = cd_step_planes(ctx, s, a, upd, ws, mode, defer);
+        if (mode != 1) { ctx->pending_n_cost = -1; ctx->pending_stats = nullptr; }
+        return rc;
+    }
 
     float* v0 = a->V2;
     float* nv = a->V2 + B * ldv;
     float* ph = a->P2;
     float* nh = a->P2 + B * ldh;
+    int n_cost = 0;
+    if (mode != 2) {
 
     // x = train_set_x[indexes]                                        (dbn.py:307)
     HIP_OK(launch_gather(a->data, a->n_data, ldv, ldv, a->indexes, a->index_is_64, B, v0, ldv, s));
@@ -1400,7 +1453,6 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         CHECK(run_affine(up, ws, s, nullptr));
         if (a->trace_h) HIP_OK(hipMemcpyAsync(a->trace_h, a->hs, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
     }
-    int n_cost = 0;
     for (int t = 1; t <= a->k; ++t) {                                  // gibbs_hvh x k (rbm.py:318-336)
         const bool last = t == a->k;
         const float* chain = (t == 1 && a->persistent) ? a->persistent : a->hs;   // rbm.py:308-311
@@ -1429,6 +1481,15 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         if (a->trace_h && need_sample)
             HIP_OK(hipMemcpyAsync(a->trace_h + (int64_t)t * B * ldh, hdst, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
     }
+
+    }       // mode != 2
+    if (mode == 1) {
+        ctx->pending_n_cost = n_cost; ctx->pending_stats = a->stats;
+        return MDBN_OK;
+    }
+    if (mode == 2) { n_cost = ctx->pending_n_cost; ctx->pending_n_cost = -1; ctx->pending_stats = nullptr; }
+    // (f32-operand kernels: the previous step's deferred update is its own launch, ahead of the statistics GEMM)
+    if (defer) HIP_OK(launch_update(*defer, s, nullptr, 1, 0, reinterpret_cast<unsigned short*>(defer->W_planes)));
 
     float* S = a->stats;
     float* s_h = a->stats + V * ldh;
@@ -1535,6 +1596,20 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
 int mdbn_cd_step(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a)
 {
     return cd_step_impl(ctx, stream, a, nullptr);
+}
+
+int mdbn_cd_forward(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a)
+{
+    return cd_step_impl(ctx, stream, a, nullptr, 1, nullptr);
+}
+
+int mdbn_cd_statistics(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, const mdbn_update_args* deferred)
+{
+    if (deferred) {
+        CHECK(check_update_args(deferred));
+        REQUIRE(deferred->phase == 3 || deferred->phase == 0, "a deferred update is phase 3 (or the whole rule, phase 0)");
+    }
+    return cd_step_impl(ctx, stream, a, nullptr, 2, deferred);
 }
 
 int mdbn_cd_train_step(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, const mdbn_update_args* upd)

@@ -50,9 +50,23 @@ struct UpdEpi {
     float lr, l1, l2, wc, mu, inv_bs;
     unsigned short* Wp;            // nullable: bf16 planes [3][rows][ld] of the NEW W, kept in step with it
     int64_t wp_stride;
+    const float* Sprev;            // early == 2: S block of the (all-reduced) statistics of the PREVIOUS step
     int early;                     // plane statistics GEMM: the PARAMETER half (W, W planes: it needs only the old W and the old
                                    // speed, rbm.py:364-365) is applied by the loader waves DURING the main loop; the epilogue
-                                   // then only forms the new speed from the finished tile (needs l1 == 0 and wc == 0 or W0)
+                                   // then only forms the new speed from the finished tile (needs l1 == 0 and wc == 0 or W0).
+                                   // 2 (data-parallel, FUSED == 0): the loader waves apply the WHOLE deferred update of the
+                                   // previous step (phase 3: speed' from Sprev, W' from speed') -- nothing of it depends on
+                                   // this GEMM; the launch of update_kernel<true, true, true> disappears
+};
+
+// bias / cost half of that deferred update (update_kernel's leading blocks), run by the MFMA waves ahead of the main loop
+struct DeferredBias {
+    int on;
+    float* hb; float* hbs; float* vb; float* vbs;
+    const float* s_h; const float* s_v; const float* cost_sum;
+    int64_t H, V;
+    float lr, mu, inv_rows, cost_scale;
+    float* cost_out;
 };
 
 // bias half of the update + monitoring cost, applied by finalize_stats_kernel
@@ -136,6 +150,7 @@ struct PlaneGemmArgs {
     int fin_enabled;
     FinArgs fin;
     GatherAhead ga;
+    DeferredBias db;
 };
 
 // balanced launches (mdbn_planes.hip): U units in (tile, stage) order, workgroup w of P takes [w U / P, (w + 1) U / P)

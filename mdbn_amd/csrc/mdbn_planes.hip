@@ -175,7 +175,42 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
 // reading registers whose load had not landed; found by the ISA audit, scripts/experiments/audit_asm_loads.py.)
 #define ASM_WAIT(N) do { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
     if constexpr (EARLYW) {
-        if (g.upd.early) {
+        if (g.upd.early == 2) {
+            // the whole deferred update of the previous step (phase 3), 16 chunk items, one per stage (host: nt >= 20):
+            // speed' = g + (speed - g) mu with g = Sprev / batch_size - wc W0, W' = W decay + speed' lr -- update_kernel's
+            // NEWSPEED branch on the same operands.  Four loads per item (W0 from a dummy address when wc == 0).
+            const float decay = upd_decay(g.upd.lr, g.upd.l2);
+            const int64_t lane_off = (int64_t)(m0 + (lt >> 5)) * g.upd.ld + n0 + 4 * (lt & 31);
+            const bool has_wc = g.upd.wc != 0.0f;
+            const float* w0base = has_wc ? g.upd.W0 : g.upd.Ws;
+            pf32x4 dw[16], ds[16], dt[16], d0[16];
+            ASM_LOAD4(dw[0], g.upd.W + lane_off); ASM_LOAD4(ds[0], g.upd.Ws + lane_off);
+            ASM_LOAD4(dt[0], g.upd.Sprev + lane_off); ASM_LOAD4(d0[0], w0base + lane_off);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                LD_SYNC();
+                if (i + 1 < 16) {
+                    const int64_t o1 = lane_off + (int64_t)8 * (i + 1) * g.upd.ld;
+                    ASM_LOAD4(dw[i + 1], g.upd.W + o1); ASM_LOAD4(ds[i + 1], g.upd.Ws + o1);
+                    ASM_LOAD4(dt[i + 1], g.upd.Sprev + o1); ASM_LOAD4(d0[i + 1], w0base + o1);
+                }
+                PL_ISSUE(it + 3);
+                if (i + 1 < 16) ASM_WAIT(PER + 4); else ASM_WAIT(PER);
+                const int64_t off = lane_off + (int64_t)8 * i * g.upd.ld;
+                float4 sn, wn;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float w0j = has_wc ? d0[i][j] : 0.0f;
+                    const float snj = upd_speed(upd_grad(dt[i][j], g.upd.inv_bs, g.upd.wc, w0j), ds[i][j], g.upd.mu);
+                    setc(sn, j, snj);
+                    setc(wn, j, upd_param(dw[i][j], decay, snj, g.upd.lr));
+                }
+                *reinterpret_cast<float4*>(g.upd.Ws + off) = sn;
+                *reinterpret_cast<float4*>(g.upd.W + off) = wn;
+                if (g.upd.Wp) store_planes4(g.upd.Wp, g.upd.wp_stride, off, wn);
+                ++it;
+            }
+        } else if (g.upd.early) {
             const float decay = upd_decay(g.upd.lr, g.upd.l2);
             const int64_t lane_off = (int64_t)(m0 + (lt >> 5)) * g.upd.ld + n0 + 4 * (lt & 31);
 #define CW_STORE(WV, SV, CH)                                                                  \
@@ -226,6 +261,8 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
                 }
             }
 #undef CW_STORE
+        }
+        if (g.upd.early) {
             if (g.ga.idx) {
                 // gather-ahead: rows blockIdx * rpw .. of the next minibatch, <= 4 units (host); source rows resolved once
                 // (as gather_planes_kernel).  The loads are unconditional at clamped, valid addresses: only stores are predicated.
@@ -300,7 +337,7 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
 #undef ASM_WAIT
 #undef LD_SYNC
     if constexpr (EARLYW) {
-        if (g.upd.early) {
+        if (g.upd.early == 1) {
             // the old speed of this lane's 16 chunks is still in registers (es->sp, from the chunk phase); the MFMA waves are
             // on the last stages: fetch the frozen W0 (when there is one) for the speed epilogue now, so that only its
             // stores follow the main loop
@@ -520,11 +557,31 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
     EarlySpeed es;
     (void)es;
     if (wave >= 4) {
-        pl_loader<LA, LB, AP, MS, FUSED == 2 && MS == 16>(g, smem, wave - 4, lane, m0, n0, kbeg, nt, &es);
+        pl_loader<LA, LB, AP, MS, (FUSED == 2 || (FUSED == 0 && LA == LAY_MN && LB == LAY_MN && AP == 3)) && MS == 16>(
+            g, smem, wave - 4, lane, m0, n0, kbeg, nt, &es);
         if constexpr (FUSED == 0 && !parked_slab) return;
     } else {
         const int r = lane & 31, h = lane >> 5;
         const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+        if constexpr (FUSED == 0 && LA == LAY_MN && LB == LAY_MN) {
+            if (g.db.on) {              // data-parallel: bias / cost half of the previous step's deferred update (same
+                                        // arithmetic as update_kernel<true, true, true>'s leading blocks)
+                const DeferredBias& d = g.db;
+                for (int64_t i = (int64_t)blockIdx.x * 256 + wave * 64 + lane; i < d.H + d.V; i += (int64_t)gridDim.x * 256) {
+                    if (i < d.H) {
+                        const float sn = upd_speed(upd_scale(d.s_h[i], d.inv_rows), d.hbs[i], d.mu);
+                        d.hbs[i] = sn;
+                        d.hb[i] = upd_param(d.hb[i], 1.0f, sn, d.lr);
+                    } else {
+                        const int64_t j = i - d.H;
+                        const float sn = upd_speed(upd_scale(d.s_v[j], d.inv_rows), d.vbs[j], d.mu);
+                        d.vbs[j] = sn;
+                        d.vb[j] = upd_param(d.vb[j], 1.0f, sn, d.lr);
+                    }
+                }
+                if (blockIdx.x == 0 && wave == 0 && lane == 0 && d.cost_out) d.cost_out[0] = d.cost_sum[0] * d.cost_scale;
+            }
+        }
         if constexpr ((FUSED == 2 || FUSED == 0) && LA == LAY_MN && LB == LAY_MN) {
             if (g.fin_enabled) {        // statistics GEMM: finalize units while the first stages are in flight
                 const int nu = fin_units(g.fin);
@@ -751,7 +808,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
         float* T = reinterpret_cast<float*>(smem);
         constexpr int NT = 64 * (4 + PL_LW);
         if constexpr (FUSED == 1) fused_tile_epilogue<128, 128, NT>(g.epi, T, m0, n0);
-        else if (MS == 16 && g.upd.early) {          // W went early (pl_loader); the loader waves hold speed_old (+ W0)
+        else if (MS == 16 && g.upd.early == 1) {     // W went early (pl_loader); the loader waves hold speed_old (+ W0)
             if (wave >= 4) {
                 const int lt = (wave - 4) * 64 + lane;
                 constexpr int LDT = 128 + 8;

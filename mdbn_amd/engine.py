@@ -481,6 +481,38 @@ class HipEngine(object):
             self._w_planes_written(W)            # (split on entry if they were stale)
         return stats, sc
 
+    def cd_forward(self, data, indexes, W, hbias, vbias, gauss, k, rng, add_noise=False, sample_stats=False, stats=None,
+                   comm_cus=0, next_indexes=None):
+        """The first half of ``cd_step`` (mdbn_cd_forward): gather, positive phase and the Gibbs chain -- everything that
+        reads the parameters.  Returns the token ``cd_statistics`` completes the step with."""
+        a, stats, sc, keep = self._cd_args(data, indexes, W, hbias, vbias, gauss, k, rng, None, add_noise, 0,
+                                           sample_stats, stats, comm_cus, next_indexes=next_indexes)
+        sc._announce, announce = None, getattr(sc, "_announce", None)
+        keep.append(announce)
+        _lib.check(self.lib.mdbn_cd_forward(self.ctx, self._stream(), C.byref(a)), "mdbn_cd_forward")
+        if a.W_planes:
+            self._w_planes_written(W)
+            a.W_planes_valid = 1
+        return (a, stats, sc, keep, W)
+
+    def cd_statistics(self, token, deferred=None):
+        """The second half (mdbn_cd_statistics): bias statistics + statistics GEMM of the step ``cd_forward`` began.
+        ``deferred``: the arguments of ``apply_update(..., phase=3)`` for the PREVIOUS step (whose all-reduced statistics
+        the current stream has just been made to wait for) -- the library applies that update inside the statistics GEMM
+        when it can, as its own launch otherwise; returns (stats, scratch, cost of the deferred update or None)."""
+        a, stats, sc, keep, W = token
+        u, cost = (None, None)
+        if deferred is not None:
+            u, cost = self._update_args(*deferred)
+        _lib.check(self.lib.mdbn_cd_statistics(self.ctx, self._stream(), C.byref(a), C.byref(u) if u is not None else None),
+                   "mdbn_cd_statistics")
+        if u is not None:
+            self._w_planes_written(W)
+        announce = keep[-1]
+        if announce is not None and a.ahead_done and self._ahead_flag.value:
+            sc.ahead = announce              # the next call finds its rows in the other X2 buffer
+        return stats, sc, cost
+
     def _update_args(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats, lr, lambda_1,
                      lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale, phase, ldv):
         V, H = W.shape

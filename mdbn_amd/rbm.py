@@ -117,6 +117,13 @@ class StepFunction(object):
         # reference's commented-out NanGuardMode would do, rbm.py:542-543, dbn.py:311)
         self.nan_guard = bool(getattr(self.engine, "nan_guard", False))
         self.comm_cus = 0
+        # Overlapped data-parallel order with the deferred update of step t-1 INSIDE the statistics GEMM of step t (one
+        # launch and one queue packet fewer: 163 -> 146 us per step without a collective on one GPU), at the price of waiting
+        # for the all-reduce of step t-1 before that GEMM instead of after it (~100 us of cover instead of ~150).  Only with
+        # one workgroup per CU (comm_cus == 0: the balanced launches do not carry the update).  MDBN_DP_FUSED_UPDATE=0 or
+        # fn.fuse_deferred = False restores the update launch after the step; bench.py --gpus N measures both.
+        import os as _os
+        self.fuse_deferred = _os.environ.get("MDBN_DP_FUSED_UPDATE", "1") != "0"
         if self.group is not None and self.group.world_size > 1 and hasattr(self.engine, "set_option"):
             # The collective's kernels run beside the next step's GEMMs and take whole CUs (RCCL's gfx950 all-reduce
             # kernel: 248-256 VGPRs per wave, 37.6 KB LDS -- nothing of ours fits next to it), and a one-workgroup-per-
@@ -308,11 +315,35 @@ class StepFunction(object):
             self._stats_slots[slot] = eng.new_stats_buffer(rbm.n_visible, rbm.n_hidden, data.stride(0),
                                                            rbm.W.tensor.stride(0))
         stats = self._stats_slots[slot]
+        args = (rbm.W.tensor, rbm.W_speed.tensor, p.W0.tensor if p.W0 is not None else None,
+                rbm.hbias.tensor, rbm.hbias_speed.tensor, rbm.vbias.tensor, rbm.vbias_speed.tensor)
+        deferred_done = False
         if hi > lo:
             extra = {"comm_cus": self.comm_cus} if self.comm_cus else {}
-            eng.cd_step(data, idx, rbm.W.tensor, rbm.hbias.tensor, rbm.vbias.tensor, rbm.gauss, p.k,
-                        RngAddr(rbm.theano_rng.seed, rbm.stream_id, step, 0, lo),
-                        persistent=persistent, sample_stats=p.symbolic_grad, stats=stats, **extra)
+            if self.overlap and self._pending is not None and self.fuse_deferred and not self.comm_cus and \
+                    getattr(eng, "cd_forward", None) is not None:
+                # Overlapped order with the update INSIDE the statistics GEMM: the forward half of step t (everything that
+                # reads theta(t)), then wait for the all-reduce of step t-1, then the statistics half, whose kernel applies
+                # the deferred update of step t-1 (speeds from its reduced statistics, theta(t+1) from those speeds) beside
+                # its own main loop -- bitwise what apply_update(phase=3) after cd_step does, one launch fewer.
+                token = eng.cd_forward(data, idx, rbm.W.tensor, rbm.hbias.tensor, rbm.vbias.tensor, rbm.gauss, p.k,
+                                       RngAddr(rbm.theano_rng.seed, rbm.stream_id, step, 0, lo),
+                                       sample_stats=p.symbolic_grad, stats=stats,
+                                       next_indexes=(eng.index_tensor(next_indexes, data.shape[0])[lo:hi]
+                                                     if (next_indexes is not None and idx is not None and staged_slot is None
+                                                         and len(next_indexes) == n_global) else None), **extra)
+                pwork, pstats, hp, plazy = self._pending
+                self._pending = None
+                pwork.wait()
+                _, _, pcost = eng.cd_statistics(token, deferred=args + (pstats, lr, p.lambda_1, p.lambda_2, p.weightcost,
+                                                                        hp["momentum"], hp["batch_size"], hp["n_rows"],
+                                                                        hp["cost_scale"], 3, hp["ldv"]))
+                plazy._value = pcost
+                deferred_done = True
+            else:
+                eng.cd_step(data, idx, rbm.W.tensor, rbm.hbias.tensor, rbm.vbias.tensor, rbm.gauss, p.k,
+                            RngAddr(rbm.theano_rng.seed, rbm.stream_id, step, 0, lo),
+                            persistent=persistent, sample_stats=p.symbolic_grad, stats=stats, **extra)
         else:                                  # this rank holds no row of a short minibatch
             stats.zero_()
 
@@ -334,12 +365,11 @@ class StepFunction(object):
             cost = None
             # rbm.py:480 (sum over units, mean over rows) / rbm.py:697 (mean over everything)
             cost_scale = 1.0 / (n_global * rbm.n_visible) if rbm.gauss else 1.0 / n_global
-        args = (rbm.W.tensor, rbm.W_speed.tensor, p.W0.tensor if p.W0 is not None else None,
-                rbm.hbias.tensor, rbm.hbias_speed.tensor, rbm.vbias.tensor, rbm.vbias_speed.tensor)
-
         if self.overlap:
             work = self.group.all_reduce_sum_async(stats, self.engine)
-            if self._pending is not None:
+            if deferred_done:
+                pass                                   # (step t-1's update went into this step's statistics GEMM)
+            elif self._pending is not None:
                 # speeds from the reduced statistics of step t-1, then theta(t+1) from those speeds:
                 # phases 1 and 2 back to back touch the same arrays, so they run as ONE pass (phase 3;
                 # the speed half keeps step t-1's momentum and divisors, the parameter half this lr)

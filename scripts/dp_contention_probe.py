@@ -107,8 +107,8 @@ def make(group):
 
 def run(fn, n):
     for it in range(n):
-        mb = it % (N // B)
-        fn(indexes=perm[mb * B:(mb + 1) * B], momentum=0.0)
+        mb, nb = it % (N // B), (it + 1) % (N // B)
+        fn(indexes=perm[mb * B:(mb + 1) * B], momentum=0.0, next_indexes=perm[nb * B:(nb + 1) * B])
 
 
 host_us = [0.0]

@@ -14,6 +14,8 @@ from oracle.philox_np import PhiloxDraws
 
 
 class ShadowEngine(mdbn_amd.HipEngine):
+    cd_forward = None           # every CD step goes through cd_step / cd_train_step below, where the oracle rides along
+
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         self.trace_chain = True

@@ -38,9 +38,10 @@ def run_steps(group_mode, overlap, shape="small"):
     fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=eng),
                            data_parallel="auto" if group_mode else None, overlap=overlap)
     costs = []
+    batches = [rs.permutation(N)[:BG] for _ in range(7)]
     for t in range(6):
-        idx = rs.permutation(N)[:BG]
-        costs.append(fn(indexes=idx, momentum=0.3))
+        # (with the hint of the next minibatch: the overlapped order gathers it inside its statistics kernel)
+        costs.append(fn(indexes=batches[t], momentum=0.3, next_indexes=batches[t + 1]))
     costs = [float(c) for c in costs]
     fn.flush()
     return dict(W=rbm.W.get_value(), Ws=rbm.W_speed.get_value(), vb=rbm.vbias.get_value(),
