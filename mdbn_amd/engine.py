@@ -445,7 +445,8 @@ class HipEngine(object):
         ahead, sc.ahead = sc.ahead, None
         keep = [data, idx, ws]
         if sc.planes is not None and idx is not None and not self.keep_f32 and not self.trace_chain:
-            if ahead is not None and ahead[0] == data.data_ptr() and ahead[1] == data._version and \
+            # (the announcing step keeps the matrix and the index tensor alive, so an equal address is the same object)
+            if ahead is not None and ahead[0].data_ptr() == data.data_ptr() and ahead[1] == data._version and \
                     self._same_index_tensor(ahead[2], idx):
                 sc.x_buffer = ahead[3]
                 a.v0_ready = 1
@@ -459,7 +460,7 @@ class HipEngine(object):
                     self._ahead_flag = C.c_int32(0)
                     a.ahead_done = C.pointer(self._ahead_flag)
                     keep.append(nxt)
-                    sc._announce = (data.data_ptr(), data._version, nxt, 1 - sc.x_buffer)
+                    sc._announce = (data, data._version, nxt, 1 - sc.x_buffer)
         if self.trace_chain:
             if sc.trace_h is None or sc.trace_h.shape[0] != k + 1:
                 sc.trace_h = torch.zeros((k + 1, B, ldh), dtype=torch.float32, device=self.device)
