@@ -376,68 +376,4 @@ __device__ __forceinline__ void fused_update_epilogue(const UpdEpi& u, const flo
     }
 }
 
-// The two halves of fused_update_epilogue for the plane statistics GEMM (UpdEpi.early): the parameter step uses the OLD
-// speed (rbm.py:364-365), so W' = W * decay + speed_old * lr needs nothing the GEMM computes -- the loader waves apply it
-// chunk by chunk while the MFMA waves run the main loop (75 MB of W / W-plane traffic at c2 hidden under MFMA time instead
-// of following it) -- and only speed' = g + (speed_old - g) * mu, g = S / batch_size - wc * W0, waits for the tile.  Same
-// functions, same operands as update_rule4 with l1 == 0: bitwise the same parameters and speeds.
-//
-// early_w_chunk: rows {8 j + lt / 32} of the 128 x 128 tile, one float4 per lane (lt = 0..255 over the 4 loader waves).
-// The loads are issued BEFORE the caller's LDS-DMA stage and consumed after it: their latency hides behind the DMA issue.
-struct EarlyW { float4 w, sp; int64_t off; };
-__device__ __forceinline__ EarlyW early_w_load(const UpdEpi& u, int m0, int n0, int j, int lt)
-{
-    EarlyW e;
-    e.off = (int64_t)(m0 + 8 * j + (lt >> 5)) * u.ld + n0 + 4 * (lt & 31);
-    e.w = *reinterpret_cast<const float4*>(u.W + e.off);
-    e.sp = *reinterpret_cast<const float4*>(u.Ws + e.off);
-    return e;
-}
-__device__ __forceinline__ void early_w_apply(const UpdEpi& u, const EarlyW& e)
-{
-    const float decay = upd_decay(u.lr, u.l2);
-    float4 wn;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) setc(wn, j, upd_param(comp(e.w, j), decay, comp(e.sp, j), u.lr));
-    *reinterpret_cast<float4*>(u.W + e.off) = wn;
-    if (u.Wp) store_planes4(u.Wp, u.wp_stride, e.off, wn);
-}
-
-// ... and the speed half on the parked tile, all NT threads: reads speed_old (+ the frozen W0), writes speed'
-template <int BM, int BN, int NT = 512>
-__device__ __forceinline__ void fused_speed_epilogue(const UpdEpi& u, const float* T, int m0, int n0)
-{
-    constexpr int LDT = BN + 8, C4 = BN / 4, RSTEP = NT / C4, RB = 4;
-    const int c4 = threadIdx.x % C4, rr = threadIdx.x / C4;
-    const int col = n0 + 4 * c4;
-    if (col >= (int)u.ld) return;
-#pragma unroll 1
-    for (int r = rr; r < BM; r += RSTEP * RB) {
-        float4 sp[RB], w0[RB];
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const int row = m0 + r + b * RSTEP;
-            if (r + b * RSTEP < BM && row < u.rows) {
-                const int64_t off = (int64_t)row * u.ld + col;
-                sp[b] = *reinterpret_cast<const float4*>(u.Ws + off);
-                // wc == 0 without a snapshot: wc * w0 is 0 * (the old W) = 0 for every finite weight
-                w0[b] = u.W0 ? *reinterpret_cast<const float4*>(u.W0 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const int row = m0 + r + b * RSTEP;
-            if (r + b * RSTEP < BM && row < u.rows) {
-                const int64_t off = (int64_t)row * u.ld + col;
-                const float4 st = *reinterpret_cast<const float4*>(T + (r + b * RSTEP) * LDT + 4 * c4);
-                float4 sn;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    setc(sn, j, upd_speed(upd_grad(comp(st, j), u.inv_bs, u.wc, comp(w0[b], j)), comp(sp[b], j), u.mu));
-                *reinterpret_cast<float4*>(u.Ws + off) = sn;
-            }
-        }
-    }
-}
-
 }  // namespace mdbn

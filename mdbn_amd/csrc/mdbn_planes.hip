@@ -75,11 +75,10 @@ template <int MS> __device__ __forceinline__ int pl_col_swz(int k)
 #else
 #define PL_STAMP(SLOT) do {} while (0)
 #endif
-// EARLYW (statistics GEMM with the fused update, UpdEpi.early): between their LDS-DMA issues the loader waves also apply
-// the PARAMETER half of the update to this workgroup's W tile, one 8-row chunk (CPI chunks) per stage -- see
-// early_w_load / early_w_apply in mdbn_device.h.  A chunk's loads are issued before the stage's DMAs and consumed after
-// them (same basic block: the compiler's own vmcnt(PER) before the first use lets the DMAs fly); its stores are younger
-// than the stage, so the counted waits below stay valid (they only become stricter).
+// EARLYW (statistics GEMMs): between their LDS-DMA issues the loader waves also do memory-bound work that does not depend
+// on this GEMM -- UpdEpi.early = 1: the PARAMETER half of the fused update of this workgroup's W tile (+ the gather of the
+// next minibatch, GatherAhead); UpdEpi.early = 2 (data-parallel): the whole deferred update of the previous step.  One item
+// per stage, loads one stage ahead: see the comment at the phases below.
 struct EarlySpeed { float4 sp[16], w0[16]; };      // a loader lane's share of the tile's old speed (+ frozen W0), rows 8 j + lt / 32
 template <int LA, int LB, int AP, int MS, bool EARLYW = false>
 __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, int w, int lane, int m0, int n0, int kbeg, int nt,
