@@ -51,6 +51,10 @@ def parse_args():
     ap.add_argument("--default-only", action="store_true",
                     help="only the default (product) path: no exact-f32 / bf16-input re-runs, no CPU baseline (profiling runs)")
     ap.add_argument("--no-sweep", action="store_true", help="N > 1: keep the default data-parallel setting, no comm_cus sweep")
+    ap.add_argument("--sweep-capi", action="store_true",
+                    help="N > 1: also sweep with the all-reduce issued through the C-ABI communicator (mdbn_allreduce_stats); off "
+                         "by default: it is the same RCCL collective, and a second communicator that failed to build on one "
+                         "rank would hang the run that matters")
     return ap.parse_args()
 
 
@@ -72,6 +76,8 @@ def launch_ranks(args):
         cmd.append("--default-only")
     if args.no_sweep:
         cmd.append("--no-sweep")
+    if args.sweep_capi:
+        cmd.append("--sweep-capi")
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for line in proc.stdout:
         sys.stdout.write(line)
@@ -345,7 +351,7 @@ def main():
     if world > 1 and not args.no_sweep and getattr(step_fn, "overlap", False):
         sweep = []
         # (overlap, comm_cus, C-ABI collective, deferred update inside the statistics GEMM [comm_cus 0 only])
-        settings = [(ov, cus, nat, fu) for nat in (False, True)
+        settings = [(ov, cus, nat, fu) for nat in ((False, True) if (args.sweep_capi or os.environ.get("MDBN_BENCH_SWEEP_CAPI") == "1") else (False,))
                     for ov, cus, fu in ((True, 0, True), (True, 0, False), (True, 8, False), (True, 16, False), (True, 32, False),
                                         (True, 64, False), (False, 0, False))]
         nxt0 = args.warmup
@@ -374,11 +380,14 @@ def main():
             sweep.append({"overlap": ov, "comm_cus": cus if ov else 0, "collective": "capi" if nat else "torch",
                           "update_inside_statistics_gemm": fu, "ms_per_step": ms, "windows": len(w) if ms else 0, "error": err})
         ok = [r for r in sweep if r.get("ms_per_step")]
-        best = min(ok, key=lambda r: r["ms_per_step"])
         step_fn.flush()
-        step_fn.overlap, step_fn.comm_cus = best["overlap"], best["comm_cus"]
-        step_fn.fuse_deferred = best["update_inside_statistics_gemm"]
-        step_fn.group.native = best["collective"] == "capi"
+        if ok:
+            best = min(ok, key=lambda r: r["ms_per_step"])
+            step_fn.overlap, step_fn.comm_cus = best["overlap"], best["comm_cus"]
+            step_fn.fuse_deferred = best["update_inside_statistics_gemm"]
+            step_fn.group.native = best["collective"] == "capi"
+        else:                                             # nothing could be timed: the defaults, and the errors in the line
+            step_fn.overlap, step_fn.comm_cus, step_fn.fuse_deferred, step_fn.group.native = True, 0, True, False
         run(args.warmup, nxt0)
     wins, cost, nxt = measure(args.warmup)
     elapsed = float(np.median(wins))
