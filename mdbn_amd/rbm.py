@@ -365,6 +365,8 @@ class StepFunction(object):
             cost = None
             # rbm.py:480 (sum over units, mean over rows) / rbm.py:697 (mean over everything)
             cost_scale = 1.0 / (n_global * rbm.n_visible) if rbm.gauss else 1.0 / n_global
+        if next_indexes is not None and staged_slot is not None:
+            self.prefetch(next_indexes)              # host-resident table: the next shard starts moving now
         if self.overlap:
             work = self.group.all_reduce_sum_async(stats, self.engine)
             if deferred_done:
