@@ -176,6 +176,9 @@ int  mdbn_ctx_destroy(mdbn_ctx *ctx);
  *   needs only the old W and the old speed, rbm.py:364-365) is applied by the kernel's loader waves during the main loop,
  *   the epilogue only forms the new speed; bitwise the same parameters and speeds (needs lambda_1 == 0 and weightcost == 0
  *   or a frozen W0, else the whole rule stays in the epilogue).
+ * "narrow_tiles" (default 1): a forward pass of the plane path whose 128 x 128 plan would split K exactly two ways
+ *   (propdown at the c2 shape) runs unsplit on 128 x 64 tiles with the activation fused into the GEMM instead: no slabs,
+ *   no epilogue launch; another fp32 summation grouping (one K-long chain instead of two halves).
  * "gather_ahead" (default 1): honour mdbn_cd_args.next_indexes (the next minibatch gathered inside the statistics
  *   kernel); 0 = every step launches its own gather.
  * "comm_cus" (default 0): CUs left to a collective that runs beside the step when mdbn_cd_args.comm_cus is 0 (see

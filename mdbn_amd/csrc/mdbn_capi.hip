@@ -206,6 +206,9 @@ static int g_opt_planes_mfma = 16;
 // mdbn_set_option("early_w"): the statistics GEMM's loader waves apply the parameter half of the fused update during the
 // main loop (W' needs only the old W and the old speed), the epilogue only forms the new speed (default on; same bits)
 static int g_opt_early_w = 1;
+// mdbn_set_option("narrow_tiles"): forward passes whose 128 x 128 plan would split K two ways run unsplit on 128 x 64 tiles
+// with the fused activation epilogue instead (default on)
+static int g_opt_narrow_tiles = 1;
 // mdbn_set_option("gather_ahead"): honour mdbn_cd_args.next_indexes (default on; same bits)
 static int g_opt_gather_ahead = 1;
 // mdbn_set_option("bf16_inputs"): REPORTING mode of BASELINE configs[1] ("bf16/fp32"): the plane GEMMs use only the
@@ -593,6 +596,13 @@ int run_affine_planes(mdbn_ctx* ctx, int comm_cus, const unsigned short* A, int6
         if ((int64_t)bal_slabs * rows * e.ld > ws.slab_floats) bal = 0;        // a workspace sized before the option was set
         if ((int64_t)bal_slabs * rows * e.ld * 4 >= (int64_t)1 << 31) bal = 0;  // 32-bit buffer offsets
     }
+    // 128 x 64 tiles instead of a 2-way split-K (propdown at c2: 256 tiles, the activation on the parked tile, no slabs and
+    // no epilogue launch): "narrow_tiles" (default on), 16x16x32 shape, ROW W operand, a split factor of exactly 2
+    if (!bal && g_opt_narrow_tiles && g_opt_fused_epilogue && dir == 1 && g.splitk == 2 && Ndim % 64 == 0 && g_opt_planes_mfma == 16 &&
+        !g_opt_bf16_inputs && (ap == 1 || ap == 3) && (int64_t)g.tiles_m * (Ndim / 64) <= 2 * ctx->num_cu &&
+        (!e.target || (e.ld_target % 4 == 0 && ((uintptr_t)e.target & 15) == 0))) {      // its epilogue reads targets as float4
+        g.bn = 64; g.tiles_n = (int)(Ndim / 64); g.splitk = 1; g.kchunk = (int)Kdim;
+    }
     const bool fuse = !bal && g_opt_fused_epilogue && g.splitk == 1;
     const int nb = fuse ? g.tiles_m * g.tiles_n : epilogue_blocks(rows, e.ld);
     e.rows = (int)rows; e.cols = (int)Ndim;
@@ -976,6 +986,10 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "planes_mfma") == 0) {
         if (value != 16 && value != 32) return fail(MDBN_EINVAL, "planes_mfma must be 16 or 32");
         g_opt_planes_mfma = (int)value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "narrow_tiles") == 0) {
+        g_opt_narrow_tiles = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "gather_ahead") == 0) {

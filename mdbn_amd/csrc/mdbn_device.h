@@ -334,6 +334,102 @@ __device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, 
 }
 
 
+// The same epilogue for a 128 x 64 tile on 512 threads in ONE pass: a thread owns 4 rows x 4 consecutive columns.  With
+// only 8 waves on the CU (the GEMM's own) latency cannot be hidden by occupancy, so all global loads (the four target
+// rows through the minibatch index) are issued up front, and every store is 8 or 16 bytes (one per plane and row, one
+// float4 of bias statistics) instead of 2-byte plane stores per element.  Same arithmetic per element as act_quad (same
+// Philox words: one block per column and 4-row group), so samples are bit-identical to the two-launch path.
+template <int NT = 512>
+__device__ __forceinline__ void fused_tile_epilogue_4x4(const EpiArgs& e, float* T, int m0, int n0)
+{
+    constexpr int BM = 128, BN = 64, LDT = BN + 8;
+    static_assert(NT == 512, "one 4 x 4 block per thread");
+    const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;       // column quad 0..15, row group 0..31
+    const int col0 = n0 + 4 * cq, r0 = m0 + 4 * rg;
+    float cost = 0.f;
+    if (r0 < e.rows && col0 < (int)e.ld) {
+        float4 tg[4];
+        const bool want_tg = e.target != nullptr;
+        if (want_tg) {
+            int64_t srow[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) srow[j] = epi_target_row(e, r0 + j < e.rows ? r0 + j : e.rows - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tg[j] = *reinterpret_cast<const float4*>(e.target + srow[j] * e.ld_target + col0);
+        }
+        const float4 b4 = make_float4(col0 < e.cols ? e.bias[col0] : 0.f, col0 + 1 < e.cols ? e.bias[col0 + 1] : 0.f,
+                                      col0 + 2 < e.cols ? e.bias[col0 + 2] : 0.f, col0 + 3 < e.cols ? e.bias[col0 + 3] : 0.f);
+        float4 x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x[j] = *reinterpret_cast<const float4*>(T + (4 * rg + j) * LDT + 4 * cq);
+            x[j].x += b4.x; x[j].y += b4.y; x[j].z += b4.z; x[j].w += b4.w;
+        }
+        const bool need_u = e.sample != nullptr || e.sample_plane != nullptr;
+        const bool need_z = need_u && e.gauss;
+        float4 ms[4], sv[4], pre[4];
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = col0 + c;
+            const bool live = col < e.cols;
+            uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
+            if (need_u) {
+                const uint64_t g0 = e.rng.row_offset + (uint64_t)r0;
+                philox_rows4(e.rng, e.rng.draw, g0, (uint32_t)col, wa);
+                if (need_z) philox_rows4(e.rng, e.rng.draw | MDBN_NORMAL_BIT, g0, (uint32_t)col, wb);
+            }
+            float csum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float xj = comp(x[j], c);
+                float m, s1 = 0.f;
+                if (e.gauss) {
+                    m = xj;
+                    if (need_u) {
+                        const float u1 = philox_u01(wa[j]), u2 = philox_u01(wb[j]);
+                        s1 = m + sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+                    }
+                } else {
+                    m = sigmoidf_(xj);
+                    if (need_u) s1 = philox_u01(wa[j]) < m ? 1.0f : 0.0f;
+                }
+                float t1 = 0.f;
+                if (want_tg && live && r0 + j < e.rows) {
+                    t1 = comp(tg[j], c);
+                    if (e.gauss) { const float d = sigmoidf_(xj) - t1; cost += d * d; }
+                    else cost += t1 * softplusf_(-xj) + (1.0f - t1) * softplusf_(xj);
+                }
+                if (!live) { m = 0.f; s1 = 0.f; xj = 0.f; }
+                const float m1 = m * e.mean_scale;
+                setc(ms[j], c, m1); setc(sv[j], c, s1); setc(pre[j], c, xj);
+                if (live && r0 + j < e.rows) csum += e.colsum_kind == 0 ? m1 : (e.colsum_kind == 1 ? t1 - m : t1 - s1);
+            }
+            setc(cs, c, csum);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (r0 + j >= e.rows) break;
+            const int64_t off = (int64_t)(r0 + j) * e.ld + col0;
+            if (e.pre) *reinterpret_cast<float4*>(e.pre + off) = pre[j];
+            if (e.mean) *reinterpret_cast<float4*>(e.mean + off) = ms[j];
+            if (e.sample) *reinterpret_cast<float4*>(e.sample + off) = sv[j];
+            if (e.mean_planes) store_planes4(e.mean_planes, e.plane_stride, off, ms[j]);
+            if (e.sample_plane) {
+                uint2 w;
+                w.x = (__builtin_bit_cast(unsigned, sv[j].x) >> 16) | (__builtin_bit_cast(unsigned, sv[j].y) & 0xffff0000u);
+                w.y = (__builtin_bit_cast(unsigned, sv[j].z) >> 16) | (__builtin_bit_cast(unsigned, sv[j].w) & 0xffff0000u);
+                *reinterpret_cast<uint2*>(e.sample_plane + off) = w;
+            }
+        }
+        if (e.colsum) *reinterpret_cast<float4*>(e.colsum + (int64_t)(r0 >> 2) * e.ld + col0) = cs;
+    }
+    if (e.cost_partials) {
+        const float tot = block_sum(cost, T + BM * LDT);
+        if (threadIdx.x == 0) e.cost_partials[blockIdx.x] = tot;
+    }
+}
+
 // Parameter update applied by the statistics GEMM to the tile it just computed (parked in LDS, row
 // stride BN + 8): W and W_speed are read and written once, S never touches HBM.  The GEMM reads
 // only V2 / P2, so updating W in place under it is safe.  A thread owns one float4 column group and

@@ -137,6 +137,7 @@ struct PlaneGemmArgs {
     int ap;                // planes of A: 3, or 1 when A holds 0/1 samples (three products instead of six);
                            // 0 = bf16-input reporting mode: the leading plane of each operand, ONE product
     int ms;                // MFMA shape: 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16
+    int bn;                // 0 / 128: 128 x 128 tiles; 64: 128 x 64 tiles (unsplit ROW-operand forward pass, fused == 1)
     int fused;             // 0 | 1 activation epilogue (epi) | 2 parameter update (upd) + finalize units (fin)
     // balanced launches (launch_gemm_planes_bal): `bal` workgroups share tiles x (K / 32) stages evenly;
     // fused = 0: slabs, one per piece of a tile; fused = 4: result in place, pieces of shared tiles through `scratch`

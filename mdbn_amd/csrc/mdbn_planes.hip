@@ -80,14 +80,19 @@ template <int MS> __device__ __forceinline__ int pl_col_swz(int k)
 // next minibatch, GatherAhead); UpdEpi.early = 2 (data-parallel): the whole deferred update of the previous step.  One item
 // per stage, loads one stage ahead: see the comment at the phases below.
 struct EarlySpeed { float4 sp[16], w0[16]; };      // a loader lane's share of the tile's old speed (+ frozen W0), rows 8 j + lt / 32
-template <int LA, int LB, int AP, int MS, bool EARLYW = false>
+// BN = 128 | 64: columns of the output tile.  BN = 64 (ROW B operand only: propdown) halves the B image -- four 16-row
+// instructions per plane instead of eight -- so that an output with 256 tiles of 128 x 64 needs no split-K.
+template <int LA, int LB, int AP, int MS, bool EARLYW = false, int BN = 128>
 __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, int w, int lane, int m0, int n0, int kbeg, int nt,
                                           EarlySpeed* es = nullptr)
 {
     PL_STAMP(0);
+    static_assert(BN == 128 || (BN == 64 && LB == LAY_K), "a 64-column tile is implemented for a ROW B operand");
     // AP = planes of A (3 | 1); AP = 0 is the bf16-input REPORTING mode: one plane of each operand, one product
     constexpr int NA = AP == 3 ? 3 : 1, NB = AP == 0 ? 1 : 3;
-    constexpr int NQ = 8 * (NA + NB), PER = NQ / PL_LW;
+    constexpr int QB = BN / 16;                      // 1-KiB instructions per B plane
+    constexpr int NQ = 8 * NA + QB * NB, PER = NQ / PL_LW;
+    static_assert(NQ % PL_LW == 0, "staging instructions must divide over the loader waves");
     const char* src[PER];
     unsigned dst[PER];
     int64_t step[PER];
@@ -95,7 +100,7 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
     for (int j = 0; j < PER; ++j) {
         const int q = w + j * PL_LW;
         const bool isA = q < 8 * NA;
-        const int plane = isA ? q / 8 : (q - 8 * NA) / 8, sub = q & 7;
+        const int plane = isA ? q / 8 : (q - 8 * NA) / QB, sub = isA ? (q & 7) : (q - 8 * NA) % QB;
         const int lay = isA ? LA : LB;
         const unsigned short* base = isA ? g.A + plane * g.pa : g.B + plane * g.pb;
         const int64_t ld = isA ? g.lda : g.ldb;
@@ -415,12 +420,12 @@ __device__ __forceinline__ void pl_offsets16(int lane, int wm, int wn, int (&off
             FA[pl][i] = pl_frag<LA>((BASE) + pl * PL_PLANE, offA[2 * (HALF) + i][0], offA[2 * (HALF) + i][1]);
 #define RD_B(FB, BASE, HALF)                                                                  \
     _Pragma("unroll") for (int pl = 0; pl < NB; ++pl)                                         \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
-            FB[pl][i] = pl_frag<LB>((BASE) + (3 + pl) * PL_PLANE, offB[2 * (HALF) + i][0], offB[2 * (HALF) + i][1]);
+        _Pragma("unroll") for (int i = 0; i < NBH; ++i)                                       \
+            FB[pl][i] = pl_frag<LB>((BASE) + (3 + pl) * PL_PLANE, offB[NBH * (HALF) + i][0], offB[NBH * (HALF) + i][1]);
 #define MMQ(FA, FB, AH, BH)                                                                   \
     _Pragma("unroll") for (int a = 0; a < 2; ++a)                                             \
-        _Pragma("unroll") for (int b = 0; b < 2; ++b) {     /* smallest products first */     \
-            pf32x4a& c = acc[2 * (AH) + a][2 * (BH) + b];                                     \
+        _Pragma("unroll") for (int b = 0; b < NBH; ++b) {   /* smallest products first */     \
+            pf32x4a& c = acc[2 * (AH) + a][NBH * (BH) + b];                                   \
             if constexpr (AP == 3) {                                                          \
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[2][a], FB[0][b], c, 0, 0, 0);  \
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[2][b], c, 0, 0, 0);  \
@@ -449,13 +454,16 @@ __device__ __forceinline__ void pl_offsets16(int lane, int wm, int wn, int (&off
 #define PIN(FA, NPL)                                                                          \
     _Pragma("unroll") for (int pl = 0; pl < (NPL); ++pl)                                      \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(FA[pl][i]));
+#define PINB(FB, NPL)                                                                         \
+    _Pragma("unroll") for (int pl = 0; pl < (NPL); ++pl)                                      \
+        _Pragma("unroll") for (int i = 0; i < NBH; ++i) asm volatile("" :: "v"(FB[pl][i]));
 // The two stage bodies of the serpentine.  EVEN enters holding (Alo, Blo) of its stage and leaves holding (Alo, Bhi) of
 // the next; ODD enters holding (Alo, Bhi) and leaves holding (Alo, Blo).
 #define PL_STAGE_EVEN(BASE, NEXT, BARRIER)                                                    \
     do {                                                                                      \
         RD_B(Bhi, BASE, 1); MMQ(Alo, Blo, 0, 0); ORD(RB);                                     \
         RD_A(Ahi, BASE, 1); MMQ(Alo, Bhi, 0, 1); ORD(RA);                                     \
-        PIN(Bhi, NB); PIN(Ahi, NA);                                                           \
+        PINB(Bhi, NB); PIN(Ahi, NA);                                                          \
         BARRIER;                     /* every read of this stage is done; the next has landed */ \
         RD_A(Alo, NEXT, 0); MMQ(Ahi, Bhi, 1, 1); ORD(RA);                                     \
         RD_B(Bhi, NEXT, 1); MMQ(Ahi, Blo, 1, 0); ORD(RB);                                     \
@@ -464,7 +472,7 @@ __device__ __forceinline__ void pl_offsets16(int lane, int wm, int wn, int (&off
     do {                                                                                      \
         RD_B(Blo, BASE, 0); MMQ(Alo, Bhi, 0, 1); ORD(RB);                                     \
         RD_A(Ahi, BASE, 1); MMQ(Alo, Blo, 0, 0); ORD(RA);                                     \
-        PIN(Blo, NB); PIN(Ahi, NA);                                                           \
+        PINB(Blo, NB); PIN(Ahi, NA);                                                          \
         BARRIER;                                                                              \
         RD_A(Alo, NEXT, 0); MMQ(Ahi, Blo, 1, 0); ORD(RA);                                     \
         RD_B(Blo, NEXT, 0); MMQ(Ahi, Bhi, 1, 1); ORD(RB);                                     \
@@ -480,13 +488,14 @@ __device__ __forceinline__ void pl_offsets16(int lane, int wm, int wn, int (&off
 #define PL_MAIN_BARRIER() __syncthreads()
 #endif
 #endif
+// NBH = 16-column blocks per B half of a wave's tile: 2 (64 x 64 per wave, 128-column tile) or 1 (64 x 32, 64-column tile)
 #define PL_CONSUME_CONSTS()                                                                   \
     constexpr int NA = AP == 3 ? 3 : 1, NB = AP == 0 ? 1 : 3;      /* AP = 0: bf16-input reporting mode */ \
-    constexpr int RA = 2 * NA * (LA == LAY_MN ? 2 : 1), RB = 2 * NB * (LB == LAY_MN ? 2 : 1), \
-                  NM = 4 * (AP == 3 ? 6 : (AP == 1 ? 3 : 1));
+    constexpr int RA = 2 * NA * (LA == LAY_MN ? 2 : 1), RB = NBH * NB * (LB == LAY_MN ? 2 : 1), \
+                  NM = 2 * NBH * (AP == 3 ? 6 : (AP == 1 ? 3 : 1));
 
-template <int LA, int LB, int AP>
-__device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int wm, int wn, pf32x4a (&acc)[4][4],
+template <int LA, int LB, int AP, int NBH = 2>
+__device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int wm, int wn, pf32x4a (&acc)[4][2 * NBH],
                                              bool open_barrier = true, long long* bar_wait_out = nullptr)
 {
     long long bar_wait = 0;       // diagnostic builds: shader cycles spent at the stage barriers
@@ -524,9 +533,10 @@ __device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int w
 // commit 23f393d).  The chain store -> drain -> arrive -> poll -> load -> activate costs what the kernel boundary costs,
 // and the activation then runs on 512 threads per CU instead of 2048.  No kernel of this library waits for another
 // workgroup.)
-template <int LA, int LB, int AP, int FUSED, int MS>
+template <int LA, int LB, int AP, int FUSED, int MS, int BN = 128>
 __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemmArgs g)
 {
+    static_assert(BN == 128 || (BN == 64 && MS == 16 && FUSED == 1 && LB == LAY_K), "64-column tiles: unsplit ROW-operand forward pass");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware (split, tile) order, as the other GEMM kernels: placement only affects speed
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -538,7 +548,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
     int tm, tn;
     if (g.tiles_m <= g.tiles_n) { tn = t / g.tiles_m; tm = t - tn * g.tiles_m; }
     else { tm = t / g.tiles_n; tn = t - tm * g.tiles_n; }
-    const int m0 = tm * 128, n0 = tn * 128;
+    const int m0 = tm * 128, n0 = tn * BN;
     const int kbeg = ks * g.kchunk;
     const int nt = g.kchunk / 32;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -556,12 +566,12 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
     EarlySpeed es;
     (void)es;
     if (wave >= 4) {
-        pl_loader<LA, LB, AP, MS, (FUSED == 2 || (FUSED == 0 && LA == LAY_MN && LB == LAY_MN && AP == 3)) && MS == 16>(
+        pl_loader<LA, LB, AP, MS, (FUSED == 2 || (FUSED == 0 && LA == LAY_MN && LB == LAY_MN && AP == 3)) && MS == 16, BN>(
             g, smem, wave - 4, lane, m0, n0, kbeg, nt, &es);
         if constexpr (FUSED == 0 && !parked_slab) return;
     } else {
         const int r = lane & 31, h = lane >> 5;
-        const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+        const int wm = (wave >> 1) * 64, wn = (wave & 1) * (BN / 2);
         if constexpr (FUSED == 0 && LA == LAY_MN && LB == LAY_MN) {
             if (g.db.on) {              // data-parallel: bias / cost half of the previous step's deferred update (same
                                         // arithmetic as update_kernel<true, true, true>'s leading blocks)
@@ -589,11 +599,12 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
             }
         }
         if constexpr (MS == 16) {
-            pf32x4a acc[4][4];
+            constexpr int NBH = BN / 64, NBB = 2 * NBH;          // 16-column blocks of a wave's tile
+            pf32x4a acc[4][NBB];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = pf32x4a{0.f, 0.f, 0.f, 0.f};
+                for (int b = 0; b < NBB; ++b) acc[a][b] = pf32x4a{0.f, 0.f, 0.f, 0.f};
 #ifdef MDBN_STAMP
 #define PL_MSTAMP(SLOT)                                                                       \
     do {                                                                                      \
@@ -612,9 +623,9 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
 #endif
 #ifdef MDBN_STAMP
             long long bw = 0;
-            pl_consume16<LA, LB, AP>(smem, nt, lane, wm, wn, acc, false, &bw);
+            pl_consume16<LA, LB, AP, NBH>(smem, nt, lane, wm, wn, acc, false, &bw);
 #else
-            pl_consume16<LA, LB, AP>(smem, nt, lane, wm, wn, acc, false);
+            pl_consume16<LA, LB, AP, NBH>(smem, nt, lane, wm, wn, acc, false);
 #endif
             PL_MSTAMP(10);
 #ifdef MDBN_STAMP
@@ -627,11 +638,11 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
             const int c16 = lane & 15, q4 = lane >> 4;
             if constexpr (FUSED != 0 || parked_slab) {
                 float* T = reinterpret_cast<float*>(smem);
-                constexpr int LDT = 128 + 8;
+                constexpr int LDT = BN + 8;
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
+                    for (int b = 0; b < NBB; ++b)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             T[(wm + 16 * a + 4 * q4 + e) * LDT + wn + 16 * b + c16] = acc[a][b][e];
@@ -645,7 +656,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
+                    for (int b = 0; b < NBB; ++b)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (PL_DIAG_DIRTY != 2 || acc[a][b][e] == 12345.678f)
@@ -806,7 +817,8 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
         __syncthreads();
         float* T = reinterpret_cast<float*>(smem);
         constexpr int NT = 64 * (4 + PL_LW);
-        if constexpr (FUSED == 1) fused_tile_epilogue<128, 128, NT>(g.epi, T, m0, n0);
+        if constexpr (FUSED == 1 && BN == 64) fused_tile_epilogue_4x4<NT>(g.epi, T, m0, n0);     // one pass, loads up front
+        else if constexpr (FUSED == 1) fused_tile_epilogue<128, BN, NT>(g.epi, T, m0, n0);
         else if (MS == 16 && g.upd.early == 1) {     // W went early (pl_loader); the loader waves hold speed_old (+ W0)
             if (wave >= 4) {
                 const int lt = (wave - 4) * 64 + lane;
@@ -827,10 +839,10 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
     }
 }
 
-template <int LA, int LB, int AP, int FUSED, int MS>
+template <int LA, int LB, int AP, int FUSED, int MS, int BN = 128>
 static hipError_t launch_planes_m(const PlaneGemmArgs& g, hipStream_t s)
 {
-    auto kern = gemm_planes_kernel<LA, LB, AP, FUSED, MS>;
+    auto kern = gemm_planes_kernel<LA, LB, AP, FUSED, MS, BN>;
     static bool attr_set = false;
     constexpr int lds = PL_NSTAGE * PL_STAGE;        // 144 KB (the parked tile of the epilogues, 70 KB, reuses it)
     if (!attr_set) {
@@ -851,6 +863,12 @@ static hipError_t launch_planes_t(const PlaneGemmArgs& g, hipStream_t s)
 
 hipError_t launch_gemm_planes(int la, int lb, const PlaneGemmArgs& g, hipStream_t s)
 {
+    if (g.bn == 64) {       // unsplit forward pass on 128 x 64 tiles with the fused activation epilogue (propdown)
+        if (g.M % 128 || g.N % 64 || g.K % 32 || g.kchunk != g.K || g.splitk != 1 || g.tiles_m != g.M / 128 || g.tiles_n != g.N / 64 ||
+            (g.lda & 7) || (g.ldb & 7) || g.fused != 1 || la != LAY_K || lb != LAY_K || g.ms != 16 || (g.ap != 1 && g.ap != 3))
+            return hipErrorInvalidValue;
+        return g.ap == 1 ? launch_planes_m<LAY_K, LAY_K, 1, 1, 16, 64>(g, s) : launch_planes_m<LAY_K, LAY_K, 3, 1, 16, 64>(g, s);
+    }
     if (g.M % 128 || g.N % 128 || g.kchunk % 32 || g.kchunk * g.splitk != g.K || g.tiles_m != g.M / 128 ||
         g.tiles_n != g.N / 128 || (g.lda & 7) || (g.ldb & 7) || ((g.fused == 1 || g.fused == 2) && g.splitk != 1) ||
         (g.ap != 0 && g.ap != 1 && g.ap != 3))
@@ -1034,6 +1052,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_bal_kernel(Plane
     }
     int offA[4][2], offB[4][2];
     pl_offsets16<LA, LB>(lane, wm, wn, offA, offB);
+    constexpr int NBH = 2;
     PL_CONSUME_CONSTS();
     pbf16x8 Alo[3][2], Ahi[3][2], Blo[3][2], Bhi[3][2];
     pf32x4a acc[4][4];

@@ -10,8 +10,8 @@ out = os.path.join(tempfile.gettempdir(), "mdbn_planes_audit.s")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
                       cwd=os.path.dirname(src), stderr=subprocess.DEVNULL)
 text = open(out).read()
-kerns = ["_ZN4mdbn18gemm_planes_kernelILi1ELi1ELi3ELi2ELi16EEEvNS_13PlaneGemmArgsE",      # statistics + fused update
-         "_ZN4mdbn18gemm_planes_kernelILi1ELi1ELi3ELi0ELi16EEEvNS_13PlaneGemmArgsE"]      # statistics, data-parallel (deferred update)
+kerns = ["_ZN4mdbn18gemm_planes_kernelILi1ELi1ELi3ELi2ELi16ELi128EEEvNS_13PlaneGemmArgsE",      # statistics + fused update
+         "_ZN4mdbn18gemm_planes_kernelILi1ELi1ELi3ELi0ELi16ELi128EEEvNS_13PlaneGemmArgsE"]      # statistics, data-parallel (deferred update)
 body = ""
 for kern in kerns:
     part = text[text.index("\n" + kern + ":"):]

@@ -148,10 +148,15 @@ def test_w_planes_follow_every_way_w_changes(hip_engine):
     assert in_step()
 
 
-def test_plane_step_against_oracle_teacher_forced(hip_engine):
-    """One CD-2 step of a Bernoulli RBM on the plane path with the chain taps on, oracle following the device."""
+@pytest.mark.parametrize("V,H,B,k,narrow", [(1024, 512, 256, 2, None), (4096, 1024, 512, 2, 1), (4096, 1024, 512, 2, 0)])
+def test_plane_step_against_oracle_teacher_forced(hip_engine, V, H, B, k, narrow):
+    """One CD-2 step of a Bernoulli RBM on the plane path with the chain taps on, oracle following the device.  At the
+    headline shape propdown runs unsplit on 128 x 64 tiles with the activation on the parked tile (option
+    "narrow_tiles", default on: the timing records must show that kernel) or split two ways + epilogue launch."""
     from mdbn_amd import RngAddr
-    V, H, B, k = 1024, 512, 256, 2
+    if narrow is not None:
+        hip_engine.set_option("narrow_tiles", narrow)
+        hip_engine.kernel_timing(True)
     rs = np.random.RandomState(3)
     W = rbm_np.init_W(rs, V, H, np.float32)
     hb, vb = rs.normal(0, 0.2, H).astype(np.float32), rs.normal(0, 0.2, V).astype(np.float32)
@@ -163,8 +168,15 @@ def test_plane_step_against_oracle_teacher_forced(hip_engine):
         stats, sc = eng.cd_step(dx, None, dW, dhb, dvb, False, k, RngAddr(11, 1, 2, 0, 0))
         assert sc.planes is not None
         th, tv = sc.trace_h.cpu().numpy(), sc.trace_v.cpu().numpy()
+        if narrow is not None:
+            eng.synchronize()
+            kinds = [kind for _, _, _, kind in eng.kernel_timing_detail()]
+            assert (kinds.count(2210) == k) == bool(narrow), kinds      # 2210: fused propdown (128 x 64 tiles)
     finally:
         eng.trace_chain = False
+        if narrow is not None:
+            eng.kernel_timing(False)
+            eng.set_option("narrow_tiles", 1)
     st = rbm_np.RBMState(V, H, W=W, hbias=hb, vbias=vb, gauss=False)
     v0 = x.astype(np.float64)
     ph, _, out, flips = rbm_np.cd_chain_forced(st, v0, PhiloxDraws(11, 1, 2, 0), k, th, tv)
@@ -201,7 +213,9 @@ def test_balanced_launches_match_and_repeat(hip_engine, gauss, V, H, B, k, comm_
     for key in ("W", "Ws", "hb", "vbs"):
         scale = max(1e-3, np.abs(ref[key]).max())
         assert np.isfinite(runs[0][key]).all(), key
-        assert np.abs(runs[0][key] - ref[key]).max() <= 2e-5 * scale, key
+        # fp32 summation order only; widest measured 2.3e-5 (hb of the 1024 x 2048 layer, whose reference step runs
+        # propdown unsplit on 128 x 64 tiles while the balanced one sums per-segment slabs)
+        assert np.abs(runs[0][key] - ref[key]).max() <= 4e-5 * scale, key
     np.testing.assert_allclose(runs[0]["costs"], ref["costs"], rtol=1e-4)
     for other in runs[1:]:
         for key in runs[0]:
