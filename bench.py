@@ -474,11 +474,14 @@ def main():
             _, up_h = rbm_h.get_cost_updates(lr=LR, k=K_GIBBS, lambda_1=LAMBDA_1, lambda_2=LAMBDA_2, batch_size=B_global)
             fn_h = mdbn_amd.function(up_h, host_x)
 
+            host_perm = perm.cpu()
+
             def run_host(n, announce):
+                views = [perm[(it % n_mb) * B_global:(it % n_mb + 1) * B_global] for it in range(n)]
+                if announce:      # the order of the coming steps, as the trainers announce an epoch's
+                    fn_h.announce(views, host_indexes=[host_perm[(it % n_mb) * B_global:(it % n_mb + 1) * B_global] for it in range(n)])
                 for it in range(n):
-                    mb, nb = it % n_mb, (it + 1) % n_mb
-                    fn_h(indexes=perm[mb * B_global:(mb + 1) * B_global], momentum=0.0,
-                         next_indexes=perm[nb * B_global:(nb + 1) * B_global] if announce else None)
+                    fn_h(indexes=views[it], momentum=0.0)
             res = {}
             for announce in (True, False):
                 run_host(args.warmup, announce)
@@ -487,11 +490,14 @@ def main():
                 run_host(10 * args.steps, announce)
                 torch.cuda.synchronize(dev)
                 res[announce] = 1e3 * (time.perf_counter() - t0) / (10 * args.steps)
-            pcie = {"ms_per_step": res[True], "samples_per_s": B_global * 1e3 / res[True],
+            feed = fn_h._staging["feeder"].stats() if fn_h._staging and fn_h._staging.get("feeder") else None
+            pcie = {"ms_per_step": res[True], "samples_per_s": B_global * 1e3 / res[True], "feeder_host_times": feed,
                     "ms_per_step_without_prefetch": res[False],
                     "minibatch_bytes": 4 * B_global * V,
-                    "note": "training table in pinned host memory; minibatch rows gathered over PCIe by the library's gather "
-                            "kernel on a side stream, one step ahead (StepFunction.prefetch); NOT `value`"}
+                    "note": "training table in pinned host memory; announced minibatches are gathered by 8 CPU threads into "
+                            "pinned staging and moved by one SDMA copy each, three slots deep (mdbn_feeder_*, "
+                            "StepFunction.announce); unannounced ones by the library's PCIe gather kernel on the spot; "
+                            "NOT `value`"}
             del host_x, fn_h, rbm_h
         except Exception as exc:                    # reporting figure only
             pcie = {"error": repr(exc)[:200]}

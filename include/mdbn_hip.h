@@ -242,6 +242,39 @@ int  mdbn_gather_rows_host(mdbn_ctx *ctx, void *stream, const float *src, int64_
                            int64_t cols, int64_t ld_src, const void *indexes, int index_is_64,
                            int64_t n_idx, float *dst, int64_t ld_dst, int workgroups, int threads);
 
+/* out[r] = table[indexes[r]] on the HOST, by `threads` CPU threads (row-sized memcpys; indexes NULL = the first n rows):
+ * the host half of the row feeder below, callable on its own (no GPU needed).  MDBN_EINVAL on an index outside
+ * [0, n_rows). */
+int  mdbn_host_gather_rows(const float *table, int64_t n_rows, int64_t cols, int64_t ld,
+                           const int64_t *indexes, int64_t n, float *out, int64_t ld_out, int threads);
+
+/* ROW FEEDER of a host-resident training table (the streamed form of src/utils.py:113-115's table for data that is not
+ * uploaded whole) that keeps the CUs out of it: `threads` CPU threads gather a minibatch's rows into a pinned staging
+ * slot, ONE hipMemcpyAsync moves the slot to the device on the feeder's own copy stream (SDMA), the consuming stream
+ * waits for that copy's event.  Unlike mdbn_gather_rows_host's kernel, which slows every GEMM it runs beside, the copy
+ * costs the step nothing; the ring of `slots` (>= 2; 3 keeps two minibatches in flight beside the one being read) hides
+ * the gather and the PCIe time behind the steps.
+ *   create : table [n_rows, ld] in host memory (pinned or pageable), device_slots[slots] device buffers of
+ *            [max_rows, ld_device] floats owned by the caller (pad columns are written as zero);
+ *   submit : queue a minibatch (the indexes are copied; NULL = rows 0 .. n-1); returns at once with a ticket;
+ *   acquire: tickets in submission order; blocks the HOST until the ticket's copy has been enqueued, makes `stream` wait
+ *            for it, returns the slot whose device buffer holds the rows;
+ *   release: the work that reads the slot has been enqueued on `stream`: the slot may be overwritten after it;
+ *   cancel : forget everything submitted and not acquired.
+ * Thread-safe against its own worker threads; the calls themselves are for one host thread. */
+typedef struct mdbn_feeder mdbn_feeder;
+int  mdbn_feeder_create(mdbn_ctx *ctx, const float *table, int64_t n_rows, int64_t cols, int64_t ld,
+                        int64_t max_rows, int slots, float *const *device_slots, int64_t ld_device,
+                        int threads, mdbn_feeder **out);
+int  mdbn_feeder_submit(mdbn_feeder *f, const int64_t *indexes, int64_t n, int64_t *ticket);
+int  mdbn_feeder_acquire(mdbn_feeder *f, int64_t ticket, void *stream, int *slot);
+int  mdbn_feeder_release(mdbn_feeder *f, int64_t ticket, void *stream);
+/* host-side time per stage since the last call: out5 = { minibatches fed, mean gather us, mean copy-enqueue us,
+ * acquires, mean host wait in acquire us }; resets the counters */
+int  mdbn_feeder_stats(mdbn_feeder *f, double *out5);
+int  mdbn_feeder_cancel(mdbn_feeder *f);
+int  mdbn_feeder_destroy(mdbn_feeder *f);
+
 /* propup + sample_h_given_v (src/rbm.py:187-213), also HiddenLayer.output (src/mlp.py:103-107):
  * pre = v W + hbias ; mean = sigmoid(pre) ; sample = (u < mean).
  * pre / mean / sample may each be NULL; mean is stored multiplied by mean_scale. */

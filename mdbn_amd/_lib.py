@@ -71,6 +71,14 @@ SIGNATURES = {
     "mdbn_stats_floats": [_i64, _i64, _i64, C.POINTER(_i64)],
     "mdbn_gather_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _i64, _vp, _i64],
     "mdbn_gather_rows_host": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _i64, _vp, _i64, _i32, _i32],
+    "mdbn_host_gather_rows": [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i32],
+    "mdbn_feeder_create": [_vp, _vp, _i64, _i64, _i64, _i64, _i32, C.POINTER(_vp), _i64, _i32, C.POINTER(_vp)],
+    "mdbn_feeder_submit": [_vp, _vp, _i64, C.POINTER(_i64)],
+    "mdbn_feeder_acquire": [_vp, _i64, _vp, C.POINTER(_i32)],
+    "mdbn_feeder_release": [_vp, _i64, _vp],
+    "mdbn_feeder_stats": [_vp, C.POINTER(C.c_double)],
+    "mdbn_feeder_cancel": [_vp],
+    "mdbn_feeder_destroy": [_vp],
     "mdbn_propup_sample": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp,
                            _vp, _vp, _f32, _vp, _rngp, _vp, _i64],
     "mdbn_propdown_sample": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i32, _i32,

@@ -2,8 +2,17 @@
 // planning, workspace carving and the launch sequence of one CD-k step.  No allocation,
 // no synchronisation: every entry point only enqueues kernels on the caller's stream.
 #include <hip/hip_runtime.h>
+#include <emmintrin.h>
 #include <dlfcn.h>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <set>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -209,6 +218,9 @@ static int g_opt_early_w = 1;
 // mdbn_set_option("narrow_tiles"): forward passes whose 128 x 128 plan would split K two ways run unsplit on 128 x 64 tiles
 // with the fused activation epilogue instead (default on)
 static int g_opt_narrow_tiles = 1;
+// mdbn_set_option("feed_copy_streams"): a row feeder created afterwards moves each minibatch as 1 or 2 copies on as many
+// streams (two SDMA engines side by side)
+static int g_opt_feed_copy_streams = 1;
 // mdbn_set_option("gather_ahead"): honour mdbn_cd_args.next_indexes (default on; same bits)
 static int g_opt_gather_ahead = 1;
 // mdbn_set_option("bf16_inputs"): REPORTING mode of BASELINE configs[1] ("bf16/fp32"): the plane GEMMs use only the
@@ -992,6 +1004,11 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
         g_opt_narrow_tiles = value != 0;
         return MDBN_OK;
     }
+    if (strcmp(name, "feed_copy_streams") == 0) {
+        REQUIRE(value == 1 || value == 2, "feed_copy_streams must be 1 or 2");
+        g_opt_feed_copy_streams = value;
+        return MDBN_OK;
+    }
     if (strcmp(name, "gather_ahead") == 0) {
         g_opt_gather_ahead = value != 0;
         return MDBN_OK;
@@ -1739,6 +1756,412 @@ int mdbn_philox_host(float* out, int64_t rows, int64_t cols, int64_t ld, const m
             out[r * ld + c] = philox_u01(w[g & 3]);
         }
     }
+    return MDBN_OK;
+}
+
+// ---------------------------------------------------------------------------------- row feeder (host-resident table)
+// Minibatch rows of a table that stays in host memory reach the device WITHOUT a kernel on the CUs: worker threads
+// gather the rows into a pinned staging slot, one hipMemcpyAsync per minibatch moves the slot on the feeder's own copy
+// stream (SDMA), the consuming stream waits for the copy's event.  A kernel reading the pinned table over PCIe beside the
+// step slows every GEMM of the step (one-workgroup-per-CU grids: step 145 -> 215 us); an SDMA copy
+// does not (145.7 -> 147.3 us).  The ring is `slots` deep so the copy of minibatch t + 2 runs beside step t.
+namespace {
+struct RowPool {                                  // persistent worker threads: out[r] = table[idx[r]]
+    // Workers SPIN for a job for up to 2 ms after the last one before they sleep on the condition variable: a feed delivers a
+    // minibatch every ~170 us, and waking a sleeping thread costs 50+ us each on the GPU box's host (8.4 MB gathered in
+    // 228 us with sleeping workers, 85 us with spinning ones).  An idle pool sleeps.
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_work;
+    const float* src = nullptr; int64_t ld_src = 0, n_rows = 0, cols = 0;
+    const int64_t* idx = nullptr; int64_t n = 0;
+    float* dst = nullptr; int64_t ld_dst = 0;
+    std::atomic<int64_t> next{0};
+    std::atomic<int> bad{0};
+    std::atomic<uint64_t> generation{0};
+    std::atomic<int> running{0}, sleepers{0};
+    std::atomic<bool> stop{false};
+
+    static void relax() { __builtin_ia32_pause(); }
+    // one row into the staging slot with NON-TEMPORAL stores: the slot is read next by the copy engine, not by a CPU, and a
+    // plain memcpy first reads every destination line for ownership (3 bytes of traffic per byte copied instead of 2)
+    static void copy_row(float* d, const float* s, size_t bytes)
+    {
+        if ((reinterpret_cast<uintptr_t>(d) & 15u) != 0 || bytes < 256) { memcpy(d, s, bytes); return; }
+        const __m128i* sp = reinterpret_cast<const __m128i*>(s);
+        __m128i* dp = reinterpret_cast<__m128i*>(d);
+        size_t q = bytes / 64;
+        for (; q > 0; --q, sp += 4, dp += 4) {
+            const __m128i a = _mm_loadu_si128(sp), b = _mm_loadu_si128(sp + 1), c = _mm_loadu_si128(sp + 2), e = _mm_loadu_si128(sp + 3);
+            _mm_stream_si128(dp, a); _mm_stream_si128(dp + 1, b); _mm_stream_si128(dp + 2, c); _mm_stream_si128(dp + 3, e);
+        }
+        const size_t done = bytes / 64 * 64;
+        if (done < bytes) memcpy(reinterpret_cast<char*>(d) + done, reinterpret_cast<const char*>(s) + done, bytes - done);
+    }
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+    explicit RowPool(int threads)
+    {
+        for (int t = 0; t < threads; ++t) workers.emplace_back([this] { loop(); });
+    }
+    ~RowPool()
+    {
+        { std::lock_guard<std::mutex> l(m); stop.store(true); }
+        cv_work.notify_all();
+        for (auto& w : workers) w.join();
+    }
+    void rows()                                   // a few rows at a time: contiguous row copies, dynamic balance
+    {
+        constexpr int64_t CHUNK = 4;
+        for (;;) {
+            const int64_t r0 = next.fetch_add(CHUNK);
+            if (r0 >= n) break;
+            for (int64_t r = r0; r < std::min(n, r0 + CHUNK); ++r) {
+                const int64_t s = idx ? idx[r] : r;
+                if (s < 0 || s >= n_rows) { bad.store(1); continue; }
+                copy_row(dst + r * ld_dst, src + s * ld_src, (size_t)cols * sizeof(float));
+            }
+        }
+        _mm_sfence();                             // the streamed rows are globally visible before this thread checks in
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const double give_up = now() + 2e-3;
+            int spins = 0;
+            while (generation.load(std::memory_order_acquire) == seen && !stop.load()) {
+                relax();
+                if ((++spins & 1023) == 0 && now() > give_up) {
+                    std::unique_lock<std::mutex> l(m);
+                    sleepers.fetch_add(1);
+                    cv_work.wait(l, [&] { return stop.load() || generation.load(std::memory_order_acquire) != seen; });
+                    sleepers.fetch_sub(1);
+                }
+            }
+            if (stop.load()) return;
+            seen = generation.load(std::memory_order_acquire);
+            rows();
+            running.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    // one gather at a time (the feeder's dispatcher, or mdbn_host_gather_rows's private pool)
+    bool gather(const float* src_, int64_t n_rows_, int64_t cols_, int64_t ld_src_, const int64_t* idx_, int64_t n_,
+                float* dst_, int64_t ld_dst_)
+    {
+        src = src_; n_rows = n_rows_; cols = cols_; ld_src = ld_src_; idx = idx_; n = n_; dst = dst_; ld_dst = ld_dst_;
+        next.store(0); bad.store(0);
+        running.store((int)workers.size());
+        {
+            std::lock_guard<std::mutex> l(m);     // a worker between its predicate and its wait holds this lock
+            generation.fetch_add(1, std::memory_order_release);
+        }
+        if (sleepers.load() > 0) cv_work.notify_all();
+        rows();                                   // the calling thread works too
+        int spins = 0;
+        while (running.load(std::memory_order_acquire) != 0) {      // every worker checks in: none still reads this job
+            relax();
+            if ((++spins & 4095) == 0) std::this_thread::yield();
+        }
+        return bad.load() == 0;
+    }
+};
+}  // namespace
+
+struct mdbn_feeder {
+    int device = 0;
+    const float* table = nullptr; int64_t n_rows = 0, cols = 0, ld = 0, max_rows = 0, ld_dev = 0;
+    int slots = 0;
+    std::vector<float*> dev, staging;
+    std::vector<hipEvent_t> copied, consumed;
+    std::vector<char> copied_set, consumed_set, busy;
+    hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;     // the second one only with feed_copy_streams = 2
+    hipEvent_t half_done = nullptr, half_go = nullptr;
+    RowPool* pool = nullptr;
+    std::thread dispatcher;
+    std::mutex m;
+    std::condition_variable cv;
+    struct Job { int64_t ticket; std::vector<int64_t> idx; bool identity; int64_t n; };
+    struct Done { int slot; int rc; int64_t n; };
+    struct Staged { int64_t ticket; int slot; int rc; int64_t n; };
+    std::deque<Job> queue;                        // submitted
+    std::deque<Staged> staged;                    // gathered into pinned staging, copy not yet enqueued
+    std::set<int64_t> inflight;                   // taken off `queue`, not yet in `ready`
+    std::map<int64_t, Done> ready;                // copy enqueued, not yet acquired
+    std::map<int64_t, int> held;                  // acquired, not yet released: ticket -> slot
+    std::thread copier;
+    int64_t next_ticket = 0;
+    int next_slot = 0;
+    bool stop = false;
+    // host-side time spent per stage (mdbn_feeder_stats), seconds
+    double t_gather = 0, t_copy_call = 0, t_acquire_wait = 0;
+    int64_t n_fed = 0, n_acquired = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+    // stage 1 (dispatcher + pool): rows -> pinned staging slot
+    void run()
+    {
+        for (;;) {
+            Job job;
+            int slot;
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return stop || (!queue.empty() && !busy[next_slot]); });
+                if (stop) return;
+                job = std::move(queue.front());
+                queue.pop_front();
+                slot = next_slot;
+                next_slot = (next_slot + 1) % slots;
+                busy[slot] = 1;
+                inflight.insert(job.ticket);
+            }
+            int rc = MDBN_OK;
+            // the staging slot is free once the copy that last read it has finished (long ago in steady state)
+            if (copied_set[slot] && hipEventSynchronize(copied[slot]) != hipSuccess) rc = MDBN_EHIP;
+            const double t0 = now();
+            if (rc == MDBN_OK && !pool->gather(table, n_rows, cols, ld, job.identity ? nullptr : job.idx.data(), job.n,
+                                               staging[slot], ld_dev))
+                rc = MDBN_EINVAL;
+            {
+                std::lock_guard<std::mutex> l(m);
+                t_gather += now() - t0;
+                staged.push_back(Staged{job.ticket, slot, rc, job.n});
+            }
+            cv.notify_all();
+        }
+    }
+    // stage 2 (copier): staging slot -> device slot, one copy on the copy stream.  Its own thread: enqueueing an 8-MB
+    // hipMemcpyAsync takes the host ~100 us, during which stage 1 gathers the next minibatch.
+    void copy_loop()
+    {
+        (void)hipSetDevice(device);
+        for (;;) {
+            Staged st;
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return stop || !staged.empty(); });
+                if (stop) return;
+                st = staged.front();
+                staged.pop_front();
+            }
+            int rc = st.rc;
+            const double t0 = now();
+            if (rc == MDBN_OK) {
+                // the device slot is free once the step that last read it has finished: stream order, no host wait
+                hipError_t e = consumed_set[st.slot] ? hipStreamWaitEvent(copy_stream, consumed[st.slot], 0) : hipSuccess;
+                const int64_t n1 = copy_stream2 ? (st.n + 1) / 2 : st.n;       // rows of the first copy
+                if (e == hipSuccess && copy_stream2 && st.n > n1) {
+                    // second half on the second stream, ordered after the same "slot is free" point
+                    e = hipEventRecord(half_go, copy_stream);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(copy_stream2, half_go, 0);
+                    if (e == hipSuccess)
+                        e = hipMemcpyAsync(dev[st.slot] + n1 * ld_dev, staging[st.slot] + n1 * ld_dev,
+                                           (size_t)(st.n - n1) * ld_dev * sizeof(float), hipMemcpyHostToDevice, copy_stream2);
+                    if (e == hipSuccess) e = hipEventRecord(half_done, copy_stream2);
+                }
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(dev[st.slot], staging[st.slot], (size_t)n1 * ld_dev * sizeof(float), hipMemcpyHostToDevice,
+                                       copy_stream);
+                if (e == hipSuccess && copy_stream2 && st.n > n1) e = hipStreamWaitEvent(copy_stream, half_done, 0);
+                if (e == hipSuccess) e = hipEventRecord(copied[st.slot], copy_stream);
+                if (e != hipSuccess) rc = MDBN_EHIP;
+                else copied_set[st.slot] = 1;
+            }
+            {
+                std::lock_guard<std::mutex> l(m);
+                ready[st.ticket] = Done{st.slot, rc, st.n};
+                inflight.erase(st.ticket);
+                t_copy_call += now() - t0;
+                ++n_fed;
+            }
+            cv.notify_all();
+        }
+    }
+};
+
+int mdbn_host_gather_rows(const float* table, int64_t n_rows, int64_t cols, int64_t ld, const int64_t* indexes, int64_t n,
+                          float* out, int64_t ld_out, int threads)
+{
+    REQUIRE(table && out && n_rows > 0 && cols > 0 && ld >= cols && ld_out >= cols && n >= 0, "bad arguments");
+    REQUIRE(threads >= 1 && threads <= 64, "threads must be in [1, 64]");
+    REQUIRE(indexes != nullptr || n <= n_rows, "identity gather longer than the table");
+    RowPool pool(threads - 1);
+    if (!pool.gather(table, n_rows, cols, ld, indexes, n, out, ld_out)) return fail(MDBN_EINVAL, "row index out of range");
+    return MDBN_OK;
+}
+
+int mdbn_feeder_create(mdbn_ctx* ctx, const float* table, int64_t n_rows, int64_t cols, int64_t ld, int64_t max_rows,
+                       int slots, float* const* device_slots, int64_t ld_device, int threads, mdbn_feeder** out)
+{
+    REQUIRE(ctx != nullptr && out != nullptr, "ctx / out is NULL");
+    REQUIRE(table && n_rows > 0 && cols > 0 && ld >= cols && max_rows > 0, "bad table");
+    REQUIRE(slots >= 2 && slots <= 16 && device_slots != nullptr, "slots must be in [2, 16]");
+    REQUIRE(ld_device >= cols && ld_device % 4 == 0, "bad device leading dimension");
+    REQUIRE(threads >= 1 && threads <= 64, "threads must be in [1, 64]");
+    for (int i = 0; i < slots; ++i) REQUIRE(device_slots[i] && aligned16(device_slots[i]), "device slot NULL / not 16-byte aligned");
+    HIP_OK(hipSetDevice(ctx->device));
+    mdbn_feeder* f = new mdbn_feeder;
+    f->device = ctx->device;
+    f->table = table; f->n_rows = n_rows; f->cols = cols; f->ld = ld; f->max_rows = max_rows; f->ld_dev = ld_device;
+    f->slots = slots;
+    f->copied_set.assign(slots, 0); f->consumed_set.assign(slots, 0); f->busy.assign(slots, 0);
+    hipError_t e = hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess && g_opt_feed_copy_streams == 2) {
+        e = hipStreamCreateWithFlags(&f->copy_stream2, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&f->half_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&f->half_go, hipEventDisableTiming);
+    }
+    for (int i = 0; i < slots && e == hipSuccess; ++i) {
+        float* st = nullptr;
+        hipEvent_t a = nullptr, b = nullptr;
+        e = hipHostMalloc(reinterpret_cast<void**>(&st), (size_t)max_rows * ld_device * sizeof(float), hipHostMallocDefault);
+        if (e == hipSuccess) { memset(st, 0, (size_t)max_rows * ld_device * sizeof(float)); f->staging.push_back(st); }   // pad columns stay zero
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&a, hipEventDisableTiming);
+        if (e == hipSuccess) { f->copied.push_back(a); e = hipEventCreateWithFlags(&b, hipEventDisableTiming); }
+        if (e == hipSuccess) f->consumed.push_back(b);
+        f->dev.push_back(device_slots[i]);
+    }
+    if (e != hipSuccess) {
+        for (float* st : f->staging) (void)hipHostFree(st);
+        for (hipEvent_t ev : f->copied) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : f->consumed) (void)hipEventDestroy(ev);
+        if (f->half_done) (void)hipEventDestroy(f->half_done);
+        if (f->half_go) (void)hipEventDestroy(f->half_go);
+        if (f->copy_stream2) (void)hipStreamDestroy(f->copy_stream2);
+        if (f->copy_stream) (void)hipStreamDestroy(f->copy_stream);
+        delete f;
+        return fail(MDBN_EHIP, "row feeder: %s", hipGetErrorString(e));
+    }
+    f->pool = new RowPool(threads - 1);           // the dispatcher thread is the pool's last worker
+    f->dispatcher = std::thread([f] { f->run(); });
+    f->copier = std::thread([f] { f->copy_loop(); });
+    *out = f;
+    return MDBN_OK;
+}
+
+int mdbn_feeder_submit(mdbn_feeder* f, const int64_t* indexes, int64_t n, int64_t* ticket)
+{
+    REQUIRE(f != nullptr && ticket != nullptr, "feeder / ticket is NULL");
+    REQUIRE(n > 0 && n <= f->max_rows, "row count outside (0, max_rows]");
+    REQUIRE(indexes != nullptr || n <= f->n_rows, "identity gather longer than the table");
+    mdbn_feeder::Job job;
+    job.identity = indexes == nullptr;
+    job.n = n;
+    if (indexes) job.idx.assign(indexes, indexes + n);          // the caller's array may go away
+    {
+        std::lock_guard<std::mutex> l(f->m);
+        job.ticket = *ticket = f->next_ticket++;
+        f->queue.push_back(std::move(job));
+    }
+    f->cv.notify_all();
+    return MDBN_OK;
+}
+
+int mdbn_feeder_acquire(mdbn_feeder* f, int64_t ticket, void* stream, int* slot)
+{
+    REQUIRE(f != nullptr && slot != nullptr, "feeder / slot is NULL");
+    mdbn_feeder::Done d;
+    {
+        std::unique_lock<std::mutex> l(f->m);
+        bool pending = f->ready.count(ticket) != 0 || f->inflight.count(ticket) != 0;
+        if (!pending)
+            for (const auto& j : f->queue) pending = pending || j.ticket == ticket;
+        if (!pending) return fail(MDBN_EINVAL, "row feeder: ticket %lld is not pending", (long long)ticket);
+        // tickets are served in submission order on a ring of `slots`: with every slot held by the caller the ring cannot
+        // reach this ticket
+        if (!f->ready.count(ticket) && (int)f->held.size() >= f->slots)
+            return fail(MDBN_EINVAL, "row feeder: all %d slots are held; release one before acquiring ticket %lld", f->slots,
+                        (long long)ticket);
+        const double t0 = mdbn_feeder::now();
+        f->cv.wait(l, [&] { return f->ready.count(ticket) != 0 || f->stop; });
+        f->t_acquire_wait += mdbn_feeder::now() - t0;
+        ++f->n_acquired;
+        if (!f->ready.count(ticket)) return fail(MDBN_EINVAL, "row feeder: shut down");
+        d = f->ready[ticket];
+        f->ready.erase(ticket);
+        if (d.rc != MDBN_OK) {
+            f->busy[d.slot] = 0;
+            l.unlock();
+            f->cv.notify_all();
+            return fail(d.rc, d.rc == MDBN_EINVAL ? "row feeder: row index out of range" : "row feeder: a HIP call failed");
+        }
+        f->held[ticket] = d.slot;
+    }
+    HIP_OK(hipStreamWaitEvent((hipStream_t)stream, f->copied[d.slot], 0));
+    *slot = d.slot;
+    return MDBN_OK;
+}
+
+int mdbn_feeder_release(mdbn_feeder* f, int64_t ticket, void* stream)
+{
+    REQUIRE(f != nullptr, "feeder is NULL");
+    int slot;
+    {
+        std::lock_guard<std::mutex> l(f->m);
+        auto it = f->held.find(ticket);
+        if (it == f->held.end()) return fail(MDBN_EINVAL, "row feeder: ticket %lld is not held", (long long)ticket);
+        slot = it->second;
+        f->held.erase(it);
+    }
+    HIP_OK(hipEventRecord(f->consumed[slot], (hipStream_t)stream));
+    {
+        std::lock_guard<std::mutex> l(f->m);
+        f->consumed_set[slot] = 1;
+        f->busy[slot] = 0;
+    }
+    f->cv.notify_all();
+    return MDBN_OK;
+}
+
+int mdbn_feeder_stats(mdbn_feeder* f, double* out5)
+{
+    REQUIRE(f != nullptr && out5 != nullptr, "feeder / out is NULL");
+    std::lock_guard<std::mutex> l(f->m);
+    out5[0] = (double)f->n_fed;
+    out5[1] = f->n_fed ? 1e6 * f->t_gather / f->n_fed : 0.0;
+    out5[2] = f->n_fed ? 1e6 * f->t_copy_call / f->n_fed : 0.0;
+    out5[3] = (double)f->n_acquired;
+    out5[4] = f->n_acquired ? 1e6 * f->t_acquire_wait / f->n_acquired : 0.0;
+    f->t_gather = f->t_copy_call = f->t_acquire_wait = 0;
+    f->n_fed = f->n_acquired = 0;
+    return MDBN_OK;
+}
+
+int mdbn_feeder_cancel(mdbn_feeder* f)
+{
+    REQUIRE(f != nullptr, "feeder is NULL");
+    std::unique_lock<std::mutex> l(f->m);
+    f->queue.clear();
+    f->cv.wait(l, [&] { return f->inflight.empty(); });
+    for (auto& kv : f->ready) f->busy[kv.second.slot] = 0;     // uploaded (or failed) and never read
+    f->ready.clear();
+    l.unlock();
+    f->cv.notify_all();
+    return MDBN_OK;
+}
+
+int mdbn_feeder_destroy(mdbn_feeder* f)
+{
+    if (!f) return MDBN_OK;
+    {
+        std::lock_guard<std::mutex> l(f->m);
+        f->stop = true;
+    }
+    f->cv.notify_all();
+    if (f->dispatcher.joinable()) f->dispatcher.join();
+    if (f->copier.joinable()) f->copier.join();
+    delete f->pool;
+    (void)hipSetDevice(f->device);
+    if (f->copy_stream) (void)hipStreamSynchronize(f->copy_stream);
+    if (f->copy_stream2) (void)hipStreamSynchronize(f->copy_stream2);
+    if (f->half_done) (void)hipEventDestroy(f->half_done);
+    if (f->half_go) (void)hipEventDestroy(f->half_go);
+    if (f->copy_stream2) (void)hipStreamDestroy(f->copy_stream2);
+    for (float* st : f->staging) (void)hipHostFree(st);
+    for (hipEvent_t ev : f->copied) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : f->consumed) (void)hipEventDestroy(ev);
+    if (f->copy_stream) (void)hipStreamDestroy(f->copy_stream);
+    delete f;
     return MDBN_OK;
 }
 

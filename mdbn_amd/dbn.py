@@ -226,11 +226,14 @@ class DBN(object):
             batches = get_minibatches_idx(data.shape[0], batch_size, shuffle=True, rng=self.shuffle_rng)[1]
             order = self.engine.index_tensor(numpy.concatenate(batches))
             bounds = numpy.cumsum([0] + [len(b) for b in batches])
+            views = [order[bounds[mb]:bounds[mb + 1]] for mb in range(len(batches))]
+            if hasattr(step_fn, "announce"):            # the epoch's order (a host-resident table starts feeding its rows)
+                step_fn.announce(views, host_indexes=batches)
             for mb in range(len(batches)):
                 hint = {}
                 if hinted and mb + 1 < len(batches):    # the next minibatch of the epoch (a pure hint: StepFunction.__call__)
-                    hint["next_indexes"] = order[bounds[mb + 1]:bounds[mb + 2]]
-                cost = step_fn(indexes=order[bounds[mb]:bounds[mb + 1]], momentum=momentum, lr=lr, **hint)
+                    hint["next_indexes"] = views[mb + 1]
+                cost = step_fn(indexes=views[mb], momentum=momentum, lr=lr, **hint)
                 it = (epoch - 1) * n_batches + mb
                 if stop.due(it):
                     cost = float(cost)

@@ -88,6 +88,63 @@ class CDScratch(object):
         return self.planes_alt
 
 
+class RowFeeder(object):
+    """``mdbn_feeder_*`` (include/mdbn_hip.h): minibatches of a host-resident table, gathered by CPU threads into pinned
+    staging and moved by one copy each on the feeder's copy stream, ``slots`` deep.  ``submit`` returns a ticket at once;
+    ``acquire(ticket)`` (submission order) makes the current stream wait for that minibatch's copy and returns its device
+    rows; ``release(ticket)`` after the work reading them has been enqueued."""
+
+    def __init__(self, engine, host, cols, max_rows, slots, threads):
+        self.engine, self.host, self.cols, self.max_rows = engine, host, int(cols), int(max_rows)
+        self.bufs = [engine.alloc_matrix(self.max_rows, self.cols, host.stride(0)) for _ in range(slots)]
+        ptrs = (C.c_void_p * slots)(*[b.data_ptr() for b in self.bufs])
+        self.handle = C.c_void_p()
+        _lib.check(engine.lib.mdbn_feeder_create(engine.ctx, C.c_void_p(host.data_ptr()), host.shape[0], self.cols,
+                                                 host.stride(0), self.max_rows, slots, ptrs, self.bufs[0].stride(0),
+                                                 int(threads), C.byref(self.handle)), "mdbn_feeder_create")
+
+    def submit(self, indexes, n=None):
+        """``indexes``: CPU int64 tensor (or None with ``n``: the table's first n rows)."""
+        t = C.c_int64()
+        if indexes is None:
+            _lib.check(self.engine.lib.mdbn_feeder_submit(self.handle, None, int(n), C.byref(t)), "mdbn_feeder_submit")
+        else:
+            assert indexes.dtype == torch.int64 and indexes.device.type == "cpu" and indexes.is_contiguous()
+            _lib.check(self.engine.lib.mdbn_feeder_submit(self.handle, C.c_void_p(indexes.data_ptr()), indexes.numel(),
+                                                         C.byref(t)), "mdbn_feeder_submit")
+        return t.value
+
+    def acquire(self, ticket, rows):
+        slot = C.c_int32()
+        _lib.check(self.engine.lib.mdbn_feeder_acquire(self.handle, int(ticket), self.engine._stream(), C.byref(slot)),
+                   "mdbn_feeder_acquire")
+        return self.bufs[slot.value][:rows]
+
+    def release(self, ticket):
+        _lib.check(self.engine.lib.mdbn_feeder_release(self.handle, int(ticket), self.engine._stream()), "mdbn_feeder_release")
+
+    def stats(self):
+        """Host-side time per stage since the last call (resets): dict of counts and mean microseconds."""
+        out = (C.c_double * 5)()
+        _lib.check(self.engine.lib.mdbn_feeder_stats(self.handle, out), "mdbn_feeder_stats")
+        return {"fed": int(out[0]), "gather_us": out[1], "copy_enqueue_us": out[2], "acquired": int(out[3]),
+                "acquire_wait_us": out[4]}
+
+    def cancel(self):
+        _lib.check(self.engine.lib.mdbn_feeder_cancel(self.handle), "mdbn_feeder_cancel")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.engine.lib.mdbn_feeder_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HipEngine(object):
     name = "hip"
 
@@ -102,7 +159,7 @@ class HipEngine(object):
         _lib.check(self.lib.mdbn_ctx_create(C.byref(ctx), self.device.index or 0), "mdbn_ctx_create")
         self.ctx = ctx
         self._workspace = None
-        self._ws_key = (0, 0, 0)
+        self._ws_need = {}              # (B, V, H) -> bytes the library asks for (options that change it clear this)
         self._stats = {}
         self._scratch = {}
         self._cost_ring = torch.zeros(1024, dtype=torch.float32, device=self.device)
@@ -156,6 +213,7 @@ class HipEngine(object):
     trace_chain = False         # True: every CD step also records the samples its Gibbs chain feeds onward
     keep_f32 = False            # True: the plane path also stores the float32 copies of ph / nh / nv / samples in the
                                 # CD scratch (CDScratch.P2, V2[B:], hs, vs) for inspection; nothing on the path reads them
+    host_feed_threads = 8           # CPU threads of a RowFeeder's gather (85 us per 8.4-MB minibatch on the GPU box's host; 16: 67)
     host_gather_workgroups = 32     # workgroups x threads of the PCIe gather of a host-resident table (mdbn_gather_rows_host)
     host_gather_threads = 256
     check_indexes = False       # True: also range-check index lists that already live on the device (one sync)
@@ -184,15 +242,15 @@ class HipEngine(object):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def workspace(self, B, V, H):
-        """One shared workspace, grown to the largest (B, V, H) seen."""
-        kB, kV, kH = self._ws_key
-        if self._workspace is None or B > kB or V > kV or H > kH:
-            B, V, H = max(B, kB), max(V, kV), max(H, kH)
+        """One shared workspace, grown to the largest requirement seen.  The requirement is NOT monotone in (B, V, H) (a
+        smaller minibatch takes more split-K slabs), so every shape asks the library (cached per shape)."""
+        need = self._ws_need.get((B, V, H))
+        if need is None:
             n = C.c_int64()
             _lib.check(self.lib.mdbn_workspace_bytes(B, V, H, C.byref(n)), "mdbn_workspace_bytes")
-            nbytes = max(n.value, 8 << 20)
-            self._workspace = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.device)
-            self._ws_key = (B, V, H)
+            need = self._ws_need[(B, V, H)] = max(n.value, 8 << 20)
+        if self._workspace is None or self._workspace.numel() * 4 < need + 256:
+            self._workspace = torch.empty(need // 4 + 64, dtype=torch.float32, device=self.device)
         return self._workspace
 
     def new_stats_buffer(self, V, H, ldv=None, ldh=None):
@@ -251,6 +309,7 @@ class HipEngine(object):
         """Library tuning knob (mdbn_set_option), e.g. ``set_option('gemm_bk', 32)``; process-wide."""
         _lib.check(self.lib.mdbn_set_option(self.ctx, name.encode(), int(value)), "mdbn_set_option")
         self._scratch.clear()            # options decide which scratch a shape needs (planes, slabs)
+        self._ws_need.clear()            # ... and how many split-K slabs its workspace holds
 
     def w_planes(self, W, create=False):
         """(planes, valid) for a weight matrix: the [3, V, ldh] bf16 planes the library keeps in step with W, and
@@ -394,6 +453,11 @@ class HipEngine(object):
                 int(self.host_gather_workgroups), int(self.host_gather_threads)), "mdbn_gather_rows_host")
         self._keep_alive = (host, idx)           # until the next call: the kernel reads them asynchronously
         return out
+
+    def row_feeder(self, host, cols, max_rows, slots=3, threads=None):
+        """A ``RowFeeder`` over the host matrix ``host`` [n, ld] (``mdbn_feeder_*``: CPU gather threads + one SDMA copy per
+        minibatch on the feeder's own stream)."""
+        return RowFeeder(self, host, cols, max_rows, slots, self.host_feed_threads if threads is None else threads)
 
     # ------------------------------------------------------------------ CD-k
     @staticmethod

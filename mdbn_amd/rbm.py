@@ -107,7 +107,7 @@ class StepFunction(object):
                             and p.persistent is None and p.lambda_1 == 0.0
                             and (p.weightcost == 0.0 or p.W0 is not None))
         self._pending = None                # (work, stats, hyper-parameters, LazyCost) of the last step
-        self._staging = None                # double-buffered minibatch staging of a host-resident table
+        self._staging = None                # feed of a host-resident table (RowFeeder, announced minibatches)
         self._n_calls = 0
         # statistics buffers of the data-parallel path are OWNED by this step function: a deferred
         # update reads them a whole call later, so another step function of the same shape (two
@@ -160,69 +160,107 @@ class StepFunction(object):
         a, b = numpy.asarray(a), numpy.asarray(b)
         return a.shape == b.shape and bool((a == b).all())
 
-    def _staging_state(self):
+    # A host-resident table feeds the step through a RowFeeder (engine.row_feeder, mdbn_feeder_*): CPU threads gather an
+    # ANNOUNCED minibatch's rows into pinned staging, one SDMA copy moves them, three slots deep -- no kernel runs beside
+    # the step (a PCIe gather kernel there costs it 60 us).  Unannounced minibatches are gathered on the spot by the PCIe
+    # gather kernel, in stream order.
+    def _feed_state(self):
         if self._staging is None:
-            self._staging = {"bufs": [None, None], "slot": 0, "side": torch.cuda.Stream(self.engine.device), "next": None,
-                             "before_step": None}
+            from collections import deque
+            self._staging = {"feeder": None, "queue": deque(), "held": None, "now": None}
         return self._staging
 
-    def _stage_rows(self, table, indexes, slot, stream):
-        """Enqueue the gather of ``table[shard of indexes]`` into staging buffer ``slot`` on ``stream`` (the index list is
-        brought to the device on that stream too)."""
-        eng = self.engine
-        n_global = len(table) if indexes is None else len(indexes)
-        lo, hi = (0, n_global) if self.group is None else self.group.shard(n_global)
-        st = self._staging_state()
-        buf = st["bufs"][slot]
-        if buf is None or buf.shape[0] != hi - lo:
-            buf = st["bufs"][slot] = eng.alloc_matrix(hi - lo, table.cols, table.host.stride(0))
-        with torch.cuda.stream(stream):
-            idx = torch.arange(lo, hi, dtype=torch.int64, device=eng.device) if indexes is None else \
-                eng.index_tensor(indexes, len(table))[lo:hi]
-            idx.record_stream(stream)
-            buf.record_stream(stream)
-            if hi > lo:
-                table.rows(idx, out=buf)
-            ev = torch.cuda.Event()
-            ev.record(stream)
-        return buf, ev, n_global, lo, hi
+    def _shard(self, n_global):
+        return (0, n_global) if self.group is None else self.group.shard(n_global)
+
+    def announce(self, batches, host_indexes=None):
+        """Tell the step function which minibatches come next, in order (the trainers know the epoch's order up front):
+        with a host-resident table their rows start moving now, up to two minibatches ahead of the step that reads them.
+        ``batches``: the index lists / tensors exactly as the following calls will pass them; ``host_indexes``: the same
+        values as host arrays, when the caller has them (saves one device-to-host copy of the list).  A pure hint: a call
+        whose ``indexes`` are not the announced ones drops the remaining announcements.  No-op for device-resident data."""
+        table = self._host_table()
+        if table is None or not torch.cuda.is_available() or not hasattr(self.engine, "row_feeder"):
+            return
+        batches = list(batches)
+        if not batches:
+            return
+        if host_indexes is None:
+            if any(isinstance(b, torch.Tensor) and b.device.type != "cpu" for b in batches):
+                flat = torch.cat([torch.as_tensor(b).reshape(-1).to(torch.int64) for b in batches]).cpu()   # one copy for all
+                host_indexes = list(torch.split(flat, [len(b) for b in batches]))
+            else:
+                host_indexes = batches
+        st = self._feed_state()
+        self._drop_feed()                          # "these are the next calls": whatever was announced before is void
+        shards = []
+        for key, h in zip(batches, host_indexes):
+            h = h if isinstance(h, torch.Tensor) else torch.from_numpy(numpy.ascontiguousarray(numpy.asarray(h), dtype=numpy.int64))
+            h = h.to(torch.int64).reshape(-1)
+            if len(h) and (int(h.min()) < 0 or int(h.max()) >= len(table)):
+                raise IndexError("minibatch index outside the table's %d rows" % len(table))
+            lo, hi = self._shard(len(h))
+            shards.append((key, h[lo:hi].contiguous(), len(h), lo, hi))
+        need = max(hi - lo for _, _, _, lo, hi in shards)
+        fd = st["feeder"]
+        if need > 0 and (fd is None or fd.max_rows < need or fd.host is not table.host):     # (set_value replaces .host)
+            if fd is not None:
+                fd.close()
+            fd = st["feeder"] = self.engine.row_feeder(table.host, table.cols, need)
+        for key, h, n_global, lo, hi in shards:
+            ticket = fd.submit(h) if hi > lo else None
+            st["queue"].append((key, ticket, n_global, lo, hi))
 
     def prefetch(self, indexes):
-        """Tell the step function which minibatch comes NEXT (the trainers know the epoch's order): with a host-resident
-        table its rows start moving now, on a side stream, beside the step that was just enqueued.  A no-op for
-        device-resident data."""
-        table = self._host_table()
-        if table is None or not torch.cuda.is_available():
+        """``announce([indexes])``: the next minibatch only."""
+        self.announce([indexes])
+
+    def _drop_feed(self):
+        st = self._staging
+        if st is None:
             return
-        st = self._staging_state()
-        slot = 1 - st["slot"]
-        # The side stream waits for everything enqueued BEFORE the current step -- the index tensors of the epoch and
-        # the step that last read this buffer (two steps ago) -- but not for the current step itself.
-        if st["before_step"] is not None:
-            st["side"].wait_event(st["before_step"])
-        else:
-            st["side"].wait_stream(torch.cuda.current_stream(self.engine.device))
-        st["next"] = (indexes, slot) + self._stage_rows(table, indexes, slot, st["side"])
+        if st["held"] is not None:
+            st["feeder"].release(st["held"])
+            st["held"] = None
+        if st["queue"]:
+            st["queue"].clear()
+            if st["feeder"] is not None:
+                st["feeder"].cancel()
 
     def _staged(self, table, indexes):
-        """Device rows of this step's minibatch shard: the prefetched buffer if ``indexes`` is what was announced,
-        else gathered now."""
-        st = self._staging_state()
-        cur = torch.cuda.current_stream(self.engine.device)
-        ev0 = torch.cuda.Event()
-        ev0.record(cur)                      # "before this step": what a prefetch issued after it may rely on
-        st["before_step"] = ev0
-        nxt, st["next"] = st["next"], None
-        if nxt is not None and self._same_indexes(nxt[0], indexes):
-            _, slot, buf, ev, n_global, lo, hi = nxt
-            cur.wait_event(ev)
-        else:
-            if nxt is not None:
-                cur.wait_event(nxt[3])       # an abandoned prefetch still owns its buffer until it has finished
-            slot = 1 - st["slot"]
-            buf, ev, n_global, lo, hi = self._stage_rows(table, indexes, slot, cur)
-        st["slot"] = slot
-        return buf, slot, n_global, lo, hi
+        """Device rows of this step's minibatch shard: the fed buffer if ``indexes`` is what was announced next, else
+        gathered now by the PCIe kernel."""
+        st = self._feed_state()
+        eng = self.engine
+        if st["held"] is not None:                 # a step that raised before handing its rows back
+            self._fed()
+        if st["queue"]:
+            key, ticket, n_global, lo, hi = st["queue"][0]
+            if self._same_indexes(key, indexes):
+                st["queue"].popleft()
+                if ticket is None:
+                    return eng.alloc_matrix(0, table.cols, table.host.stride(0)), n_global, lo, hi
+                buf = st["feeder"].acquire(ticket, hi - lo)
+                st["held"] = ticket
+                return buf, n_global, lo, hi
+            self._drop_feed()                      # not what was announced: the remaining announcements are void
+        n_global = len(table) if indexes is None else len(indexes)
+        lo, hi = self._shard(n_global)
+        buf = st["now"]
+        if buf is None or buf.shape[0] != hi - lo:
+            buf = st["now"] = eng.alloc_matrix(hi - lo, table.cols, table.host.stride(0))
+        if hi > lo:
+            idx = torch.arange(lo, hi, dtype=torch.int64, device=eng.device) if indexes is None else \
+                eng.index_tensor(indexes, len(table))[lo:hi]
+            table.rows(idx, out=buf)               # same stream as the steps: the previous reader of `buf` is ahead of it
+        return buf, n_global, lo, hi
+
+    def _fed(self):
+        """The step that reads the fed rows has been enqueued: their slot may be refilled after it."""
+        st = self._staging
+        if st is not None and st["held"] is not None:
+            st["feeder"].release(st["held"])
+            st["held"] = None
 
     # -- deferred half of an overlapped step: speeds (and cost) from the reduced statistics
     def _complete_pending(self):
@@ -262,9 +300,10 @@ class StepFunction(object):
         distributed = self.group is not None and self.group.world_size > 1
         staged_slot = None
         if table is not None and torch.cuda.is_available():
-            # host-resident table: the shard's rows arrive in a staging buffer (prefetched one step ahead when the
-            # trainer announced them); the step then runs on that buffer with the identity index
-            data, staged_slot, n_global, lo, hi = self._staged(table, indexes)
+            # host-resident table: the shard's rows arrive in a device buffer (fed ahead of the step when the trainer
+            # announced them); the step then runs on that buffer with the identity index
+            data, n_global, lo, hi = self._staged(table, indexes)
+            staged_slot = True
             idx = None
         else:
             data = self._data()
@@ -304,8 +343,10 @@ class StepFunction(object):
                                     **({"next_indexes": next_indexes} if (next_indexes is not None and idx is not None
                                                                           and staged_slot is None) else {}))
             rbm._n_updates += 1
-            if next_indexes is not None and staged_slot is not None:
-                self.prefetch(next_indexes)
+            if staged_slot is not None:
+                self._fed()
+                if next_indexes is not None and not self._staging["queue"]:
+                    self.announce([next_indexes])
             if self.nan_guard:
                 self._check_finite(out)
             return out
@@ -365,8 +406,10 @@ class StepFunction(object):
             cost = None
             # rbm.py:480 (sum over units, mean over rows) / rbm.py:697 (mean over everything)
             cost_scale = 1.0 / (n_global * rbm.n_visible) if rbm.gauss else 1.0 / n_global
-        if next_indexes is not None and staged_slot is not None:
-            self.prefetch(next_indexes)              # host-resident table: the next shard starts moving now
+        if staged_slot is not None:
+            self._fed()
+            if next_indexes is not None and not self._staging["queue"]:
+                self.announce([next_indexes])        # host-resident table: the next shard starts moving now
         if self.overlap:
             work = self.group.all_reduce_sum_async(stats, self.engine)
             if deferred_done:
@@ -668,14 +711,13 @@ class RBM(object):
             _, minibatches = get_minibatches_idx(n_train_data, batch_size, shuffle=True, rng=shuffle_rng)
             dev_idx = self.engine.index_tensor(numpy.concatenate(minibatches))
             # costs are 0-d device scalars: fold them into a running sum every 256 steps, without synchronising
-            costs, start, total = [], 0, 0.0
-            for b_i, batch_indexes in enumerate(minibatches):
-                n = len(batch_indexes)
-                # the next minibatch of the epoch as a hint (gathered inside this step's statistics kernel, or started
-                # over PCIe for a host-resident table)
-                nxt = dev_idx[start + n:start + n + len(minibatches[b_i + 1])] if b_i + 1 < len(minibatches) else None
-                costs.append(train_rbm(dev_idx[start:start + n], momentum, next_indexes=nxt))
-                start += n
+            costs, total = [], 0.0
+            views = list(torch.split(dev_idx, [len(b) for b in minibatches]))
+            train_rbm.announce(views, host_indexes=minibatches)      # the epoch's order (a host-resident table starts feeding)
+            for b_i in range(len(minibatches)):
+                # the next minibatch of the epoch as a hint (gathered inside this step's statistics kernel)
+                nxt = views[b_i + 1] if b_i + 1 < len(minibatches) else None
+                costs.append(train_rbm(views[b_i], momentum, next_indexes=nxt))
                 if len(costs) >= 256:
                     total = total + torch.stack([c.reshape(()) for c in costs]).sum()
                     costs = []

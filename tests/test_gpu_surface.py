@@ -489,3 +489,88 @@ def test_host_table_prefetch_announces_the_next_minibatch(hip_engine):
         outs.append((costs, rbm.W.get_value(), rbm.vbias_speed.get_value()))
     assert outs[0][0] == outs[1][0]
     assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_row_feeder_ring(hip_engine):
+    """mdbn_feeder_*: minibatches submitted ahead come back in order, each slot's device rows equal table[indexes] (pad
+    columns zero), ragged row counts, identity batches, more submissions than slots, a bad index refused at acquire
+    without stalling the ring, cancel, and the ring-exhaustion guard."""
+    import mdbn_amd
+    from mdbn_amd import _lib
+    eng = hip_engine
+    rs = np.random.RandomState(4)
+    N, cols = 5000, 300
+    t = mdbn_amd.shared(rs.normal(size=(N, cols)).astype(np.float32), engine=eng, resident="host")
+    fd = eng.row_feeder(t.host, cols, 256, slots=3, threads=4)
+    host = t.host.numpy()
+    batches = [torch.from_numpy(rs.randint(0, N, size=n).astype(np.int64)) for n in (256, 17, 1, 256, 100, 255, 3, 256, 64)]
+    tickets = [fd.submit(b) for b in batches]
+    for b, tk in zip(batches, tickets):
+        got = fd.acquire(tk, len(b))
+        assert got.shape == (len(b), cols)
+        full = got._base[:len(b)] if got._base is not None else got
+        want = torch.from_numpy(host[b.numpy()]).to(eng.device)
+        assert torch.equal(full[:, :want.shape[1]], want)           # pad columns: the table's own zeros
+        fd.release(tk)
+    tk = fd.submit(None, 40)                                        # identity: rows 0 .. 39
+    assert torch.equal(fd.acquire(tk, 40), torch.from_numpy(host[:40, :cols]).to(eng.device))
+    fd.release(tk)
+    bad = fd.submit(torch.tensor([1, N, 2], dtype=torch.int64))
+    good = fd.submit(batches[1])
+    with pytest.raises(_lib.MdbnError, match="out of range"):
+        fd.acquire(bad, 3)
+    assert torch.equal(fd.acquire(good, 17), torch.from_numpy(host[batches[1].numpy()][:, :cols]).to(eng.device))
+    fd.release(good)
+    # cancel: nothing submitted before it can be acquired afterwards; the ring keeps working
+    old = [fd.submit(b) for b in batches[:5]]
+    fd.cancel()
+    with pytest.raises(_lib.MdbnError, match="not pending"):
+        fd.acquire(old[0], 256)
+    tk = fd.submit(batches[4])
+    assert torch.equal(fd.acquire(tk, 100), torch.from_numpy(host[batches[4].numpy()][:, :cols]).to(eng.device))
+    # all slots held: a fourth acquire must fail instead of waiting for ever
+    more = [fd.submit(b) for b in batches[:3]]
+    fd.acquire(more[0], 256), fd.acquire(more[1], 17)
+    with pytest.raises(_lib.MdbnError, match="slots are held"):
+        fd.acquire(more[2], 1)
+    for x in (tk, more[0], more[1]):
+        fd.release(x)
+    assert torch.equal(fd.acquire(more[2], 1), torch.from_numpy(host[batches[2].numpy()][:, :cols]).to(eng.device))
+    fd.release(more[2])
+    eng.synchronize()
+    fd.close()
+
+
+def test_announced_epoch_feeds_a_host_table(hip_engine):
+    """StepFunction.announce: a whole epoch announced up front (as the trainers do) is fed three slots deep; a call that
+    departs from the announced order drops the rest and gathers on the spot; a second announce replaces the first -- the
+    steps always see table[indexes] (bitwise equal to the device-resident run)."""
+    import mdbn_amd
+    V, H, B, N = 512, 128, 128, 4096
+    rs = np.random.RandomState(9)
+    x = rs.normal(size=(N, V)).astype(np.float32)
+    r2 = np.random.RandomState(1)
+    epoch = [r2.permutation(N)[:n] for n in (B, B, B, 77, B, B, B, B, 5, B)]
+    outs = []
+    for resident in ("device", "host"):
+        rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123),
+                            theano_rng=mdbn_amd.RandomStreams(4), engine=hip_engine)
+        _, up = rbm.get_cost_updates(lr=0.002, k=1, lambda_2=0.1, batch_size=B)
+        fn = mdbn_amd.function(up, mdbn_amd.shared(x, engine=hip_engine, resident=resident), data_parallel=None)
+        dev = [hip_engine.index_tensor(b) for b in epoch]
+        costs = []
+        fn.announce(dev, host_indexes=epoch)                        # device views + the host values
+        for t in range(4):
+            costs.append(float(fn(indexes=dev[t], momentum=0.2)))
+        costs.append(float(fn(indexes=dev[7], momentum=0.2)))       # NOT the announced one (4): the rest is dropped
+        costs.append(float(fn(indexes=dev[5], momentum=0.2)))       # unannounced
+        fn.announce(epoch[6:])                                      # host lists only
+        fn.announce(dev[4:])                                        # replaces it; device tensors only (one D2H copy)
+        for t in range(4, len(epoch)):
+            costs.append(float(fn(indexes=dev[t], momentum=0.2, next_indexes=dev[t + 1] if t + 1 < len(epoch) else None)))
+        if resident == "host":
+            st = fn._staging
+            assert st["feeder"] is not None and not st["queue"] and st["held"] is None
+        outs.append((costs, rbm.W.get_value(), rbm.vbias_speed.get_value()))
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])

@@ -234,3 +234,29 @@ def test_host_resident_table_on_the_checker_engine(tmp_path, oracle_engine):
     for a, b in zip(nets[0][1], nets[1][1]):
         np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(nets[0][2], nets[1][2])
+
+
+def test_host_row_gather_threads(built_lib):
+    """mdbn_host_gather_rows: the CPU half of the row feeder (worker threads, row-sized copies) -- out[r] = table[idx[r]]
+    for ragged row counts and thread counts, identity gather, pad columns untouched, an index outside the table refused."""
+    import ctypes as C
+    from mdbn_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(0)
+    N, cols, ld, ld_out = 1000, 37, 40, 48
+    table = rs.normal(size=(N, ld)).astype(np.float32)
+    for n, threads in ((1, 1), (7, 3), (513, 8), (64, 64), (0, 4)):
+        idx = rs.randint(0, N, size=n).astype(np.int64)
+        out = np.full((max(n, 1), ld_out), 7.0, np.float32)
+        rc = lib.mdbn_host_gather_rows(C.c_void_p(table.ctypes.data), N, cols, ld, C.c_void_p(idx.ctypes.data), n,
+                                       C.c_void_p(out.ctypes.data), ld_out, threads)
+        assert rc == 0, _lib.last_error()
+        assert np.array_equal(out[:n, :cols], table[idx, :cols])
+        assert (out[:, cols:] == 7.0).all() and (out[n:] == 7.0).all()
+    out = np.zeros((5, ld_out), np.float32)
+    assert lib.mdbn_host_gather_rows(C.c_void_p(table.ctypes.data), N, cols, ld, None, 5, C.c_void_p(out.ctypes.data), ld_out, 2) == 0
+    assert np.array_equal(out[:, :cols], table[:5, :cols])
+    bad = np.array([3, N, 5], np.int64)
+    assert lib.mdbn_host_gather_rows(C.c_void_p(table.ctypes.data), N, cols, ld, C.c_void_p(bad.ctypes.data), 3,
+                                     C.c_void_p(out.ctypes.data), ld_out, 2) == -1
+    assert "out of range" in _lib.last_error()
