@@ -55,6 +55,8 @@ def parse_args():
                     help="N > 1: also sweep with the all-reduce issued through the C-ABI communicator (mdbn_allreduce_stats); off "
                          "by default: it is the same RCCL collective, and a second communicator that failed to build on one "
                          "rank would hang the run that matters")
+    ap.add_argument("--no-cta-sweep", action="store_true",
+                    help="N > 1 on RCCL: skip the second sweep stage (communicators capped at 8 / 16 / 32 channels)")
     return ap.parse_args()
 
 
@@ -78,6 +80,8 @@ def launch_ranks(args):
         cmd.append("--no-sweep")
     if args.sweep_capi:
         cmd.append("--sweep-capi")
+    if args.no_cta_sweep:
+        cmd.append("--no-cta-sweep")
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for line in proc.stdout:
         sys.stdout.write(line)
@@ -156,6 +160,36 @@ def capi_collective_alive(group, eng, td, deadline_s=20.0):
     flag = torch.tensor([ok], dtype=torch.int32, device=eng.device)
     td.all_reduce(flag, op=td.ReduceOp.MIN)              # through torch's own communicator
     return bool(int(flag.item()))
+
+
+def capped_process_group(td, eng, max_ctas, world, deadline_s=30.0):
+    """A second RCCL communicator over all ranks whose kernels use at most `max_ctas` workgroups (ncclConfig_t.maxCTAs
+    through torch's ProcessGroupNCCL.Options): one channel = one workgroup = one CU taken from the step, so this is the other
+    half of the comm_cus trade.  Proven alive with one small all-reduce polled against a deadline; every rank takes the same
+    decision (None = not usable)."""
+    import torch
+    ok, pg = 1, None
+    try:
+        opts = td.ProcessGroupNCCL.Options()
+        opts.config.max_ctas = int(max_ctas)
+        pg = td.new_group(backend="nccl", pg_options=opts)
+        buf = torch.ones(1024, dtype=torch.float32, device=eng.device)
+        work = td.all_reduce(buf, op=td.ReduceOp.SUM, group=pg, async_op=True)
+        t0 = time.perf_counter()
+        while not work.is_completed():
+            if time.perf_counter() - t0 > deadline_s:
+                ok = 0
+                break
+            time.sleep(0.01)
+        if ok:
+            work.wait()
+            torch.cuda.synchronize(eng.device)
+            ok = int(abs(float(buf[0]) - world) < 0.5)
+    except Exception:
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=eng.device)
+    td.all_reduce(flag, op=td.ReduceOp.MIN)              # through the default communicator
+    return pg if int(flag.item()) else None
 
 
 def _blas_threads():
@@ -348,6 +382,7 @@ def main():
     # here: short windows at every setting, all reported in `distributed.sweep`; the fastest is then installed and timed
     # like the single-GPU run (it is `value`).  Every rank sees the same all-reduced times, so all pick the same setting.
     sweep = None
+    groups = {}
     if world > 1 and not args.no_sweep and getattr(step_fn, "overlap", False):
         sweep = []
         # (overlap, comm_cus, C-ABI collective, deferred update inside the statistics GEMM [comm_cus 0 only])
@@ -379,6 +414,37 @@ def main():
                 ms, err = None, repr(exc)[:200]
             sweep.append({"overlap": ov, "comm_cus": cus if ov else 0, "collective": "capi" if nat else "torch",
                           "update_inside_statistics_gemm": fu, "ms_per_step": ms, "windows": len(w) if ms else 0, "error": err})
+        # Second stage, RCCL only: communicators capped at a few channel counts (one channel = one workgroup = one CU the
+        # collective takes; it has a whole step to finish 16.8 MB, so it may not need RCCL's default).  Each cap is timed
+        # with the GEMMs as they are (comm_cus 0, update inside the statistics GEMM) and balanced on the other CUs.
+        default_pg, groups = step_fn.group.pg, {None: step_fn.group.pg}
+        if backend_name == "nccl" and not args.no_cta_sweep:
+            for ctas in (8, 16, 32):
+                pg = capped_process_group(td, eng, ctas, world)
+                if pg is None:
+                    sweep.append({"rccl_max_ctas": ctas, "error": "a communicator with this cap could not be built or did not "
+                                                                   "complete a small all-reduce within 30 s on every rank"})
+                    continue
+                groups[ctas] = pg
+                for cus, fu in ((0, True), (ctas, False)):
+                    step_fn.flush()
+                    torch.cuda.synchronize(dev)
+                    step_fn.group.pg, step_fn.group.native = pg, False
+                    step_fn.overlap, step_fn.comm_cus, step_fn.fuse_deferred = True, cus, fu
+                    try:
+                        run(max(5, args.warmup // 2), nxt0)
+                        w, _, nxt0 = measure(nxt0, min_total=0.15)
+                        step_fn.flush()
+                        ms = 1e3 * float(np.median(w)) / args.steps
+                        err = None
+                    except Exception as exc:
+                        ms, err = None, repr(exc)[:200]
+                    sweep.append({"overlap": True, "comm_cus": cus, "collective": "torch", "rccl_max_ctas": ctas,
+                                  "update_inside_statistics_gemm": fu, "ms_per_step": ms, "windows": len(w) if ms else 0,
+                                  "error": err})
+            step_fn.flush()
+            torch.cuda.synchronize(dev)
+            step_fn.group.pg = default_pg
         ok = [r for r in sweep if r.get("ms_per_step")]
         step_fn.flush()
         if ok:
@@ -386,6 +452,7 @@ def main():
             step_fn.overlap, step_fn.comm_cus = best["overlap"], best["comm_cus"]
             step_fn.fuse_deferred = best["update_inside_statistics_gemm"]
             step_fn.group.native = best["collective"] == "capi"
+            step_fn.group.pg = groups[best.get("rccl_max_ctas")]
         else:                                             # nothing could be timed: the defaults, and the errors in the line
             step_fn.overlap, step_fn.comm_cus, step_fn.fuse_deferred, step_fn.group.native = True, 0, True, False
         run(args.warmup, nxt0)
@@ -414,6 +481,21 @@ def main():
         e1.record()
         torch.cuda.synchronize(dev)
         allreduce_us = 1e3 * e0.elapsed_time(e1) / 20
+        # ... and through each channel-capped communicator of the sweep's second stage
+        allreduce_by_cap = {}
+        for ctas, pg in sorted((k, v) for k, v in groups.items() if k is not None):
+            try:
+                for _ in range(3):
+                    td.all_reduce(buf, group=pg)
+                barrier()
+                e0.record()
+                for _ in range(20):
+                    td.all_reduce(buf, group=pg)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                allreduce_by_cap[str(ctas)] = 1e3 * e0.elapsed_time(e1) / 20
+            except Exception as exc:
+                allreduce_by_cap[str(ctas)] = repr(exc)[:120]
 
     # per-kernel durations: HIP events around every GEMM launch on its stream, over K more steps
     # (the library keeps at most 8192 event pairs: time a bounded number of steps and count THOSE)
@@ -566,11 +648,13 @@ def main():
         "free_energy_max_elementwise_rel_err": fe_rel_elem,
         "distributed": {"ranks": world, "backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
                         "per_rank_ms_per_step": rank_ms, "allreduce_alone_us": allreduce_us,
+                        "allreduce_alone_us_by_rccl_max_ctas": (allreduce_by_cap if world > 1 else None),
                         "allreduce_bytes": 4 * (V * H + H + V + 4) if world > 1 else 0,
                         "overlap": bool(getattr(step_fn, "overlap", False)),
                         "comm_cus": int(getattr(step_fn, "comm_cus", 0)),
                         "update_inside_statistics_gemm": bool(getattr(step_fn, "fuse_deferred", False)) and not getattr(step_fn, "comm_cus", 0),
                         "collective": step_fn.group.collective if getattr(step_fn, "group", None) is not None else None,
+                        "rccl_max_ctas": (best.get("rccl_max_ctas") if (sweep and ok) else None),
                         "sweep": sweep, "rccl": rccl_info},
         # achieved = FLOPs ISSUED on the matrix pipe the GEMM kernels execute on (six / three bf16 products per
         # algorithmic f32 product), summed over the step's GEMM launches, / their summed HIP-event durations;

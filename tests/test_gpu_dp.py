@@ -165,3 +165,36 @@ def test_split_update_phases_equal_fused(hip_engine):
     assert float(c0) == float(c1)
     with pytest.raises(Exception):       # lambda_1 != 0 cannot be split
         e.apply_update(W, Ws, None, hb, hbs, vb, vbs, stats, 0.05, 0.01, 0.1, 0.0, 0.6, 20.0, 17.0, 0.5, phase=1)
+
+
+def capped_worker(rank, world, port, outdir):
+    """One-rank RCCL job (the box has one GPU): a channel-capped communicator as bench.py's second sweep stage builds it,
+    installed in a data-parallel step function."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as td
+    import mdbn_amd
+    import bench
+    torch.cuda.set_device(0)
+    td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
+    pg = bench.capped_process_group(td, eng, 8, world)
+    assert pg is not None, "a one-rank communicator with max_ctas = 8 must come up"
+    buf = torch.full((4096 * 1024 + 5124,), 2.0, device=eng.device)
+    work = td.all_reduce(buf, group=pg, async_op=True)
+    work.wait()
+    torch.cuda.synchronize()
+    ok = bool((buf == 2.0 * world).all())
+    td.destroy_process_group()
+    np.save(os.path.join(outdir, "ok.npy"), np.array([ok]))
+
+
+def test_channel_capped_rccl_communicator(built_lib):
+    """bench.py's second sweep stage (N > 1 on RCCL): ProcessGroupNCCL.Options().config.max_ctas -> a second communicator,
+    proven with a deadline-guarded all-reduce.  One rank here (RCCL wants one GPU per rank)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(capped_worker, args=(1, free_port(), d), nprocs=1, join=True)
+        assert bool(np.load(os.path.join(d, "ok.npy"))[0])
