@@ -387,8 +387,8 @@ def main():
         sweep = []
         # (overlap, comm_cus, C-ABI collective, deferred update inside the statistics GEMM [comm_cus 0 only])
         settings = [(ov, cus, nat, fu) for nat in ((False, True) if (args.sweep_capi or os.environ.get("MDBN_BENCH_SWEEP_CAPI") == "1") else (False,))
-                    for ov, cus, fu in ((True, 0, True), (True, 0, False), (True, 8, False), (True, 16, False), (True, 32, False),
-                                        (True, 64, False), (False, 0, False))]
+                    for ov, cus, fu in ((True, 0, 1), (True, 0, 0), (True, 8, 0), (True, 16, 0), (True, 32, 0), (True, 32, 2),
+                                        (True, 64, 0), (False, 0, 0))]
         nxt0 = args.warmup
         capi_ok = None
         for ov, cus, nat, fu in settings:
@@ -426,7 +426,7 @@ def main():
                                                                    "complete a small all-reduce within 30 s on every rank"})
                     continue
                 groups[ctas] = pg
-                for cus, fu in ((0, True), (ctas, False)):
+                for cus, fu in ((0, 1), (ctas, 0)):
                     step_fn.flush()
                     torch.cuda.synchronize(dev)
                     step_fn.group.pg, step_fn.group.native = pg, False
@@ -454,7 +454,7 @@ def main():
             step_fn.group.native = best["collective"] == "capi"
             step_fn.group.pg = groups[best.get("rccl_max_ctas")]
         else:                                             # nothing could be timed: the defaults, and the errors in the line
-            step_fn.overlap, step_fn.comm_cus, step_fn.fuse_deferred, step_fn.group.native = True, 0, True, False
+            step_fn.overlap, step_fn.comm_cus, step_fn.fuse_deferred, step_fn.group.native = True, 0, 1, False
         run(args.warmup, nxt0)
     wins, cost, nxt = measure(args.warmup)
     elapsed = float(np.median(wins))
@@ -652,7 +652,7 @@ def main():
                         "allreduce_bytes": 4 * (V * H + H + V + 4) if world > 1 else 0,
                         "overlap": bool(getattr(step_fn, "overlap", False)),
                         "comm_cus": int(getattr(step_fn, "comm_cus", 0)),
-                        "update_inside_statistics_gemm": bool(getattr(step_fn, "fuse_deferred", False)) and not getattr(step_fn, "comm_cus", 0),
+                        "update_inside_statistics_gemm": int(getattr(step_fn, "fuse_deferred", 0)) >= (2 if getattr(step_fn, "comm_cus", 0) else 1),
                         "collective": step_fn.group.collective if getattr(step_fn, "group", None) is not None else None,
                         "rccl_max_ctas": (best.get("rccl_max_ctas") if (sweep and ok) else None),
                         "sweep": sweep, "rccl": rccl_info},

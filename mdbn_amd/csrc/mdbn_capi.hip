@@ -820,9 +820,14 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     if (defer) {
         // the previous step's deferred update: inside this GEMM's loader waves (one workgroup per tile, unsplit, >= 20 stages,
         // the split-phase conditions), else as its own launch right here -- bitwise the same either way
-        const bool inside = !bal && sp.splitk == 1 && g_opt_early_w && g_opt_planes_mfma == 16 && !g_opt_bf16_inputs &&
-                            2 * B / 32 >= 20 && defer->phase == 3 && defer->lambda_1 == 0.f &&
-                            (defer->weightcost == 0.f || defer->W0 != nullptr) && defer->stats != a->stats;
+        const bool splitphase = g_opt_early_w && g_opt_planes_mfma == 16 && !g_opt_bf16_inputs && defer->phase == 3 &&
+                                defer->lambda_1 == 0.f && (defer->weightcost == 0.f || defer->W0 != nullptr) &&
+                                defer->stats != a->stats;
+        // balanced launch: a flat share of the arrays per workgroup, 16 items of 512 pieces at most, >= 20 stages each
+        const int64_t flat = bal ? (((V * ldh / 4 + bal - 1) / bal + 511) / 512) * 512 : 0;
+        const bool inside = splitphase && (bal ? (flat <= 16 * 512 && (int64_t)g.tiles_m * g.tiles_n * (2 * B / 32) / bal >= 20)
+                                               : (sp.splitk == 1 && 2 * B / 32 >= 20));
+        g.upd.flat_per_wg = flat;
         if (inside) {
             g.upd.W = defer->W; g.upd.Ws = defer->W_speed; g.upd.W0 = defer->W0; g.upd.ld = ldh; g.upd.rows = (int)V;
             g.upd.lr = defer->lr; g.upd.l1 = 0.f; g.upd.l2 = defer->lambda_2; g.upd.wc = defer->weightcost;
@@ -834,7 +839,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
             g.db.s_h = ps_h; g.db.s_v = ps_h + ldh; g.db.cost_sum = ps_h + ldh + ldv; g.db.H = H; g.db.V = V;
             g.db.lr = defer->lr; g.db.mu = defer->momentum; g.db.inv_rows = 1.0f / defer->n_rows;
             g.db.cost_scale = defer->cost_scale; g.db.cost_out = defer->cost_out;
-            set_gather_ahead();
+            if (!bal) set_gather_ahead();
         } else {
             HIP_OK(launch_update(*defer, s, nullptr, 1, 0, reinterpret_cast<unsigned short*>(defer->W_planes)));
         }

@@ -51,6 +51,7 @@ struct UpdEpi {
     unsigned short* Wp;            // nullable: bf16 planes [3][rows][ld] of the NEW W, kept in step with it
     int64_t wp_stride;
     const float* Sprev;            // early == 2: S block of the (all-reduced) statistics of the PREVIOUS step
+    int64_t flat_per_wg;           // early == 2 in a BALANCED launch: 16-byte pieces of the flat [rows * ld] arrays per workgroup
     int early;                     // plane statistics GEMM: the PARAMETER half (W, W planes: it needs only the old W and the old
                                    // speed, rbm.py:364-365) is applied by the loader waves DURING the main loop; the epilogue
                                    // then only forms the new speed from the finished tile (needs l1 == 0 and wc == 0 or W0).

@@ -82,6 +82,25 @@ template <int MS> __device__ __forceinline__ int pl_col_swz(int k)
 struct EarlySpeed { float4 sp[16], w0[16]; };      // a loader lane's share of the tile's old speed (+ frozen W0), rows 8 j + lt / 32
 // BN = 128 | 64: columns of the output tile.  BN = 64 (ROW B operand only: propdown) halves the B image -- four 16-row
 // instructions per plane instead of eight -- so that an output with 256 tiles of 128 x 64 needs no split-K.
+// bias / cost half of the previous step's deferred update (data-parallel order), by the four MFMA waves of every workgroup
+// ahead of their main loop: the same arithmetic as update_kernel<true, true, true>'s leading blocks
+__device__ __forceinline__ void deferred_bias_update(const DeferredBias& d, int wave, int lane)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + wave * 64 + lane; i < d.H + d.V; i += (int64_t)gridDim.x * 256) {
+        if (i < d.H) {
+            const float sn = upd_speed(upd_scale(d.s_h[i], d.inv_rows), d.hbs[i], d.mu);
+            d.hbs[i] = sn;
+            d.hb[i] = upd_param(d.hb[i], 1.0f, sn, d.lr);
+        } else {
+            const int64_t j = i - d.H;
+            const float sn = upd_speed(upd_scale(d.s_v[j], d.inv_rows), d.vbs[j], d.mu);
+            d.vbs[j] = sn;
+            d.vb[j] = upd_param(d.vb[j], 1.0f, sn, d.lr);
+        }
+    }
+    if (blockIdx.x == 0 && wave == 0 && lane == 0 && d.cost_out) d.cost_out[0] = d.cost_sum[0] * d.cost_scale;
+}
+
 template <int LA, int LB, int AP, int MS, bool EARLYW = false, int BN = 128>
 __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, int w, int lane, int m0, int n0, int kbeg, int nt,
                                           EarlySpeed* es = nullptr)
@@ -573,23 +592,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
         const int r = lane & 31, h = lane >> 5;
         const int wm = (wave >> 1) * 64, wn = (wave & 1) * (BN / 2);
         if constexpr (FUSED == 0 && LA == LAY_MN && LB == LAY_MN) {
-            if (g.db.on) {              // data-parallel: bias / cost half of the previous step's deferred update (same
-                                        // arithmetic as update_kernel<true, true, true>'s leading blocks)
-                const DeferredBias& d = g.db;
-                for (int64_t i = (int64_t)blockIdx.x * 256 + wave * 64 + lane; i < d.H + d.V; i += (int64_t)gridDim.x * 256) {
-                    if (i < d.H) {
-                        const float sn = upd_speed(upd_scale(d.s_h[i], d.inv_rows), d.hbs[i], d.mu);
-                        d.hbs[i] = sn;
-                        d.hb[i] = upd_param(d.hb[i], 1.0f, sn, d.lr);
-                    } else {
-                        const int64_t j = i - d.H;
-                        const float sn = upd_speed(upd_scale(d.s_v[j], d.inv_rows), d.vbs[j], d.mu);
-                        d.vbs[j] = sn;
-                        d.vb[j] = upd_param(d.vb[j], 1.0f, sn, d.lr);
-                    }
-                }
-                if (blockIdx.x == 0 && wave == 0 && lane == 0 && d.cost_out) d.cost_out[0] = d.cost_sum[0] * d.cost_scale;
-            }
+            if (g.db.on) deferred_bias_update(g.db, wave, lane);     // data-parallel: bias / cost half of the previous step's update
         }
         if constexpr ((FUSED == 2 || FUSED == 0) && LA == LAY_MN && LB == LAY_MN) {
             if (g.fin_enabled) {        // statistics GEMM: finalize units while the first stages are in flight
@@ -1010,12 +1013,74 @@ __device__ __forceinline__ void pl_loader_bal(const PlaneGemmArgs& g, char* smem
     __builtin_amdgcn_s_barrier();                    // stage 0 landed
     if (nt > 1) { PL_ISSUE(1); }
     if (nt > 2) { PL_ISSUE(2); }
-    for (int it = 0; it < nt; ++it) {
-        if (it + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                // every read of stage `it` is done: its slot is free
+    int it = 0;
+#define LD_SYNC()                                                                             \
+    do {                                                                                      \
+        if (it + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");          \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 \
+        __builtin_amdgcn_s_barrier();                /* every read of stage `it` is done: its slot is free */ \
+    } while (0)
+    if constexpr (LA == LAY_MN && LB == LAY_MN && AP == 3) {
+        if (g.upd.early == 2) {
+            // Data-parallel step on balanced launches: the WHOLE deferred update of the previous step (phase 3), as in
+            // pl_loader's early == 2 branch -- same loads one stage ahead behind counted waits, same arithmetic -- but over a
+            // FLAT share of the [rows * ld] arrays instead of the workgroup's tile (a balanced workgroup has no tile of its
+            // own; nothing of the update depends on this GEMM): 16 items of two 16-byte pieces per thread, pieces
+            // [wg * flat_per_wg, (wg + 1) * flat_per_wg) (host: flat_per_wg <= 16 * 512, every workgroup has >= 20 stages).
+            // Loads are unconditional at clamped, valid addresses; only the stores are predicated.
+#define ASM_LOAD4(DST, PTR) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(DST) : "v"(PTR) : "memory")
+#define ASM_WAIT(N) do { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+            const int lt = w * 64 + lane;
+            const float decay = upd_decay(g.upd.lr, g.upd.l2);
+            const bool has_wc = g.upd.wc != 0.0f;
+            const float* w0base = has_wc ? g.upd.W0 : g.upd.Ws;
+            const int64_t total4 = (int64_t)g.upd.rows * g.upd.ld / 4;
+            const int64_t base4 = (int64_t)wg * g.upd.flat_per_wg + lt;
+            const int64_t end4 = total4 < (int64_t)(wg + 1) * g.upd.flat_per_wg ? total4 : (int64_t)(wg + 1) * g.upd.flat_per_wg;
+            pf32x4 dw[16][2], ds[16][2], dt[16][2], d0[16][2];
+#define BAL_ITEM_LOAD(I)                                                                      \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                        \
+        const int64_t f_ = base4 + (2 * (I) + h_) * 256;                                      \
+        const int64_t o_ = 4 * (f_ < total4 ? f_ : total4 - 1);                               \
+        ASM_LOAD4(dw[I][h_], g.upd.W + o_); ASM_LOAD4(ds[I][h_], g.upd.Ws + o_);              \
+        ASM_LOAD4(dt[I][h_], g.upd.Sprev + o_); ASM_LOAD4(d0[I][h_], w0base + o_);            \
+    }
+            BAL_ITEM_LOAD(0)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                LD_SYNC();
+                if (i + 1 < 16) { BAL_ITEM_LOAD(i + 1) }
+                PL_ISSUE(it + 3);
+                if (i + 1 < 16) ASM_WAIT(PER + 8); else ASM_WAIT(PER);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int64_t f = base4 + (2 * i + h) * 256;
+                    float4 sn, wn;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float w0j = has_wc ? d0[i][h][j] : 0.0f;
+                        const float snj = upd_speed(upd_grad(dt[i][h][j], g.upd.inv_bs, g.upd.wc, w0j), ds[i][h][j], g.upd.mu);
+                        setc(sn, j, snj);
+                        setc(wn, j, upd_param(dw[i][h][j], decay, snj, g.upd.lr));
+                    }
+                    if (f < end4) {
+                        *reinterpret_cast<float4*>(g.upd.Ws + 4 * f) = sn;
+                        *reinterpret_cast<float4*>(g.upd.W + 4 * f) = wn;
+                        if (g.upd.Wp) store_planes4(g.upd.Wp, g.upd.wp_stride, 4 * f, wn);
+                    }
+                }
+                ++it;
+            }
+#undef BAL_ITEM_LOAD
+#undef ASM_LOAD4
+#undef ASM_WAIT
+        }
+    }
+    for (; it < nt; ++it) {
+        LD_SYNC();
         if (it + 3 < nt) { PL_ISSUE(it + 3); }
     }
+#undef LD_SYNC
 #undef PL_ISSUE
 }
 
@@ -1044,6 +1109,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_bal_kernel(Plane
     }
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     if constexpr (LA == LAY_MN && LB == LAY_MN) {
+        if (g.db.on) deferred_bias_update(g.db, wave, lane);     // data-parallel: bias / cost half of the previous step's update
         if (g.fin_enabled) {            // statistics GEMM: finalize units while the first stages are in flight
             const int nu = fin_units(g.fin);
             for (int unit = wave * (int)gridDim.x + (int)blockIdx.x; unit <= nu; unit += 4 * (int)gridDim.x)

@@ -119,11 +119,13 @@ class StepFunction(object):
         self.comm_cus = 0
         # Overlapped data-parallel order with the deferred update of step t-1 INSIDE the statistics GEMM of step t (one
         # launch and one queue packet fewer: 163 -> 146 us per step without a collective on one GPU), at the price of waiting
-        # for the all-reduce of step t-1 before that GEMM instead of after it (~100 us of cover instead of ~150).  Only with
-        # one workgroup per CU (comm_cus == 0: the balanced launches do not carry the update).  MDBN_DP_FUSED_UPDATE=0 or
-        # fn.fuse_deferred = False restores the update launch after the step; bench.py --gpus N measures both.
+        # for the all-reduce of step t-1 before that GEMM instead of after it (~100 us of cover instead of ~150).  The
+        # balanced launches (comm_cus > 0) can carry it too (a flat share of the arrays per workgroup), but gain only 3 us
+        # from it and lose the longer cover (185.0 vs 187.8 us alone, 216 vs 203 beside a 120-us stand-in): only with
+        # MDBN_DP_FUSED_UPDATE=2 / fn.fuse_deferred = 2.  0 restores the update launch after the step everywhere;
+        # bench.py --gpus N measures all of them.
         import os as _os
-        self.fuse_deferred = _os.environ.get("MDBN_DP_FUSED_UPDATE", "1") != "0"
+        self.fuse_deferred = int(_os.environ.get("MDBN_DP_FUSED_UPDATE", "1"))      # 0 | 1 | 2 (2: balanced launches too)
         if self.group is not None and self.group.world_size > 1 and hasattr(self.engine, "set_option"):
             # The collective's kernels run beside the next step's GEMMs and take whole CUs (RCCL's gfx950 all-reduce
             # kernel: 248-256 VGPRs per wave, 37.6 KB LDS -- nothing of ours fits next to it), and a one-workgroup-per-
@@ -361,7 +363,7 @@ class StepFunction(object):
         deferred_done = False
         if hi > lo:
             extra = {"comm_cus": self.comm_cus} if self.comm_cus else {}
-            if self.overlap and self._pending is not None and self.fuse_deferred and not self.comm_cus and \
+            if self.overlap and self._pending is not None and int(self.fuse_deferred) >= (2 if self.comm_cus else 1) and \
                     getattr(eng, "cd_forward", None) is not None:
                 # Overlapped order with the update INSIDE the statistics GEMM: the forward half of step t (everything that
                 # reads theta(t)), then wait for the all-reduce of step t-1, then the statistics half, whose kernel applies

@@ -11,7 +11,8 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-
                       cwd=os.path.dirname(src), stderr=subprocess.DEVNULL)
 text = open(out).read()
 kerns = ["_ZN4mdbn18gemm_planes_kernelILi1ELi1ELi3ELi2ELi16ELi128EEEvNS_13PlaneGemmArgsE",      # statistics + fused update
-         "_ZN4mdbn18gemm_planes_kernelILi1ELi1ELi3ELi0ELi16ELi128EEEvNS_13PlaneGemmArgsE"]      # statistics, data-parallel (deferred update)
+         "_ZN4mdbn18gemm_planes_kernelILi1ELi1ELi3ELi0ELi16ELi128EEEvNS_13PlaneGemmArgsE",      # statistics, data-parallel (deferred update)
+         "_ZN4mdbn22gemm_planes_bal_kernelILi1ELi1ELi3ELi1EEEvNS_13PlaneGemmArgsE"]             # the same on balanced launches
 body = ""
 for kern in kerns:
     part = text[text.index("\n" + kern + ":"):]
@@ -42,7 +43,10 @@ for i, line in enumerate(body.split("\n")):
     if inasm and parts[0] == "s_waitcnt":
         # an item's loads survive the ring wait of the next stage (vmcnt(12)) and are covered by the next item wait; the
         # last item of a phase is covered by a vmcnt(12) item wait: count ring waits as 1, item waits as 2, retire at 3
-        n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
+        m = re.search(r"vmcnt\((\d+)\)", t)
+        if m is None:                       # an lgkmcnt-only wait (LDS reads of the MFMA waves): no VMEM retires
+            continue
+        n = int(m.group(1))
         for p in pend:
             p[2] += 1 if n == 12 else 2
         pend = [p for p in pend if p[2] < 3]

@@ -98,15 +98,15 @@ def test_two_ranks_equal_oracle_on_global_batch(built_lib, shape):
         check("DP 2 ranks %s: |u - p| of a flipped draw" % shape, float(r[k]["flip_gap"]), 1e-6, "tie")
 
 
-def worker(rank, world, port, outdir, overlap, shape, comm_cus=0):
+def worker(rank, world, port, outdir, overlap, shape, comm_cus=0, fused=1):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
-                      MDBN_COMM_CUS=str(comm_cus))
+                      MDBN_COMM_CUS=str(comm_cus), MDBN_DP_FUSED_UPDATE=str(fused))
     from mdbn_amd import dist
     dist.init_from_env(backend="gloo")
     out = run_steps(True, overlap, shape)
-    np.savez(os.path.join(outdir, "rank%d_%d.npz" % (rank, overlap + (2 if comm_cus else 0))), **out)
+    np.savez(os.path.join(outdir, "rank%d_%d.npz" % (rank, overlap + (2 if comm_cus else 0) + (0 if fused else 4))), **out)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -120,9 +120,14 @@ def test_two_ranks_equal_one_process_on_device(built_lib, shape):
         res = {}
         # 0: synchronous; 1: overlapped; 3: overlapped with 32 CUs left to the collective (the default of a real
         # data-parallel job: the plane GEMMs then run balanced on 224 workgroups, another summation grouping)
-        for mode, (overlap, cus) in {0: (0, 0), 1: (1, 0), 3: (1, 32)}.items():
-            mp.spawn(worker, args=(2, free_port(), d, overlap, shape, cus), nprocs=2, join=True)
+        # 5 / 7: the overlapped orders with the deferred update as its own launch (MDBN_DP_FUSED_UPDATE=0) instead of inside
+        # the statistics GEMM's loader waves (one workgroup per tile: its tile; balanced: a flat share)
+        for mode, (overlap, cus, fused) in {0: (0, 0, 1), 1: (1, 0, 1), 3: (1, 32, 2), 5: (1, 0, 0), 7: (1, 32, 0)}.items():
+            mp.spawn(worker, args=(2, free_port(), d, overlap, shape, cus, fused), nprocs=2, join=True)
             res[mode] = [dict(np.load(os.path.join(d, "rank%d_%d.npz" % (r, mode)))) for r in range(2)]
+    for k in single:                     # the update inside the statistics GEMM == the update launch, bit for bit
+        assert np.array_equal(res[1][0][k], res[5][0][k]), k
+        assert np.array_equal(res[3][0][k], res[7][0][k]), k
     for overlap in (0, 1, 3):
         r0, r1 = res[overlap]
         for k in single:
