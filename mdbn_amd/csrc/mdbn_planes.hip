@@ -823,7 +823,12 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
         if constexpr (FUSED == 1 && BN == 64) fused_tile_epilogue_4x4<NT>(g.epi, T, m0, n0);     // one pass, loads up front
         else if constexpr (FUSED == 1) fused_tile_epilogue<128, BN, NT>(g.epi, T, m0, n0);
         else if (MS == 16 && g.upd.early == 1) {     // W went early (pl_loader); the loader waves hold speed_old (+ W0)
-            if (wave >= 4) {
+// diagnostic builds (wrong results; scripts/experiments/fixed_cost_probe.py stats): 1 = the new speed is formed but not
+// stored, 2 = no speed epilogue at all -- what the tail of the statistics launch costs
+#ifndef PL_DIAG_STATS
+#define PL_DIAG_STATS 0
+#endif
+            if (wave >= 4 && PL_DIAG_STATS != 2) {
                 const int lt = (wave - 4) * 64 + lane;
                 constexpr int LDT = 128 + 8;
 #pragma unroll
@@ -834,7 +839,8 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         setc(sn, c, upd_speed(upd_grad(comp(st, c), g.upd.inv_bs, g.upd.wc, comp(es.w0[j], c)), comp(es.sp[j], c), g.upd.mu));
-                    *reinterpret_cast<float4*>(g.upd.Ws + (int64_t)(m0 + row) * g.upd.ld + n0 + 4 * c4) = sn;
+                    if (PL_DIAG_STATS == 0 || sn.x == 12345.678f)
+                        *reinterpret_cast<float4*>(g.upd.Ws + (int64_t)(m0 + row) * g.upd.ld + n0 + 4 * c4) = sn;
                 }
             }
         }
