@@ -1564,7 +1564,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
     const bool fuse_upd = upd && !overlap && g_opt_fused_update && p.splitk == 1;
     // ... and in the LDS-tiled kernel even the finalize units run inside the GEMM (its MFMA waves are
     // idle while the first slice is in flight): no finalize launch either
-    const bool fin_in_gemm = fuse_upd && !p.skinny && g_opt_fused_finalize;
+    const bool fin_in_gemm = fuse_upd && g_opt_fused_finalize;
     BiasUpd bu;
     if (fuse_upd) {
         bu.hb = u.hbias; bu.hbs = u.hbias_speed; bu.vb = u.vbias; bu.vbs = u.vbias_speed;
@@ -1572,7 +1572,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         bu.cost_scale = u.cost_scale; bu.cost_out = u.cost_out;
     }
     // the unfused LDS-tiled statistics GEMM (data-parallel step) runs the plain finalize units the same way
-    const bool fin_in_plain_gemm = !fuse_upd && !overlap && !p.skinny && g_opt_fused_finalize;
+    const bool fin_in_plain_gemm = !fuse_upd && !overlap && g_opt_fused_finalize;
     if (!overlap && !fin_in_gemm && !fin_in_plain_gemm)
         HIP_OK(launch_finalize_stats(ws.colPpos, ws.colPneg, ws.colV, row_groups(B), ldh, ldv, ws.cost_partials,
                                      n_cost, s_h, s_v, cost, fuse_upd ? &bu : nullptr, s));

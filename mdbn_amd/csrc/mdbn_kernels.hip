@@ -975,6 +975,16 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmArgs
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
 
+    if constexpr (LA == LAY_MN && LB == LAY_MN) {
+        // statistics GEMM: the bias statistics / cost total / bias update units (finalize_unit: the same functions and order
+        // as finalize_stats_kernel) spread over the waves of all blocks, ahead of the operand stream -- one launch fewer
+        if (g.fin_enabled) {
+            const int nu = fin_units(g.fin);
+            for (int unit = wave * (int)gridDim.x + (int)blockIdx.x; unit <= nu; unit += NW * (int)gridDim.x)
+                finalize_unit(g.fin, unit, lane);
+        }
+    }
+
     // batch = U octets of this wave (octets wave, wave + NW, ...); two register sets
     SkinnyRegs<MI> r0, r1;
 #define SKINNY_LOAD(R, OB)                                                                   \
