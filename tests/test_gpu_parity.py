@@ -3,7 +3,7 @@ seeded inputs, plus size-independent properties at BASELINE's full size.  Tolera
 fp32-device vs float64-oracle: probabilities 2e-6 abs, free energy 1e-4 rel
 (north star), Bernoulli samples exact outside the near-tie mask |u - p| < 1e-6.  Every
 tolerance goes through tests/_margins.check, which records the worst value measured on the
-box next to it (profiles/r03k_tolerance_margins.json)."""
+box next to it (profiles/r03zf_tolerance_margins.json)."""
 import numpy as np
 import pytest
 import torch
