@@ -162,34 +162,43 @@ def capi_collective_alive(group, eng, td, deadline_s=20.0):
     return bool(int(flag.item()))
 
 
-def capped_process_group(td, eng, max_ctas, world, deadline_s=30.0):
+def capped_process_group(td, eng, max_ctas, world, deadline_s=60.0):
     """A second RCCL communicator over all ranks whose kernels use at most `max_ctas` workgroups (ncclConfig_t.maxCTAs
     through torch's ProcessGroupNCCL.Options): one channel = one workgroup = one CU taken from the step, so this is the other
-    half of the comm_cus trade.  Proven alive with one small all-reduce polled against a deadline; every rank takes the same
-    decision (None = not usable)."""
+    half of the comm_cus trade.  Built and proven (one small all-reduce) on a helper thread that the caller abandons after
+    `deadline_s`: a communicator that cannot be built must not hang the run that matters.  Every rank takes the same decision
+    through the default communicator.  Returns (process group or None, whether the helper thread was abandoned)."""
+    import threading
     import torch
-    ok, pg = 1, None
-    try:
-        opts = td.ProcessGroupNCCL.Options()
-        opts.config.max_ctas = int(max_ctas)
-        pg = td.new_group(backend="nccl", pg_options=opts)
-        buf = torch.ones(1024, dtype=torch.float32, device=eng.device)
-        work = td.all_reduce(buf, op=td.ReduceOp.SUM, group=pg, async_op=True)
-        t0 = time.perf_counter()
-        while not work.is_completed():
-            if time.perf_counter() - t0 > deadline_s:
-                ok = 0
-                break
-            time.sleep(0.01)
-        if ok:
+    box = {}
+
+    def make():
+        try:
+            torch.cuda.set_device(eng.device)
+            opts = td.ProcessGroupNCCL.Options()
+            opts.config.max_ctas = int(max_ctas)
+            pg = td.new_group(backend="nccl", pg_options=opts)
+            buf = torch.ones(1024, dtype=torch.float32, device=eng.device)
+            work = td.all_reduce(buf, op=td.ReduceOp.SUM, group=pg, async_op=True)
+            while not work.is_completed():
+                time.sleep(0.01)
             work.wait()
             torch.cuda.synchronize(eng.device)
-            ok = int(abs(float(buf[0]) - world) < 0.5)
-    except Exception:
-        ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32, device=eng.device)
+            box["pg"] = pg if abs(float(buf[0]) - world) < 0.5 else None
+        except Exception:
+            box["pg"] = None
+
+    th = threading.Thread(target=make, daemon=True)
+    th.start()
+    th.join(deadline_s)
+    abandoned = th.is_alive()
+    ok = int(not abandoned and box.get("pg") is not None)
+    flag = torch.tensor([ok, int(abandoned)], dtype=torch.int32, device=eng.device)
     td.all_reduce(flag, op=td.ReduceOp.MIN)              # through the default communicator
-    return pg if int(flag.item()) else None
+    all_ok = bool(int(flag[0].item()))
+    flag2 = torch.tensor([int(abandoned)], dtype=torch.int32, device=eng.device)
+    td.all_reduce(flag2, op=td.ReduceOp.MAX)
+    return (box.get("pg") if all_ok else None), bool(int(flag2.item()))
 
 
 def _blas_threads():
@@ -420,10 +429,12 @@ def main():
         default_pg, groups = step_fn.group.pg, {None: step_fn.group.pg}
         if backend_name == "nccl" and not args.no_cta_sweep:
             for ctas in (8, 16, 32):
-                pg = capped_process_group(td, eng, ctas, world)
+                pg, abandoned = capped_process_group(td, eng, ctas, world)
                 if pg is None:
                     sweep.append({"rccl_max_ctas": ctas, "error": "a communicator with this cap could not be built or did not "
-                                                                   "complete a small all-reduce within 30 s on every rank"})
+                                                                   "complete a small all-reduce within 60 s on every rank"})
+                    if abandoned:                         # a helper thread is still stuck in RCCL: no further communicators
+                        break
                     continue
                 groups[ctas] = pg
                 for cus, fu in ((0, 1), (ctas, 0)):

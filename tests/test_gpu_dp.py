@@ -184,8 +184,8 @@ def capped_worker(rank, world, port, outdir):
     torch.cuda.set_device(0)
     td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
-    pg = bench.capped_process_group(td, eng, 8, world)
-    assert pg is not None, "a one-rank communicator with max_ctas = 8 must come up"
+    pg, abandoned = bench.capped_process_group(td, eng, 8, world)
+    assert pg is not None and not abandoned, "a one-rank communicator with max_ctas = 8 must come up"
     buf = torch.full((4096 * 1024 + 5124,), 2.0, device=eng.device)
     work = td.all_reduce(buf, group=pg, async_op=True)
     work.wait()
