@@ -723,8 +723,6 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
                     e.target = a->data; e.ld_target = ldv; e.target_rows = a->n_data;
                     e.target_idx = a->indexes; e.target_idx64 = a->index_is_64;       // NULL: rows 0..B-1 of the data
                 }
-                // the same rows as bf16 planes (rows 0..B-1 of the X planes), for the epilogue that can read them
-                e.target_planes = pb.Xp; e.target_plane_stride = pb.px;
             }
             CHECK(run_affine_planes(ctx, a->comm_cus, pb.hsp, ldh, B * ldh, 1, 1, Wp, V, H, B, e, last, ws, s, last ? &n_cost : nullptr));
             if (a->trace_v && !a->gauss)

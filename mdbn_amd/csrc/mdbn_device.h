@@ -339,35 +339,8 @@ __device__ __forceinline__ void fused_tile_epilogue(const EpiArgs& e, float* T, 
 // rows through the minibatch index) are issued up front, and every store is 8 or 16 bytes (one per plane and row, one
 // float4 of bias statistics) instead of 2-byte plane stores per element.  Same arithmetic per element as act_quad (same
 // Philox words: one block per column and 4-row group), so samples are bit-identical to the two-launch path.
-// The thread's share of the cost target, requested BEFORE the tile is parked (a loader wave right after its last stage, an
-// MFMA wave right after its last MFMA): from the target's bf16 planes when the step has them (12.6 MB the first forward
-// pass just read, no index), else through the minibatch index from the table itself (two dependent loads, the second a
-// random 16-KB row of a table of any size: ~4 us exposed when it was issued after the barrier).
-struct Epi4x4Target { uint2 pl[4][3]; float4 f[4]; };
 template <int NT = 512>
-__device__ __forceinline__ void epi4x4_request_target(const EpiArgs& e, int m0, int n0, Epi4x4Target& t)
-{
-    const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const int col0 = n0 + 4 * cq, r0 = m0 + 4 * rg;
-    if (!(r0 < e.rows && col0 < (int)e.ld)) return;
-    if (e.target_planes) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t off = (int64_t)(r0 + j < e.rows ? r0 + j : e.rows - 1) * e.ld_target + col0;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) t.pl[j][p] = *reinterpret_cast<const uint2*>(e.target_planes + p * e.target_plane_stride + off);
-        }
-    } else if (e.target) {
-        int64_t srow[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) srow[j] = epi_target_row(e, r0 + j < e.rows ? r0 + j : e.rows - 1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) t.f[j] = *reinterpret_cast<const float4*>(e.target + srow[j] * e.ld_target + col0);
-    }
-}
-
-template <int NT = 512>
-__device__ __forceinline__ void fused_tile_epilogue_4x4(const EpiArgs& e, float* T, int m0, int n0, const Epi4x4Target& tq)
+__device__ __forceinline__ void fused_tile_epilogue_4x4(const EpiArgs& e, float* T, int m0, int n0)
 {
     constexpr int BM = 128, BN = 64, LDT = BN + 8;
     static_assert(NT == 512, "one 4 x 4 block per thread");
@@ -376,26 +349,13 @@ __device__ __forceinline__ void fused_tile_epilogue_4x4(const EpiArgs& e, float*
     float cost = 0.f;
     if (r0 < e.rows && col0 < (int)e.ld) {
         float4 tg[4];
-        const bool want_tg = e.target != nullptr || e.target_planes != nullptr;
-        if (e.target_planes) {
+        const bool want_tg = e.target != nullptr;
+        if (want_tg) {
+            int64_t srow[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v[4];
+            for (int j = 0; j < 4; ++j) srow[j] = epi_target_row(e, r0 + j < e.rows ? r0 + j : e.rows - 1);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const unsigned sh = (c & 1) ? 16u : 0u;
-                    const unsigned w1 = c < 2 ? tq.pl[j][0].x : tq.pl[j][0].y, w2 = c < 2 ? tq.pl[j][1].x : tq.pl[j][1].y,
-                                   w3 = c < 2 ? tq.pl[j][2].x : tq.pl[j][2].y;
-                    const float p1 = __builtin_bit_cast(float, ((w1 >> sh) & 0xffffu) << 16);
-                    const float p2 = __builtin_bit_cast(float, ((w2 >> sh) & 0xffffu) << 16);
-                    const float p3 = __builtin_bit_cast(float, ((w3 >> sh) & 0xffffu) << 16);
-                    v[c] = (p3 + p2) + p1;
-                }
-                tg[j] = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        } else if (e.target) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) tg[j] = tq.f[j];
+            for (int j = 0; j < 4; ++j) tg[j] = *reinterpret_cast<const float4*>(e.target + srow[j] * e.ld_target + col0);
         }
         const float4 b4 = make_float4(col0 < e.cols ? e.bias[col0] : 0.f, col0 + 1 < e.cols ? e.bias[col0 + 1] : 0.f,
                                       col0 + 2 < e.cols ? e.bias[col0 + 2] : 0.f, col0 + 3 < e.cols ? e.bias[col0 + 3] : 0.f);

@@ -28,10 +28,6 @@ struct EpiArgs {
     const void* target_idx;     // nullable: int32 / int64 [rows]
     int target_idx64;
     int64_t target_rows;        // rows of the matrix `target` points into
-    // ... or, where the GATHERED target exists as three bf16 planes (the v0 rows of the step's X planes), read it there:
-    // no index, no random row of the table, t = (p3 + p2) + p1 exactly (fused_tile_epilogue_4x4 only; ld = ld_target)
-    const unsigned short* target_planes;   // nullable
-    int64_t target_plane_stride;
     float* cost_partials;  // nullable: one float per block
     float* colsum;         // nullable: [ceil(rows/4)][ld] partial column sums over each 4-row group
     int colsum_kind;       // 0: sum of stored (scaled) mean ; 1: sum of (target - mean) ; 2: sum of (target - sample)

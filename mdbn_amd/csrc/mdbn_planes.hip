@@ -40,17 +40,6 @@ typedef float pf32x16 __attribute__((ext_vector_type(16)));
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PL_PLANE = 8192, PL_STAGE = 6 * PL_PLANE, PL_NSTAGE = 3, PL_LW = 4;
-// Stage geometry of the LDS ring.  Default: 3 stages of 48 KB, A planes at p * 8 KB, B planes at (3 + p) * 8 KB.
-// DEEP (64-column tile with a one-plane A operand: propdown on narrow tiles): a stage holds only 8 + 3 * 4 = 20 KB and its
-// MFMA work is 0.22 us, so three stages in flight cover 0.7 us of a ~2-us LDS-DMA round trip and the loop runs at the
-// latency, not at the feed or the matrix pipe (0.56 us per stage measured); the same LDS holds SIX compact stages.
-template <int AP, int BN> struct PlGeom {
-    static constexpr bool deep = BN == 64 && AP == 1;
-    static constexpr int NST = deep ? 6 : PL_NSTAGE;
-    static constexpr int BOFF = deep ? PL_PLANE : 3 * PL_PLANE;          // byte offset of B plane 0 in a stage
-    static constexpr int BPL = deep ? 4096 : PL_PLANE;                   // bytes between B planes
-    static constexpr int STG = deep ? PL_PLANE + 3 * 4096 : PL_STAGE;    // bytes per stage
-};
 #ifndef PL_RAMP_SPLIT
 #define PL_RAMP_SPLIT 1      // loader ramp-up: stage 0 alone before the first barrier (pl_loader)
 #endif
@@ -129,8 +118,6 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
     constexpr int QB = BN / 16;                      // 1-KiB instructions per B plane
     constexpr int NQ = 8 * NA + QB * NB, PER = NQ / PL_LW;
     static_assert(NQ % PL_LW == 0, "staging instructions must divide over the loader waves");
-    using GEO = PlGeom<AP, BN>;
-    static_assert(!(GEO::deep && EARLYW), "the deep ring is for forward passes");
     const char* src[PER];
     unsigned dst[PER];
     int64_t step[PER];
@@ -143,7 +130,7 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
         const unsigned short* base = isA ? g.A + plane * g.pa : g.B + plane * g.pb;
         const int64_t ld = isA ? g.lda : g.ldb;
         const int mn0 = isA ? m0 : n0;
-        dst[j] = (isA ? plane * PL_PLANE : GEO::BOFF + plane * GEO::BPL) + sub * 1024;
+        dst[j] = (isA ? plane : 3 + plane) * PL_PLANE + sub * 1024;
         if (lay == LAY_K) {      // ROW: 16 rows x 64 B per instruction
             const int row = 16 * sub + (lane >> 2);
             const int c = (lane & 3) ^ pl_row_swz<MS>(row);
@@ -158,45 +145,12 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
     }
 #define PL_ISSUE(T)                                                                           \
     do {                                                                                      \
-        const unsigned so = ((T) % GEO::NST) * GEO::STG;                                      \
+        const unsigned so = ((T) % PL_NSTAGE) * PL_STAGE;                                     \
         _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                     \
             pl_glds16(src[j], so + dst[j], smem);                                             \
             src[j] += step[j];                                                                \
         }                                                                                     \
     } while (0)
-    if constexpr (GEO::deep) {
-        // six compact stages: stage 0 alone first, then the ring is filled; every iteration waits for stage it + 1 with up
-        // to NST - 2 younger stages in flight, meets the barrier that frees slot `it`, and refills it with stage it + NST
-        constexpr int NST = GEO::NST;
-        PL_STAMP(1);
-        PL_ISSUE(0);
-        PL_STAMP(2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PL_STAMP(3);
-        __builtin_amdgcn_s_barrier();                // stage 0 landed
-#pragma unroll
-        for (int t = 1; t < NST; ++t)
-            if (t < nt) { PL_ISSUE(t); }
-        for (int it = 0; it < nt; ++it) {
-            const int young = nt - 2 - it;           // stages younger than it + 1 still to land (capped at NST - 2)
-            if (young >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * PER) : "memory");
-            else if (young == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * PER) : "memory");
-            else if (young == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER) : "memory");
-            else if (young == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();            // every read of stage `it` is done: its slot is free
-// diagnostic builds (wrong results; fixed_cost_probe.py narrow): PL_DIAG_NARROW = 1: no MFMAs anywhere (feed + LDS reads +
-// barriers only), 2: the deep loader stops feeding after the ring is full (MFMAs + LDS reads + barriers only)
-#ifndef PL_DIAG_NARROW
-#define PL_DIAG_NARROW 0
-#endif
-            if (PL_DIAG_NARROW != 2 && it + NST < nt) { PL_ISSUE(it + NST); }
-            if (it == 7) PL_STAMP(5);                // eight stages into the loop
-            if (it == 23) PL_STAMP(6);
-        }
-        PL_STAMP(4);
-        return;
-    }
     // (Rejected on the way, same-box builds, profiles/r02z_*_variants.log: a loader that copies through registers
     // -- global_load_dwordx4 -> ds_write_b128, same images -- 159.4 vs 150.9 us per step; partial tiles stored in whole
     // rows through the LDS-parked tile 153.7 vs 153.0 / 153.5.)
@@ -484,7 +438,7 @@ __device__ __forceinline__ void pl_offsets16(int lane, int wm, int wn, int (&off
 }
 
 // Building blocks of the 16x16x32 consumers (pl_consume16, pl_consume16_bal); they expect offA / offB / acc and the
-// constants NA, NB, RA, RB, NM, and the stage geometry BOFF_ / BPL_ (PlGeom), in scope.
+// constants NA, NB, RA, RB, NM in scope.
 #define RD_A(FA, BASE, HALF)                                                                  \
     _Pragma("unroll") for (int pl = 0; pl < NA; ++pl)                                         \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
@@ -492,10 +446,7 @@ __device__ __forceinline__ void pl_offsets16(int lane, int wm, int wn, int (&off
 #define RD_B(FB, BASE, HALF)                                                                  \
     _Pragma("unroll") for (int pl = 0; pl < NB; ++pl)                                         \
         _Pragma("unroll") for (int i = 0; i < NBH; ++i)                                       \
-            FB[pl][i] = pl_frag<LB>((BASE) + BOFF_ + pl * BPL_, offB[NBH * (HALF) + i][0], offB[NBH * (HALF) + i][1]);
-#if defined(PL_DIAG_NARROW) && PL_DIAG_NARROW == 1
-#define MMQ(FA, FB, AH, BH) do {} while (0)
-#else
+            FB[pl][i] = pl_frag<LB>((BASE) + (3 + pl) * PL_PLANE, offB[NBH * (HALF) + i][0], offB[NBH * (HALF) + i][1]);
 #define MMQ(FA, FB, AH, BH)                                                                   \
     _Pragma("unroll") for (int a = 0; a < 2; ++a)                                             \
         _Pragma("unroll") for (int b = 0; b < NBH; ++b) {   /* smallest products first */     \
@@ -515,7 +466,6 @@ __device__ __forceinline__ void pl_offsets16(int lane, int wm, int wn, int (&off
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], c, 0, 0, 0);  \
             }                                                                                 \
         }
-#endif
 // issue order: the prefetched half's LDS reads one by one under this quarter's MFMAs
 #define ORD(NR)                                                                               \
     _Pragma("unroll") for (int i_ = 0; i_ < ((NR) < NM ? (NR) : NM); ++i_) {                  \
@@ -578,90 +528,23 @@ __device__ __forceinline__ void pl_consume16(char* smem, int nt, int lane, int w
     int offA[4][2], offB[4][2];
     pl_offsets16<LA, LB>(lane, wm, wn, offA, offB);
     PL_CONSUME_CONSTS();
-    using GEO = PlGeom<AP, NBH == 1 ? 64 : 128>;
-    constexpr int BOFF_ = GEO::BOFF, BPL_ = GEO::BPL, NST = GEO::NST, STG = GEO::STG;
     pbf16x8 Alo[3][2], Ahi[3][2], Blo[3][2], Bhi[3][2];
     if (open_barrier) __syncthreads();               // stage 0 landed
     RD_A(Alo, smem, 0);
     RD_B(Blo, smem, 0);
     for (int it = 0; it < nt; it += 2) {
         {   // even stage
-            const char* base = smem + (it % NST) * STG;
-            const char* next = smem + ((it + 1) % NST) * STG;
+            const char* base = smem + (it % PL_NSTAGE) * PL_STAGE;
+            const char* next = smem + ((it + 1) % PL_NSTAGE) * PL_STAGE;
             PL_STAGE_EVEN(base, next, PL_MAIN_BARRIER());
         }
         if (it + 1 < nt) {   // odd stage
-            const char* base = smem + ((it + 1) % NST) * STG;
-            const char* next = smem + ((it + 2) % NST) * STG;
+            const char* base = smem + ((it + 1) % PL_NSTAGE) * PL_STAGE;
+            const char* next = smem + ((it + 2) % PL_NSTAGE) * PL_STAGE;
             PL_STAGE_ODD(base, next, PL_MAIN_BARRIER());
         }
     }
     if (bar_wait_out) *bar_wait_out = bar_wait;
-}
-
-// Consumer of the DEEP geometry (128 x 64 tile, ROW operands, one-plane A: propdown on narrow tiles).  A wave's 64 x 32
-// share of a stage is only 24 MFMAs (0.22 us): the quarter-by-quarter serpentine above leaves 6 MFMAs to cover each
-// fragment read, and the loop then runs at the LDS latency (0.5 us per stage with or without feed, with or without MFMAs:
-// profiles/r03zi_narrow_loop_ablation.log).  Here the fragments of a WHOLE stage (4 A + 6 B registers groups, 40 VGPRs)
-// are read one stage ahead, right after the barrier that says the next stage has landed, under the 24 MFMAs of the
-// current one.  Per accumulator the products arrive in the same order as in pl_consume16 (a1 b3, a1 b2, a1 b1, stage by
-// stage): the same bits.
-__device__ __forceinline__ void pl_consume16_deep(char* smem, int nt, int lane, int wm, int wn, pf32x4a (&acc)[4][2])
-{
-    using GEO = PlGeom<1, 64>;
-    const int c16 = lane & 15, q = lane >> 4;
-    int offA[4], offB[2];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int row = wm + 16 * b + c16;
-        offA[b] = row * 64 + ((q ^ pl_row_swz<16>(row)) << 4);
-    }
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int row = wn + 16 * b + c16;
-        offB[b] = row * 64 + ((q ^ pl_row_swz<16>(row)) << 4);
-    }
-    pbf16x8 FA[2][4], FB[2][3][2];
-#define DEEP_READ(SET, BASE)                                                                  \
-    do {                                                                                      \
-        _Pragma("unroll") for (int b = 0; b < 4; ++b) FA[SET][b] = *reinterpret_cast<const pbf16x8*>((BASE) + offA[b]); \
-        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                      \
-            _Pragma("unroll") for (int b = 0; b < 2; ++b)                                     \
-                FB[SET][pl][b] = *reinterpret_cast<const pbf16x8*>((BASE) + GEO::BOFF + pl * GEO::BPL + offB[b]); \
-    } while (0)
-#define DEEP_MMA(SET)                                                                         \
-    _Pragma("unroll") for (int pl = 2; pl >= 0; --pl)      /* smallest products first, as pl_consume16 */ \
-        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                         \
-            _Pragma("unroll") for (int b = 0; b < 2; ++b)                                     \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[SET][a], FB[SET][pl][b], acc[a][b], 0, 0, 0);
-#if defined(PL_DIAG_NARROW) && PL_DIAG_NARROW == 1
-#undef DEEP_MMA
-#define DEEP_MMA(SET) do {} while (0)
-#endif
-#define DEEP_PIN(SET)                                                                         \
-    do {                                                                                      \
-        _Pragma("unroll") for (int b = 0; b < 4; ++b) asm volatile("" :: "v"(FA[SET][b]));    \
-        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                      \
-            _Pragma("unroll") for (int b = 0; b < 2; ++b) asm volatile("" :: "v"(FB[SET][pl][b])); \
-    } while (0)
-    DEEP_READ(0, smem);                              // (the caller's barrier: stage 0 has landed)
-    for (int it = 0; it < nt; it += 2) {
-        {
-            DEEP_PIN(0);                             // the reads of stage `it` have returned: its slot may be freed
-            PL_RAW_BARRIER();                        // ... and stage it + 1 has landed
-            if (it + 1 < nt) DEEP_READ(1, smem + ((it + 1) % GEO::NST) * GEO::STG);
-            DEEP_MMA(0);
-        }
-        if (it + 1 < nt) {
-            DEEP_PIN(1);
-            PL_RAW_BARRIER();
-            if (it + 2 < nt) DEEP_READ(0, smem + ((it + 2) % GEO::NST) * GEO::STG);
-            DEEP_MMA(1);
-        }
-    }
-#undef DEEP_READ
-#undef DEEP_MMA
-#undef DEEP_PIN
 }
 
 // FUSED: 0 = split-K slab / plain C store; 1 = activation + sampling epilogue on the parked tile (unsplit
@@ -707,12 +590,9 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
     constexpr bool parked_slab = FUSED == 0 && PL_SLAB_STORE != 0 && MS == 16;
     EarlySpeed es;
     (void)es;
-    Epi4x4Target tq;
-    (void)tq;
     if (wave >= 4) {
         pl_loader<LA, LB, AP, MS, (FUSED == 2 || (FUSED == 0 && LA == LAY_MN && LB == LAY_MN && AP == 3)) && MS == 16, BN>(
             g, smem, wave - 4, lane, m0, n0, kbeg, nt, &es);
-        if constexpr (FUSED == 1 && BN == 64) epi4x4_request_target<64 * (4 + PL_LW)>(g.epi, m0, n0, tq);     // ahead of the parked tile
         if constexpr (FUSED == 0 && !parked_slab) return;
     } else {
         const int r = lane & 31, h = lane >> 5;
@@ -752,11 +632,9 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
 #endif
 #ifdef MDBN_STAMP
             long long bw = 0;
-            if constexpr (PlGeom<AP, BN>::deep) pl_consume16_deep(smem, nt, lane, wm, wn, acc);
-            else pl_consume16<LA, LB, AP, NBH>(smem, nt, lane, wm, wn, acc, false, &bw);
+            pl_consume16<LA, LB, AP, NBH>(smem, nt, lane, wm, wn, acc, false, &bw);
 #else
-            if constexpr (PlGeom<AP, BN>::deep) pl_consume16_deep(smem, nt, lane, wm, wn, acc);
-            else pl_consume16<LA, LB, AP, NBH>(smem, nt, lane, wm, wn, acc, false);
+            pl_consume16<LA, LB, AP, NBH>(smem, nt, lane, wm, wn, acc, false);
 #endif
             PL_MSTAMP(10);
 #ifdef MDBN_STAMP
@@ -765,7 +643,6 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
                 g.stamps[(int64_t)blockIdx.x * 16 + 15] = bw;
             }
 #endif
-            if constexpr (FUSED == 1 && BN == 64) epi4x4_request_target<64 * (4 + PL_LW)>(g.epi, m0, n0, tq);
             // accumulator (16x16): col = lane & 15, row = 4 * (lane >> 4) + e
             const int c16 = lane & 15, q4 = lane >> 4;
             if constexpr (FUSED != 0 || parked_slab) {
@@ -946,14 +823,13 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
         return;
     }
     if constexpr (FUSED != 0) {     // all 8 waves work on the parked tile (every DMA has landed: the loaders drained vmcnt)
-        if constexpr (FUSED == 1 && BN == 64) PL_RAW_BARRIER();      // LDS only: the target requests stay in flight
-        else __syncthreads();
+        __syncthreads();
         float* T = reinterpret_cast<float*>(smem);
         constexpr int NT = 64 * (4 + PL_LW);
 #ifdef MDBN_STAMP
         if (PL_STAMP_COND && g.stamps && threadIdx.x == 0) g.stamps[(int64_t)blockIdx.x * 16 + 11] = wall_clock64();
 #endif
-        if constexpr (FUSED == 1 && BN == 64) fused_tile_epilogue_4x4<NT>(g.epi, T, m0, n0, tq);     // one pass, target requested earlier
+        if constexpr (FUSED == 1 && BN == 64) fused_tile_epilogue_4x4<NT>(g.epi, T, m0, n0);     // one pass, loads up front
         else if constexpr (FUSED == 1) fused_tile_epilogue<128, BN, NT>(g.epi, T, m0, n0);
         else if (MS == 16 && g.upd.early == 1) {     // W went early (pl_loader); the loader waves hold speed_old (+ W0)
 // diagnostic builds (wrong results; scripts/experiments/fixed_cost_probe.py stats): 1 = the new speed is formed but not
@@ -992,7 +868,7 @@ static hipError_t launch_planes_m(const PlaneGemmArgs& g, hipStream_t s)
 {
     auto kern = gemm_planes_kernel<LA, LB, AP, FUSED, MS, BN>;
     static bool attr_set = false;
-    constexpr int lds = PlGeom<AP, BN>::NST * PlGeom<AP, BN>::STG;      // 144 KB (120 KB deep ring); the parked tile of the epilogues (<= 70 KB) reuses it
+    constexpr int lds = PL_NSTAGE * PL_STAGE;        // 144 KB (the parked tile of the epilogues, 70 KB, reuses it)
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -1265,7 +1141,6 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_bal_kernel(Plane
     pl_offsets16<LA, LB>(lane, wm, wn, offA, offB);
     constexpr int NBH = 2;
     PL_CONSUME_CONSTS();
-    constexpr int BOFF_ = 3 * PL_PLANE, BPL_ = PL_PLANE;          // the default stage geometry
     pbf16x8 Alo[3][2], Ahi[3][2], Blo[3][2], Bhi[3][2];
     pf32x4a acc[4][4];
 #pragma unroll

@@ -38,8 +38,6 @@ rows = []
 VARIANTS = (("product", []), ("slab0_only", ["-DPL_DIAG_DIRTY=1"]), ("no_stores", ["-DPL_DIAG_DIRTY=2"]))
 if len(sys.argv) > 1 and sys.argv[1] == "stats":      # the tail of the statistics launch (speed epilogue: stores / everything)
     VARIANTS = (("product", []), ("stats_speed_not_stored", ["-DPL_DIAG_STATS=1"]), ("stats_no_speed_epilogue", ["-DPL_DIAG_STATS=2"]))
-if len(sys.argv) > 1 and sys.argv[1] == "narrow":     # what bounds the loop of the narrow-tile propdown: feed or matrix pipe
-    VARIANTS = (("product", []), ("narrow_no_mfma", ["-DPL_DIAG_NARROW=1"]), ("narrow_no_feed", ["-DPL_DIAG_NARROW=2"]))
 for tag, flags in VARIANTS:
     so = os.path.join(out, "libmdbn_fixedcost_%s.so" % tag)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
@@ -66,7 +64,7 @@ for tag, flags in VARIANTS:
     for (a, b), v in sorted(gaps.items(), key=lambda kv: -len(kv[1]))[:8]:
         rows.append((tag, "gap %s -> %s" % (a, b), len(v), statistics.median(v)))
     subprocess.call(["rm", "-rf", d])
-with open(os.path.join(out, "r03_fixed_cost_probe%s.log" % ("_" + VARIANTS[1][0].split("_")[0] if VARIANTS[1][0].split("_")[0] in ("stats", "narrow") else "")), "w") as f:
+with open(os.path.join(out, "r03_fixed_cost_probe%s.log" % ("_stats" if VARIANTS[1][0].startswith("stats") else "")), "w") as f:
     for tag, name, n, us in rows:
         line = "%-11s %-100s x%-6d %8.2f us" % (tag, name, n, us)
         print(line); f.write(line + "\n")

@@ -38,8 +38,7 @@ for rep in range(5):
     med = lambda a, b: float(np.median(st[:, a] - st[:, b])) / 100.0
     rows.append(dict(
         last_wg_start=us(np.maximum(st[:, 0], st[:, 8]).max()),
-        loader_setup=med(1, 0), stage0_issue=med(2, 1), stage0_landed=med(3, 2),
-        loader_first_8_stages=med(5, 3), loader_next_16_stages=med(6, 5), loader_last_8_stages=med(4, 6),
+        loader_setup=med(1, 0), stage0_issue=med(2, 1), stage0_landed=med(3, 2), loader_loop=med(4, 3),
         mfma_wait_stage0=med(9, 8), mfma_loop=med(10, 9), park_and_sync=med(11, 10), epilogue=med(12, 11),
         loop_clock_ghz=float(np.median((st[:, 14] - st[:, 13]) / np.maximum(1, (st[:, 10] - st[:, 9]) * 10.0))),
         first_done=us(st[:, 12].min()), last_done=us(st[:, 12].max())))
