@@ -26,7 +26,7 @@ def free_port():
     return p
 
 
-def run_steps(group_mode, overlap, shape="small"):
+def run_steps(group_mode, overlap, shape="small", resident="device"):
     import mdbn_amd
     V, H, N, BG = SHAPES[shape]
     eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
@@ -35,10 +35,12 @@ def run_steps(group_mode, overlap, shape="small"):
     rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123),
                         theano_rng=mdbn_amd.RandomStreams(3), engine=eng)
     _, up = rbm.get_cost_updates(lr=0.002, k=1, lambda_2=0.1, batch_size=BG)
-    fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=eng),
+    fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=eng, resident=resident),
                            data_parallel="auto" if group_mode else None, overlap=overlap)
     costs = []
     batches = [rs.permutation(N)[:BG] for _ in range(7)]
+    if resident == "host":          # the epoch's order, as the trainers announce it: every rank's feeder gathers ITS shard
+        fn.announce(batches[:6])
     for t in range(6):
         # (with the hint of the next minibatch: the overlapped order gathers it inside its statistics kernel)
         costs.append(fn(indexes=batches[t], momentum=0.3, next_indexes=batches[t + 1]))
@@ -170,6 +172,34 @@ def test_split_update_phases_equal_fused(hip_engine):
     assert float(c0) == float(c1)
     with pytest.raises(Exception):       # lambda_1 != 0 cannot be split
         e.apply_update(W, Ws, None, hb, hbs, vb, vbs, stats, 0.05, 0.01, 0.1, 0.0, 0.6, 20.0, 17.0, 0.5, phase=1)
+
+
+def host_worker(rank, world, port, outdir, resident):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", MDBN_COMM_CUS="0")
+    from mdbn_amd import dist
+    dist.init_from_env(backend="gloo")
+    out = run_steps(True, 1, "c2", resident)
+    np.savez(os.path.join(outdir, "rank%d_%s.npz" % (rank, resident)), **out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_fed_from_a_host_table(built_lib):
+    """Data-parallel step (overlapped order, c2 shape, two ranks on the one GPU) with the training table in pinned host
+    memory: every rank's row feeder gathers and uploads the rows of ITS shard of the announced minibatches -- bit for bit the
+    device-resident run, on both ranks."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    with tempfile.TemporaryDirectory() as d:
+        res = {}
+        for resident in ("device", "host"):
+            mp.spawn(host_worker, args=(2, free_port(), d, resident), nprocs=2, join=True)
+            res[resident] = [dict(np.load(os.path.join(d, "rank%d_%s.npz" % (r, resident)))) for r in range(2)]
+    for r in range(2):
+        for k in res["device"][r]:
+            assert np.array_equal(res["device"][r][k], res["host"][r][k]), (r, k)
 
 
 def capped_worker(rank, world, port, outdir):
