@@ -199,8 +199,12 @@ class StepFunction(object):
         for key, h in zip(batches, host_indexes):
             h = h if isinstance(h, torch.Tensor) else torch.from_numpy(numpy.ascontiguousarray(numpy.asarray(h), dtype=numpy.int64))
             h = h.to(torch.int64).reshape(-1)
-            if len(h) and (int(h.min()) < 0 or int(h.max()) >= len(table)):
-                raise IndexError("minibatch index outside the table's %d rows" % len(table))
+            if len(h):      # as engine.index_tensor: numpy fancy indexing (negative values count from the end)
+                lo_i, hi_i = int(h.min()), int(h.max())
+                if lo_i < -len(table) or hi_i >= len(table):
+                    raise IndexError("minibatch index out of range for %d rows: [%d, %d]" % (len(table), lo_i, hi_i))
+                if lo_i < 0:
+                    h = torch.where(h < 0, h + len(table), h)
             lo, hi = self._shard(len(h))
             shards.append((key, h[lo:hi].contiguous(), len(h), lo, hi))
         need = max(hi - lo for _, _, _, lo, hi in shards)

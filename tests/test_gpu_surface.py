@@ -551,6 +551,7 @@ def test_announced_epoch_feeds_a_host_table(hip_engine):
     x = rs.normal(size=(N, V)).astype(np.float32)
     r2 = np.random.RandomState(1)
     epoch = [r2.permutation(N)[:n] for n in (B, B, B, 77, B, B, B, B, 5, B)]
+    epoch[1] = epoch[1] - N                                          # numpy-style negative indexes (count from the end)
     outs = []
     for resident in ("device", "host"):
         rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123),
