@@ -87,12 +87,15 @@ class Group(object):
         return td.all_reduce(tensor, op=td.ReduceOp.SUM, group=self.pg, async_op=True)
 
 
-DEFAULT_COMM_CUS = 32
+# 0 until a multi-GPU run says otherwise.  One GPU beside a stand-in with RCCL's footprint: if the
+# collective really holds 32 CUs for most of the step, 32 beats 0 by 4 % (203 vs 212 us); if it is short or narrow, 0 beats
+# 32 by 29 % (146 vs 188 us).  bench.py --gpus N measures 0 / 8 / 16 / 32 / 64 and RCCL channel caps and quotes the best.
+DEFAULT_COMM_CUS = 0
 
 
 def comm_cus():
-    """CUs an overlapped data-parallel step leaves to the collective (``MDBN_COMM_CUS``, default 32 of 256: the
-    step's GEMMs then run on 224 workgroups, a multiple of the tile counts at the c2 shape)."""
+    """CUs an overlapped data-parallel step leaves to the collective (``MDBN_COMM_CUS``; e.g. 32 of 256: the step's GEMMs
+    then run balanced on 224 workgroups, a multiple of the tile counts at the c2 shape)."""
     return max(0, min(192, int(os.environ.get("MDBN_COMM_CUS", DEFAULT_COMM_CUS))))
 
 

@@ -130,9 +130,9 @@ class StepFunction(object):
             # The collective's kernels run beside the next step's GEMMs and take whole CUs (RCCL's gfx950 all-reduce
             # kernel: 248-256 VGPRs per wave, 37.6 KB LDS -- nothing of ours fits next to it), and a one-workgroup-per-
             # CU GEMM grid on fewer CUs needs a second round: measured 163 -> 219 us per step with EIGHT CUs taken.
-            # So an overlapped data-parallel step leaves `comm_cus` CUs to the collective and launches its GEMMs
-            # balanced on the rest (mdbn_planes.hip, "BALANCED launches").  MDBN_COMM_CUS
-            # overrides; dist.init_from_env caps RCCL's channels (= workgroups) at the same number.
+            # So an overlapped data-parallel step CAN leave `comm_cus` CUs to the collective and launch its GEMMs
+            # balanced on the rest (mdbn_planes.hip, "BALANCED launches"): MDBN_COMM_CUS /
+            # fn.comm_cus, default 0 (dist.DEFAULT_COMM_CUS says why); bench.py --gpus N measures the choices.
             self.comm_cus = _dist.comm_cus() if self.overlap else 0      # handed to every cd_step call
             self.engine.set_option("gemm_cw", 1)        # exact-f32 fallback kernels: one MFMA wave per SIMD
         if self.overlap:
