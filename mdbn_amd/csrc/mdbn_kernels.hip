@@ -1167,10 +1167,14 @@ template <> struct VecIO<1> {
     static __device__ __forceinline__ void store(float* p, const float (&v)[1]) { *p = v[0]; }
 };
 
-template <int NS, int CW>
+// MODE >= 0: e.gauss (bit 1) and "a sample is wanted" (bit 0) as compile-time facts (the launcher checks them): the
+// executed path is then short straight-line code.  With every case compiled into one body the activation arithmetic of a
+// tile took three times as long (measured on the fused form of this epilogue, mdbn_device.h fused_tile_epilogue_4x4).
+template <int NS, int CW, int MODE = -1>
 __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
 {
     __shared__ float red[4];
+    const bool is_gauss = MODE < 0 ? e.gauss != 0 : (MODE & 2) != 0;
     const int ldc = (int)(e.ld / CW);                    // column groups per row
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int rg = (int)(idx / ldc), cq = (int)(idx - (int64_t)rg * ldc);
@@ -1234,8 +1238,8 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
 #pragma unroll
             for (int j = 0; j < CW; ++j) pre[r][j] += bias[j];
         uint32_t wa[CW][4], wb[CW][4];       // [col][row]
-        const bool need_u = e.sample != nullptr || e.sample_plane != nullptr;
-        const bool need_z = need_u && e.gauss;
+        const bool need_u = MODE < 0 ? (e.sample != nullptr || e.sample_plane != nullptr) : (MODE & 1) != 0;
+        const bool need_z = need_u && is_gauss;
         if (need_u) {
             const uint64_t g0 = e.rng.row_offset + (uint64_t)r0;
 #pragma unroll
@@ -1260,7 +1264,7 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
                 const bool live = c0 + j < e.cols;
                 const float x = pre[r][j];
                 float m, sv = 0.f;
-                if (e.gauss) {
+                if (is_gauss) {
                     m = x;
                     if (need_u) {
                         const float u1 = philox_u01(wa[j][r]), u2 = philox_u01(wb[j][r]);
@@ -1271,7 +1275,7 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
                     if (need_u) sv = philox_u01(wa[j][r]) < m ? 1.0f : 0.0f;
                 }
                 if (e.target && live) {
-                    if (e.gauss) { const float d = sigmoidf_(x) - tgt[j]; cost += d * d; }
+                    if (is_gauss) { const float d = sigmoidf_(x) - tgt[j]; cost += d * d; }
                     else cost += tgt[j] * softplusf_(-x) + (1.0f - tgt[j]) * softplusf_(x);
                 }
                 if (!live) { m = 0.f; sv = 0.f; pre[r][j] = 0.f; }   // keep pad columns zero
@@ -1351,6 +1355,15 @@ static void launch_act_epilogue_cw(const EpiArgs& e, hipStream_t s)
     const int64_t n = ((int64_t)(e.rows + 3) / 4) * (e.ld / CW);
     const int t = epilogue_threads(e.rows, e.ld);
     const dim3 grid((unsigned)((n + t - 1) / t)), block(t);
+    // the split counts of the headline path take the specialised bodies
+    const int mode = (e.gauss ? 2 : 0) | ((e.sample != nullptr || e.sample_plane != nullptr) ? 1 : 0);
+    if (!e.bal_P && (e.nsplit == 8 || e.nsplit == 2)) {
+#define EPI_MODE_CASE(NSV, MV) \
+    if (e.nsplit == NSV && mode == MV) { hipLaunchKernelGGL((act_epilogue_kernel<NSV, CW, MV>), grid, block, 0, s, e); return; }
+        EPI_MODE_CASE(8, 0) EPI_MODE_CASE(8, 1) EPI_MODE_CASE(8, 2) EPI_MODE_CASE(8, 3)
+        EPI_MODE_CASE(2, 0) EPI_MODE_CASE(2, 1) EPI_MODE_CASE(2, 2) EPI_MODE_CASE(2, 3)
+#undef EPI_MODE_CASE
+    }
     switch (e.bal_P ? 0 : e.nsplit) {
         case 1: hipLaunchKernelGGL((act_epilogue_kernel<1, CW>), grid, block, 0, s, e); break;
         case 2: hipLaunchKernelGGL((act_epilogue_kernel<2, CW>), grid, block, 0, s, e); break;

@@ -68,8 +68,10 @@ template <int MS> __device__ __forceinline__ int pl_col_swz(int k)
 // diagnostic builds (-DMDBN_STAMP): wall-clock (100 MHz) stamps of one propup workgroup's phases, slot per phase
 #ifdef MDBN_STAMP
 // which launch is stamped: propup (default) or, with -DMDBN_STAMP_NARROW, propdown on narrow tiles
-#ifdef MDBN_STAMP_NARROW
+#if defined(MDBN_STAMP_NARROW)
 #define PL_STAMP_COND (LA == LAY_K && LB == LAY_K && AP == 1 && BN == 64)
+#elif defined(MDBN_STAMP_STATS)
+#define PL_STAMP_COND (LA == LAY_MN && LB == LAY_MN && AP == 3)
 #else
 #define PL_STAMP_COND (LA == LAY_K && LB == LAY_MN && AP == 3)
 #endif
@@ -828,6 +830,11 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
         constexpr int NT = 64 * (4 + PL_LW);
 #ifdef MDBN_STAMP
         if (PL_STAMP_COND && g.stamps && threadIdx.x == 0) g.stamps[(int64_t)blockIdx.x * 16 + 11] = wall_clock64();
+#endif
+#ifdef MDBN_STAMP
+        if constexpr (FUSED == 1 && BN == 64)
+            fused_tile_epilogue_4x4<NT>(g.epi, T, m0, n0, (PL_STAMP_COND && g.stamps) ? g.stamps + (int64_t)blockIdx.x * 16 + 5 : nullptr);
+        else
 #endif
         if constexpr (FUSED == 1 && BN == 64) fused_tile_epilogue_4x4<NT>(g.epi, T, m0, n0);     // one pass, loads up front
         else if constexpr (FUSED == 1) fused_tile_epilogue<128, BN, NT>(g.epi, T, m0, n0);
