@@ -254,13 +254,26 @@ class DBN(object):
         return records
 
     def _free_energy_gap(self, i, energy_fn, data, held_out):
-        """mean F(validation) - mean F(first n_val training rows), both seen through the layers below
-        layer i (dbn.py:476-501)."""
-        n_val = held_out.shape[0]
-        first = data.rows(slice(0, n_val)) if isinstance(data, HostTable) else data.tensor[:n_val]
+        """mean F(validation) - mean F(training rows) (dbn.py:476-501).  The reference's two cases differ in the
+        training rows they use: at layer 0 the WHOLE training set (``input_t_set = t_set``, dbn.py:478), at the
+        layers above only its first ``n_val`` rows, seen through the layers below
+        (``get_output(t_set[range(v_set.shape[0])], i-1)``, dbn.py:481-483)."""
         if i == 0:
-            below_train, below_val = first, held_out
+            if isinstance(data, HostTable) and data._mirror is None and len(data) > self.host_chunk_rows:
+                # a host-resident table is streamed through in row chunks, as in _forward; the mean is taken over
+                # the one vector of all rows' energies, so chunking does not change it
+                f_val = energy_fn(held_out, held_out)[1]
+                rbm = self.rbm_layers[0]
+                f_train = numpy.concatenate([
+                    rbm.free_energy(data.rows(slice(lo, min(len(data), lo + self.host_chunk_rows)))).get_value()
+                    for lo in range(0, len(data), self.host_chunk_rows)])
+                return float(f_val.mean() - f_train.mean())
+            below_train = data.rows(slice(0, len(data))) if isinstance(data, HostTable) and data._mirror is None \
+                else data.tensor
+            below_val = held_out
         else:
+            n_val = held_out.shape[0]
+            first = data.rows(slice(0, n_val)) if isinstance(data, HostTable) else data.tensor[:n_val]
             below_train = self._forward(first, i - 1)
             below_val = self._forward(held_out, i - 1)
         f_train, f_val = energy_fn(below_train, below_val)

@@ -575,3 +575,13 @@ def test_announced_epoch_feeds_a_host_table(hip_engine):
         outs.append((costs, rbm.W.get_value(), rbm.vbias_speed.get_value()))
     assert outs[0][0] == outs[1][0]
     assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.parametrize("resident,chunk", [("device", None), ("host", None), ("host", 16)])
+def test_free_energy_gap_uses_the_reference_row_sets_on_device(hip_engine, resident, chunk):
+    """dbn.py:476-501 on the HIP engine: the layer-0 gap compares the validation set with the WHOLE training set
+    (streamed in row chunks from a host-resident table), the upper layers' with its first n_val rows seen through
+    get_output(., i-1); each recorded gap equals the float64 oracle's on those rows (tests/_fe_gap.py)."""
+    import mdbn_amd
+    import _fe_gap
+    _fe_gap.run_and_check(mdbn_amd, hip_engine, resident=resident, host_chunk_rows=chunk, tol=2e-5)

@@ -297,3 +297,12 @@ def test_gibbs_chain_composes_eager_steps_on_checker_engine(oracle_engine):
     fn = a.make_sample_fn(v0, n_steps=3)
     mf, smp = fn()
     assert mf.shape == (B, V) and set(np.unique(smp)) <= {0.0, 1.0}
+
+
+@pytest.mark.parametrize("resident,chunk", [("device", None), ("host", None), ("host", 16)])
+def test_free_energy_gap_uses_the_reference_row_sets(oracle_engine, resident, chunk):
+    """dbn.py:476-501: layer 0 compares the validation set with the WHOLE training set, the layers above with its
+    first n_val rows through get_output(., i-1).  Every recorded gap equals the oracle's on exactly those rows."""
+    import mdbn_amd
+    import _fe_gap
+    _fe_gap.run_and_check(mdbn_amd, oracle_engine, resident=resident, host_chunk_rows=chunk)
