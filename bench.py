@@ -55,6 +55,9 @@ def parse_args():
                     help="N > 1: also sweep with the all-reduce issued through the C-ABI communicator (mdbn_allreduce_stats); off "
                          "by default: it is the same RCCL collective, and a second communicator that failed to build on one "
                          "rank would hang the run that matters")
+    ap.add_argument("--sweep-budget", type=float, default=float(os.environ.get("MDBN_BENCH_SWEEP_BUDGET_S", "150")),
+                    help="N > 1: wall seconds the whole sweep may take (points that no longer fit are reported as skipped); "
+                         "the default setting is always timed first and is what a watchdog prints if anything later hangs")
     ap.add_argument("--no-cta-sweep", action="store_true",
                     help="N > 1 on RCCL: skip the second sweep stage (communicators capped at 8 / 16 / 32 channels)")
     return ap.parse_args()
@@ -82,6 +85,7 @@ def launch_ranks(args):
         cmd.append("--sweep-capi")
     if args.no_cta_sweep:
         cmd.append("--no-cta-sweep")
+    cmd += ["--sweep-budget", str(args.sweep_budget)]
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for line in proc.stdout:
         sys.stdout.write(line)
@@ -89,21 +93,49 @@ def launch_ranks(args):
     return proc.wait()
 
 
-def pmc_traffic():
+def pmc_traffic(rows=None):
     """HBM bytes per CD STEP, summed over every kernel of the step, from the newest committed PMC profile of the
     default path (FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 passes and corrected as
     MI355X_MICROARCH.md prescribes; scripts/pmc_traffic.py).  Counters cannot be read from inside this process, so
-    the figure is the profiled one, or null."""
+    the figure is the profiled one -- and only if the profile is of THESE kernels: `rows` are the GEMM launches this run
+    just timed (kernel_breakdown); a profile that lacks one of their kernel families is refused (null + the reason)
+    instead of being quoted stale; a profile of the same kernels from edited sources is quoted with a note."""
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
         try:
             with open(path) as f:
                 d = json.load(f)
             if "step_bytes" in d:
-                best = (os.path.basename(path), d["step_bytes"], d.get("step_kernels"))
+                best = (os.path.basename(path), d)
         except Exception:
             pass
-    return best if best else (None, None, None)
+    if not best:
+        return None, None, None, "no profiles/r*_pmc_traffic.json with step_bytes"
+    name, d = best
+    kernels = d.get("step_kernels") or {}
+    if rows is not None:
+        need = set()
+        for r in rows.values():
+            k = r.get("kernel", "")
+            for fam in ("gemm_planes_bal_kernel", "gemm_planes_kernel", "skinny_gemm_kernel", "gemm_bf16x6_kernel"):
+                if k.startswith(fam):
+                    need.add(fam)
+                    break
+        have = " ".join(kernels)
+        missing = sorted(fam for fam in need if (fam + "<") not in have and (fam + " ") not in have and fam not in have)
+        if missing:
+            return name, None, None, "refused: the profile has no %s launches, this run timed them" % ", ".join(missing)
+    try:
+        from mdbn_amd import build
+        want = build.source_hash()
+        if d.get("source_hash") and d["source_hash"] != want:
+            note = "the profiled library (%s...) is not this one (%s...): same kernel families, sources edited since" \
+                % (d["source_hash"][:12], want[:12])
+        else:
+            note = None if d.get("source_hash") else "the profile predates source-hash stamping: kernel families checked only"
+    except Exception:
+        note = None
+    return name, d["step_bytes"], kernels, note
 
 
 def rccl_summary(path):
@@ -306,6 +338,53 @@ def kernel_breakdown(detail):
     return rows
 
 
+class Watchdog(object):
+    """N > 1: the first contact with real hardware must not lose its number.  Once the DEFAULT setting has been timed, its
+    complete JSON line is parked here; if anything after that (a sweep point, a second communicator, a collective of the
+    reporting tail) has not finished by the deadline, rank 0 prints the parked line and every rank leaves with exit code 0.
+    Exactly ONE line is ever printed: `finish` and the watchdog exclude each other."""
+
+    def __init__(self, rank):
+        import threading
+        self.rank, self.line, self.deadline, self.done, self.why = rank, None, None, False, ""
+        self.lock = threading.Lock()
+        self.thread = threading.Thread(target=self._watch, daemon=True)
+        self.thread.start()
+
+    def park(self, out):
+        with self.lock:
+            self.line = dict(out)
+
+    def arm(self, seconds, why):
+        with self.lock:
+            self.deadline, self.why = time.time() + seconds, why
+
+    def finish(self, out):
+        with self.lock:
+            self.done = True
+            if out is not None:
+                print(json.dumps(out))
+                sys.stdout.flush()
+
+    def _watch(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                if self.done:
+                    return
+                late = self.deadline is not None and time.time() > self.deadline + (0.0 if self.rank == 0 else 3.0)
+                if not late:
+                    continue
+                self.done = True
+                if self.rank == 0 and self.line is not None:
+                    self.line["provisional"] = True
+                    self.line["provisional_reason"] = "watchdog: '%s' did not finish in time; this is the DEFAULT setting, " \
+                                                      "timed before any sweep" % self.why
+                    print(json.dumps(self.line))
+                    sys.stdout.flush()
+            os._exit(0)
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -330,6 +409,7 @@ def main():
     B_global = B_PER_GPU * world
     td = torch.distributed
     backend_name = td.get_backend() if world > 1 else None
+    t_job0 = time.time()
 
     # synthetic z-scored features, identical on every rank
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -386,101 +466,125 @@ def main():
                 break
         return wins, cost, first
 
+    def time_kernels(first):
+        """Per-kernel durations: HIP events around every GEMM launch on its stream, over min(K, 1000) more steps (the library
+        keeps at most 8192 event pairs: time a bounded number of steps and count THOSE)."""
+        n = max(1, min(args.steps, 1000))
+        eng.kernel_timing(True)
+        run(n, first)
+        torch.cuda.synchronize(dev)
+        detail = eng.kernel_timing_detail()
+        n_recorded, _ = eng.kernel_timing_read()
+        eng.kernel_timing(False)
+        if n_recorded != len(detail):
+            raise SystemExit("kernel timing buffer overflowed: %d launches recorded, %d returned" % (n_recorded, len(detail)))
+        return detail, n, first + n
+
+    def agree(flag):
+        """All ranks take rank 0's decision (one small broadcast through the default communicator)."""
+        if world == 1:
+            return bool(flag)
+        t = torch.tensor([int(bool(flag))], dtype=torch.int32, device=dev)
+        td.broadcast(t, src=0)
+        return bool(int(t.item()))
+
+    def setting_of(fn):
+        return {"overlap": bool(getattr(fn, "overlap", False)), "comm_cus": int(getattr(fn, "comm_cus", 0)),
+                "collective": "capi" if (getattr(fn, "group", None) is not None and fn.group.native) else "torch",
+                "update_inside_statistics_gemm": int(getattr(fn, "fuse_deferred", 0)), "rccl_max_ctas": None}
+
+    def line_for(wins, cost, detail, n_timed_steps, dist_block, extras=None):
+        """The complete JSON line of one measured setting."""
+        elapsed = float(np.median(wins))
+        steps_per_s = args.steps / elapsed
+        # algorithmic FLOPs (SURVEY 8d): 2*B*V*H per product, 2k+3 products per CD-k step
+        flop_per_step = 2.0 * B_PER_GPU * V * H * (2 * K_GIBBS + 3)
+        rows = kernel_breakdown(detail)
+        n_launch = len(detail)
+        t_all = sum(d[0] for d in detail) * 1e-3
+        issued = sum(d[2] for d in detail)
+        alg = sum(d[1] for d in detail)
+        on_bf16 = all(((d[3] // 100) % 10) != 0 for d in detail) and n_launch > 0
+        peak = MFMA_BF16_PEAK_TFLOPS if on_bf16 else MFMA_F32_PEAK_TFLOPS
+        achieved = issued / t_all / 1e12 if n_launch else None
+        traffic_file, traffic, traffic_kernels, traffic_note = pmc_traffic(rows)
+        algorithmic_bytes = 4.0 * B_PER_GPU * V + 16.0 * V * H       # SURVEY 8d: v0 read once, W and W_speed read + written
+        worst = min(rows.items(), key=lambda kv: kv[1]["frac_of_pipe"])[0] if rows else None
+        out = {
+            "metric": "CD-k Gibbs steps/sec (samples/sec), GRBM 4096->1024 CD-1",
+            "value": steps_per_s * B_global * K_GIBBS,
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "timing": "median of %d windows of %d steps, each bracketed by barrier + synchronize (max over ranks)"
+                      % (len(wins), args.steps),
+            "windows_ms_per_step": [1e3 * w / args.steps for w in wins[:40]],
+            "windows_ms_per_step_min_max": [1e3 * min(wins) / args.steps, 1e3 * max(wins) / args.steps],
+            "arithmetic": "f32 operands split exactly into 3 bf16 pieces; 6 piece products (3 when one operand holds 0/1 "
+                          "samples) on v_mfma_f32_16x16x32_bf16 with f32 accumulation, operands pre-split into bf16 planes in "
+                          "HBM (error vs float64 = rocBLAS sgemm's or better); "
+                          "exact_f32_mfma_* = the same step on v_mfma_f32_32x32x2_f32",
+            "config": {"workload": "GRBM 4096->1024 CD-1, batch %d per GPU, fp32, N(0,1) rows resident in HBM "
+                                   "(BASELINE configs[%d])" % (B_PER_GPU, 1 if world == 1 else 2),
+                       "global_batch": B_global, "k": K_GIBBS, "n_data": N_DATA,
+                       "parallelism": "dp%d" % world},
+            "cd_steps_per_s": steps_per_s,
+            "step_algorithmic_f32_tflops": flop_per_step * world * steps_per_s / 1e12,          # whole job
+            "step_algorithmic_f32_tflops_over_f32_mfma_peak": flop_per_step * steps_per_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "final_cost": float(cost),
+            "distributed": dist_block,
+            # achieved = FLOPs ISSUED on the matrix pipe the GEMM kernels execute on (six / three bf16 products per
+            # algorithmic f32 product), summed over the step's GEMM launches, / their summed HIP-event durations;
+            # peak = that pipe's dense peak.  `kernels` has the same per GEMM; the f32-equivalent (algorithmic)
+            # rate is a separate, informational field.
+            "roofline": {"bound": "mfma",
+                         "kernel": "GEMM launches of the step (%s)" % ("bf16 matrix pipe, split f32 operands" if on_bf16
+                                                                       else "mixed / f32 matrix pipe"),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": (achieved / peak) if achieved else None,
+                         # HBM bytes per CD STEP over ALL kernels of the step (PMC, profiled run of the default path) beside
+                         # the algorithmic bytes of SURVEY 8d; their ratio is the re-read / double-storage overhead
+                         "traffic": traffic, "traffic_unit": "bytes per CD step, all kernels", "traffic_source": traffic_file,
+                         "traffic_note": traffic_note,
+                         "traffic_by_kernel": traffic_kernels,
+                         "algorithmic_bytes": algorithmic_bytes,
+                         "traffic_over_algorithmic": (traffic / algorithmic_bytes) if traffic else None,
+                         "launches_timed": n_launch, "launches_per_step": n_launch / float(n_timed_steps),
+                         "avg_launch_us": 1e6 * t_all / max(n_launch, 1),
+                         "issued_flop_per_step": issued / float(n_timed_steps),
+                         "algorithmic_flop_per_step": alg / float(n_timed_steps),
+                         "algorithmic_f32_tflops": alg / t_all / 1e12 if n_launch else None,
+                         "furthest_below_roof": worst,
+                         "kernels": rows},
+        }
+        if extras:
+            out.update(extras)
+        return out
+
     run(args.warmup, 0)
-    # N > 1: how many CUs to leave to the collective (and which collective) cannot be known from one GPU -- measure it
-    # here: short windows at every setting, all reported in `distributed.sweep`; the fastest is then installed and timed
-    # like the single-GPU run (it is `value`).  Every rank sees the same all-reduced times, so all pick the same setting.
-    sweep = None
-    groups = {}
-    if world > 1 and not args.no_sweep and getattr(step_fn, "overlap", False):
-        sweep = []
-        # (overlap, comm_cus, C-ABI collective, deferred update inside the statistics GEMM [comm_cus 0 only])
-        settings = [(ov, cus, nat, fu) for nat in ((False, True) if (args.sweep_capi or os.environ.get("MDBN_BENCH_SWEEP_CAPI") == "1") else (False,))
-                    for ov, cus, fu in ((True, 0, 1), (True, 0, 0), (True, 8, 0), (True, 16, 0), (True, 32, 0), (True, 32, 2),
-                                        (True, 64, 0), (False, 0, 0))]
-        nxt0 = args.warmup
-        capi_ok = None
-        for ov, cus, nat, fu in settings:
-            if nat and backend_name != "nccl":
-                continue                                  # the C-ABI communicator is RCCL: needs one GPU per rank
-            if nat and capi_ok is None:
-                capi_ok = capi_collective_alive(step_fn.group, eng, td)
-                if not capi_ok:
-                    sweep.append({"collective": "capi", "error": "mdbn_allreduce_stats did not complete a small all-reduce "
-                                                                   "within 20 s on every rank: C-ABI collective not swept"})
-            if nat and not capi_ok:
-                continue
-            step_fn.flush()
-            step_fn.overlap, step_fn.comm_cus, step_fn.group.native = ov, (cus if ov else 0), nat
-            step_fn.fuse_deferred = fu
-            try:
-                run(max(5, args.warmup // 2), nxt0)
-                w, _, nxt0 = measure(nxt0, min_total=0.15)
-                step_fn.flush()
-                ms = 1e3 * float(np.median(w)) / args.steps
-                err = None
-            except Exception as exc:                      # a setting that cannot run is reported, not fatal
-                ms, err = None, repr(exc)[:200]
-            sweep.append({"overlap": ov, "comm_cus": cus if ov else 0, "collective": "capi" if nat else "torch",
-                          "update_inside_statistics_gemm": fu, "ms_per_step": ms, "windows": len(w) if ms else 0, "error": err})
-        # Second stage, RCCL only: communicators capped at a few channel counts (one channel = one workgroup = one CU the
-        # collective takes; it has a whole step to finish 16.8 MB, so it may not need RCCL's default).  Each cap is timed
-        # with the GEMMs as they are (comm_cus 0, update inside the statistics GEMM) and balanced on the other CUs.
-        default_pg, groups = step_fn.group.pg, {None: step_fn.group.pg}
-        if backend_name == "nccl" and not args.no_cta_sweep:
-            for ctas in (8, 16, 32):
-                pg, abandoned = capped_process_group(td, eng, ctas, world)
-                if pg is None:
-                    sweep.append({"rccl_max_ctas": ctas, "error": "a communicator with this cap could not be built or did not "
-                                                                   "complete a small all-reduce within 60 s on every rank"})
-                    if abandoned:                         # a helper thread is still stuck in RCCL: no further communicators
-                        break
-                    continue
-                groups[ctas] = pg
-                for cus, fu in ((0, 1), (ctas, 0)):
-                    step_fn.flush()
-                    torch.cuda.synchronize(dev)
-                    step_fn.group.pg, step_fn.group.native = pg, False
-                    step_fn.overlap, step_fn.comm_cus, step_fn.fuse_deferred = True, cus, fu
-                    try:
-                        run(max(5, args.warmup // 2), nxt0)
-                        w, _, nxt0 = measure(nxt0, min_total=0.15)
-                        step_fn.flush()
-                        ms = 1e3 * float(np.median(w)) / args.steps
-                        err = None
-                    except Exception as exc:
-                        ms, err = None, repr(exc)[:200]
-                    sweep.append({"overlap": True, "comm_cus": cus, "collective": "torch", "rccl_max_ctas": ctas,
-                                  "update_inside_statistics_gemm": fu, "ms_per_step": ms, "windows": len(w) if ms else 0,
-                                  "error": err})
-            step_fn.flush()
-            torch.cuda.synchronize(dev)
-            step_fn.group.pg = default_pg
-        ok = [r for r in sweep if r.get("ms_per_step")]
-        step_fn.flush()
-        if ok:
-            best = min(ok, key=lambda r: r["ms_per_step"])
-            step_fn.overlap, step_fn.comm_cus = best["overlap"], best["comm_cus"]
-            step_fn.fuse_deferred = best["update_inside_statistics_gemm"]
-            step_fn.group.native = best["collective"] == "capi"
-            step_fn.group.pg = groups[best.get("rccl_max_ctas")]
-        else:                                             # nothing could be timed: the defaults, and the errors in the line
-            step_fn.overlap, step_fn.comm_cus, step_fn.fuse_deferred, step_fn.group.native = True, 0, 1, False
-        run(args.warmup, nxt0)
+    # ------------------------------------------------------------------ the DEFAULT setting, always first
     wins, cost, nxt = measure(args.warmup)
-    elapsed = float(np.median(wins))
-    final_cost = float(cost)
-    rank_ms = [1e3 * float(np.median(wins)) / args.steps]
-    allreduce_us = None
-    backend = None
+    detail, n_timed_steps, nxt = time_kernels(nxt)
+
+    dog = None
+    dist_block = {"ranks": world, "backend": backend_name, "rccl_ranks": world if backend_name == "nccl" else 0,
+                  "allreduce_bytes": 4 * (V * H + H + V + 4) if world > 1 else 0}
     if world > 1:
-        backend = td.get_backend()
-        mine = torch.tensor([rank_ms[0]], dtype=torch.float64, device=dev)
+        dist_block.update(setting_of(step_fn))
+        dist_block["update_inside_statistics_gemm"] = int(getattr(step_fn, "fuse_deferred", 0)) >= (2 if getattr(step_fn, "comm_cus", 0) else 1)
+        dist_block["collective"] = step_fn.group.collective if getattr(step_fn, "group", None) is not None else None
+        dist_block["default_setting_ms_per_step"] = 1e3 * float(np.median(wins)) / args.steps
+        dog = Watchdog(rank)
+        dog.park(line_for(wins, cost, detail, n_timed_steps, dict(dist_block, note="default setting; nothing after it finished")))
+        dog.arm(float(os.environ.get("MDBN_BENCH_TAIL_BUDGET_S", "180")), "per-rank times / all-reduce alone")
+        # per-rank times, and the collective on its own: the packed statistics buffer, summed over ranks, HIP events on the
+        # stream that waits for it (the step overlaps it with the next step's compute)
+        mine = torch.tensor([1e3 * float(np.median(wins)) / args.steps], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         td.all_gather(allr, mine)
-        rank_ms = [float(x.item()) for x in allr]
-        # the collective on its own: the packed statistics buffer, summed over ranks, HIP events on the
-        # stream that waits for it (the step overlaps it with the next step's compute)
+        dist_block["per_rank_ms_per_step"] = [float(x.item()) for x in allr]
         buf = torch.zeros(V * H + H + V + 4, dtype=torch.float32, device=dev)
         for _ in range(5):
             td.all_reduce(buf)
@@ -491,8 +595,120 @@ def main():
             td.all_reduce(buf)
         e1.record()
         torch.cuda.synchronize(dev)
-        allreduce_us = 1e3 * e0.elapsed_time(e1) / 20
-        # ... and through each channel-capped communicator of the sweep's second stage
+        dist_block["allreduce_alone_us"] = 1e3 * e0.elapsed_time(e1) / 20
+        dist_block["rccl"] = rccl_summary(rccl_log) if rank == 0 else None
+        dog.park(line_for(wins, cost, detail, n_timed_steps, dict(dist_block, note="default setting; the sweep did not finish")))
+
+    # ------------------------------------------------------------------ N > 1: the tuning curve, under ONE wall budget
+    # How many CUs to leave to the collective (and which collective) cannot be known from one GPU -- measure it here: short
+    # windows at every setting, all reported in `distributed.sweep`; the fastest is installed and timed like the default
+    # (it is `value`).  Rank 0's clock decides what still fits the budget; points that do not are reported as skipped.
+    sweep, groups, best = None, {}, None
+    budget = float(args.sweep_budget)
+    if world > 1 and not args.no_sweep and budget > 0 and getattr(step_fn, "overlap", False):
+        sweep = []
+        default = setting_of(step_fn)
+        t_sweep0 = time.time()
+        dog.arm(budget + 120.0, "data-parallel sweep (budget %.0f s)" % budget)
+        per_point = [8.0]                                     # seconds a point took so far (rank 0's estimate)
+
+        def left():
+            return budget - (time.time() - t_sweep0)
+
+        def install(st, pg):
+            step_fn.flush()
+            torch.cuda.synchronize(dev)
+            step_fn.group.pg, step_fn.group.native = pg, st["collective"] == "capi"
+            step_fn.overlap, step_fn.comm_cus = st["overlap"], (st["comm_cus"] if st["overlap"] else 0)
+            step_fn.fuse_deferred = st["update_inside_statistics_gemm"]
+
+        def point(st, pg, first):
+            """Time one setting in short windows; returns (record, next step index)."""
+            t0 = time.time()
+            rec = dict(st)
+            try:
+                install(st, pg)
+                run(max(5, args.warmup // 2), first)
+                w, _, first = measure(first, min_total=0.15)
+                step_fn.flush()
+                rec.update(ms_per_step=1e3 * float(np.median(w)) / args.steps, windows=len(w), error=None)
+            except Exception as exc:                          # a setting that cannot run is reported, not fatal
+                rec.update(ms_per_step=None, windows=0, error=repr(exc)[:200])
+            per_point.append(time.time() - t0)
+            return rec, first
+
+        default_pg = step_fn.group.pg
+        groups = {None: default_pg}
+        nxt0 = nxt
+        # (overlap, comm_cus, C-ABI collective, deferred update inside the statistics GEMM [comm_cus 0 only]); the default
+        # setting itself was timed above and is the first record
+        sweep.append(dict(default, ms_per_step=dist_block["default_setting_ms_per_step"], windows=len(wins), error=None,
+                          note="the default setting (timed first, full windows)"))
+        natives = (False, True) if (args.sweep_capi or os.environ.get("MDBN_BENCH_SWEEP_CAPI") == "1") else (False,)
+        settings = [dict(overlap=ov, comm_cus=cus if ov else 0, collective="capi" if nat else "torch",
+                         update_inside_statistics_gemm=fu, rccl_max_ctas=None)
+                    for nat in natives
+                    for ov, cus, fu in ((True, 0, 1), (True, 0, 0), (True, 8, 0), (True, 16, 0), (True, 32, 0), (True, 32, 2),
+                                        (True, 64, 0), (False, 0, 0))]
+        settings = [st for st in settings if st != default]
+        capi_ok = None
+        for st in settings:
+            if not agree(left() > 1.5 * max(per_point)):
+                sweep.append(dict(st, skipped="wall budget of %.0f s" % budget))
+                continue
+            if st["collective"] == "capi":
+                if backend_name != "nccl":
+                    continue                                  # the C-ABI communicator is RCCL: needs one GPU per rank
+                if capi_ok is None:
+                    capi_ok = capi_collective_alive(step_fn.group, eng, td)
+                    if not capi_ok:
+                        sweep.append({"collective": "capi", "error": "mdbn_allreduce_stats did not complete a small all-reduce "
+                                                                       "within 20 s on every rank: C-ABI collective not swept"})
+                if not capi_ok:
+                    continue
+            rec, nxt0 = point(st, default_pg, nxt0)
+            sweep.append(rec)
+        # Second stage, RCCL only: communicators capped at a few channel counts (one channel = one workgroup = one CU the
+        # collective takes; it has a whole step to finish 16.8 MB, so it may not need RCCL's default).  Each cap is timed
+        # with the GEMMs as they are (comm_cus 0, update inside the statistics GEMM) and balanced on the other CUs.  Skipped
+        # entirely when stage one has eaten the budget; never continued after a communicator had to be abandoned.
+        if backend_name == "nccl" and not args.no_cta_sweep:
+            for ctas in (8, 16, 32):
+                if not agree(left() > 40.0 + 2 * max(per_point)):
+                    sweep.append({"rccl_max_ctas": ctas, "skipped": "wall budget of %.0f s" % budget})
+                    continue
+                pg, abandoned = capped_process_group(td, eng, ctas, world, deadline_s=min(60.0, max(10.0, left() - 20.0)))
+                if pg is None:
+                    sweep.append({"rccl_max_ctas": ctas, "error": "a communicator with this cap could not be built or did not "
+                                                                   "complete a small all-reduce in time on every rank"})
+                    if abandoned:                             # a helper thread is still stuck in RCCL: no further communicators
+                        break
+                    continue
+                groups[ctas] = pg
+                for cus, fu in ((0, 1), (ctas, 0)):
+                    st = dict(overlap=True, comm_cus=cus, collective="torch", update_inside_statistics_gemm=fu, rccl_max_ctas=ctas)
+                    if not agree(left() > 1.5 * max(per_point)):
+                        sweep.append(dict(st, skipped="wall budget of %.0f s" % budget))
+                        continue
+                    rec, nxt0 = point(st, pg, nxt0)
+                    sweep.append(rec)
+        ok = [r for r in sweep if r.get("ms_per_step")]
+        best = min(ok, key=lambda r: r["ms_per_step"])
+        dist_block["sweep_wall_s"] = time.time() - t_sweep0
+        dog.arm(float(os.environ.get("MDBN_BENCH_TAIL_BUDGET_S", "180")), "final timing of the best sweep point")
+        if {k: best[k] for k in default} != default:
+            # the best point, timed like the default was: it becomes `value`
+            install({k: best[k] for k in default}, groups[best.get("rccl_max_ctas")])
+            run(args.warmup, nxt0)
+            wins, cost, nxt0 = measure(nxt0)
+            detail, n_timed_steps, nxt0 = time_kernels(nxt0)
+        else:
+            install(default, default_pg)
+        nxt = nxt0
+        dist_block.update({k: best[k] for k in default})
+        dist_block["update_inside_statistics_gemm"] = int(step_fn.fuse_deferred) >= (2 if step_fn.comm_cus else 1)
+        dist_block["collective"] = step_fn.group.collective
+        # the all-reduce alone through each channel-capped communicator of the second stage
         allreduce_by_cap = {}
         for ctas, pg in sorted((k, v) for k, v in groups.items() if k is not None):
             try:
@@ -507,19 +723,35 @@ def main():
                 allreduce_by_cap[str(ctas)] = 1e3 * e0.elapsed_time(e1) / 20
             except Exception as exc:
                 allreduce_by_cap[str(ctas)] = repr(exc)[:120]
-
-    # per-kernel durations: HIP events around every GEMM launch on its stream, over K more steps
-    # (the library keeps at most 8192 event pairs: time a bounded number of steps and count THOSE)
-    n_timed_steps = max(1, min(args.steps, 1000))
-    eng.kernel_timing(True)
-    run(n_timed_steps, nxt)
-    torch.cuda.synchronize(dev)
-    detail = eng.kernel_timing_detail()
-    n_recorded, _ = eng.kernel_timing_read()
-    eng.kernel_timing(False)
-    nxt += n_timed_steps
-    if n_recorded != len(detail):
-        raise SystemExit("kernel timing buffer overflowed: %d launches recorded, %d returned" % (n_recorded, len(detail)))
+        dist_block["allreduce_alone_us_by_rccl_max_ctas"] = allreduce_by_cap
+    if world > 1:
+        dist_block["sweep"] = sweep
+        dog.park(line_for(wins, cost, detail, n_timed_steps, dict(dist_block, note="the reporting tail did not finish")))
+        dog.arm(float(os.environ.get("MDBN_BENCH_TAIL_BUDGET_S", "180")), "exposed-communication probe")
+        # What the collective costs the step: the SAME setting with both all-reduce calls stubbed out (Group.stub_collective:
+        # measurement only -- the replicas then train on their own shards' statistics, which is why this comes last).
+        try:
+            step_fn.flush()
+            torch.cuda.synchronize(dev)
+            step_fn.group.stub_collective = True
+            run(max(5, args.warmup // 2), nxt)
+            w, _, nxt = measure(nxt, min_total=0.3)
+            step_fn.flush()
+            stub_ms = 1e3 * float(np.median(w)) / args.steps
+            step_ms = 1e3 * float(np.median(wins)) / args.steps
+            stat_us = sum(r["avg_us"] * r["launches"] for k, r in kernel_breakdown(detail).items() if k.startswith("statistics")) \
+                / float(n_timed_steps)
+            inside = dist_block["update_inside_statistics_gemm"]
+            dist_block["exposed_comm_us"] = 1e3 * (step_ms - stub_ms)
+            dist_block["step_without_collective_ms"] = stub_ms
+            # how long the collective may run before the step waits for it: a whole step when the deferred update follows
+            # the step, the step minus its statistics launch when that launch applies the update (it waits first)
+            dist_block["cover_us"] = (1e3 * step_ms - stat_us) if (inside and step_fn.overlap) else (1e3 * step_ms if step_fn.overlap else 0.0)
+        except Exception as exc:
+            dist_block["exposed_comm_us"] = None
+            dist_block["exposed_comm_error"] = repr(exc)[:200]
+        finally:
+            step_fn.group.stub_collective = False
 
     # the same steps with the GEMMs forced onto the exact-f32 MFMA (v_mfma_f32_32x32x2_f32): by default
     # they run on the bf16 matrix pipe with three-way split operands and f32 accumulation (f32 accuracy,
@@ -610,88 +842,24 @@ def main():
         fe_rel_elem = float(np.max(np.abs(F - F_o) / np.abs(F_o)))
 
     if rank != 0:
+        if dog is not None:
+            dog.finish(None)
         return
-    rccl_info = rccl_summary(rccl_log)
-    steps_per_s = args.steps / elapsed
-    # algorithmic FLOPs: 2*B*V*H per product, 2k+3 products per CD-k step
-    flop_per_step = 2.0 * B_PER_GPU * V * H * (2 * K_GIBBS + 3)
-    rows = kernel_breakdown(detail)
-    n_launch = len(detail)
-    t_all = sum(d[0] for d in detail) * 1e-3
-    issued = sum(d[2] for d in detail)
-    alg = sum(d[1] for d in detail)
-    on_bf16 = all(((d[3] // 100) % 10) != 0 for d in detail) and n_launch > 0
-    peak = MFMA_BF16_PEAK_TFLOPS if on_bf16 else MFMA_F32_PEAK_TFLOPS
-    achieved = issued / t_all / 1e12 if n_launch else None
-    traffic_file, traffic, traffic_kernels = pmc_traffic()
-    algorithmic_bytes = 4.0 * B_PER_GPU * V + 16.0 * V * H           # v0 read once, W and W_speed read + written
-    worst = min(rows.items(), key=lambda kv: kv[1]["frac_of_pipe"])[0] if rows else None
-    out = {
-        "metric": "CD-k Gibbs steps/sec (samples/sec), GRBM 4096->1024 CD-1",
-        "value": steps_per_s * B_global * K_GIBBS,
-        "unit": "samples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "timing": "median of %d windows of %d steps, each bracketed by barrier + synchronize (max over ranks)"
-                  % (len(wins), args.steps),
-        "windows_ms_per_step": [1e3 * w / args.steps for w in wins[:40]],
-        "windows_ms_per_step_min_max": [1e3 * min(wins) / args.steps, 1e3 * max(wins) / args.steps],
-        "arithmetic": "f32 operands split exactly into 3 bf16 pieces; 6 piece products (3 when one operand holds 0/1 "
-                      "samples) on v_mfma_f32_16x16x32_bf16 with f32 accumulation, operands pre-split into bf16 planes in "
-                      "HBM (error vs float64 = rocBLAS sgemm's); "
-                      "exact_f32_mfma_* = the same step on v_mfma_f32_32x32x2_f32",
+    dist_block["wall_s_since_start"] = time.time() - t_job0
+    out = line_for(wins, cost, detail, n_timed_steps, dist_block, {
         "exact_f32_mfma_ms_per_step": exact_ms,
         "exact_f32_mfma_value": (B_global * K_GIBBS * 1e3 / exact_ms) if exact_ms else None,
         "exact_f32_mfma_kernels": exact_rows,
         "bf16_input_mode": bf16_in,
         "pcie_inclusive_host_resident_table": pcie,
-        "config": {"workload": "GRBM 4096->1024 CD-1, batch %d per GPU, fp32, N(0,1) rows resident in HBM "
-                               "(BASELINE configs[%d])" % (B_PER_GPU, 1 if world == 1 else 2),
-                   "global_batch": B_global, "k": K_GIBBS, "n_data": N_DATA,
-                   "parallelism": "dp%d" % world},
-        "cd_steps_per_s": steps_per_s,
-        "step_algorithmic_f32_tflops": flop_per_step * world * steps_per_s / 1e12,          # whole job
-        "step_algorithmic_f32_tflops_over_f32_mfma_peak": flop_per_step * steps_per_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
-        "final_cost": final_cost,
         "free_energy_max_rel_err_vs_f64_oracle": fe_rel,
-        "free_energy_max_elementwise_rel_err": fe_rel_elem,
-        "distributed": {"ranks": world, "backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
-                        "per_rank_ms_per_step": rank_ms, "allreduce_alone_us": allreduce_us,
-                        "allreduce_alone_us_by_rccl_max_ctas": (allreduce_by_cap if world > 1 else None),
-                        "allreduce_bytes": 4 * (V * H + H + V + 4) if world > 1 else 0,
-                        "overlap": bool(getattr(step_fn, "overlap", False)),
-                        "comm_cus": int(getattr(step_fn, "comm_cus", 0)),
-                        "update_inside_statistics_gemm": int(getattr(step_fn, "fuse_deferred", 0)) >= (2 if getattr(step_fn, "comm_cus", 0) else 1),
-                        "collective": step_fn.group.collective if getattr(step_fn, "group", None) is not None else None,
-                        "rccl_max_ctas": (best.get("rccl_max_ctas") if (sweep and ok) else None),
-                        "sweep": sweep, "rccl": rccl_info},
-        # achieved = FLOPs ISSUED on the matrix pipe the GEMM kernels execute on (six / three bf16 products per
-        # algorithmic f32 product), summed over the step's GEMM launches, / their summed HIP-event durations;
-        # peak = that pipe's dense peak.  `kernels` has the same per GEMM; the f32-equivalent (algorithmic)
-        # rate is a separate, informational field.
-        "roofline": {"bound": "mfma",
-                     "kernel": "GEMM launches of the step (%s)" % ("bf16 matrix pipe, split f32 operands" if on_bf16
-                                                                   else "mixed / f32 matrix pipe"),
-                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                     "frac": (achieved / peak) if achieved else None,
-                     # HBM bytes per CD STEP over ALL kernels of the step (PMC, profiled run of the default path) beside
-                     # the algorithmic bytes of SURVEY 8d; their ratio is the re-read / double-storage overhead
-                     "traffic": traffic, "traffic_unit": "bytes per CD step, all kernels", "traffic_source": traffic_file,
-                     "traffic_by_kernel": traffic_kernels,
-                     "algorithmic_bytes": algorithmic_bytes,
-                     "traffic_over_algorithmic": (traffic / algorithmic_bytes) if traffic else None,
-                     "launches_timed": n_launch, "launches_per_step": n_launch / float(n_timed_steps),
-                     "avg_launch_us": 1e6 * t_all / max(n_launch, 1),
-                     "issued_flop_per_step": issued / float(n_timed_steps), "algorithmic_flop_per_step": alg / float(n_timed_steps),
-                     "algorithmic_f32_tflops": alg / t_all / 1e12 if n_launch else None,
-                     "furthest_below_roof": worst,
-                     "kernels": rows},
-    }
+        "free_energy_max_elementwise_rel_err": fe_rel_elem})
     if world == 1 and not args.no_cpu_baseline and not args.default_only:
         out["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(out))
+    if dog is not None:
+        dog.finish(out)
+    else:
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

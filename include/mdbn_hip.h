@@ -32,7 +32,9 @@ extern "C" {
 #define MDBN_EHIP    (-2)   /* a HIP runtime call failed */
 #define MDBN_ENOSPC  (-3)   /* workspace too small */
 
-#define MDBN_VERSION 1
+/* 2 (round 4): mdbn_cd_args and mdbn_update_args begin with `struct_size` -- a caller built against another layout of
+ * either struct is refused with MDBN_EINVAL instead of having trailing fields read from whatever follows its struct. */
+#define MDBN_VERSION 2
 
 typedef struct mdbn_ctx mdbn_ctx;
 
@@ -49,6 +51,7 @@ typedef struct mdbn_rng {
 /* Everything one CD-k / PCD-k step needs: the compiled step function of
  * src/rbm.py:258-376 (+ the minibatch gather of src/dbn.py:307 / src/rbm.py:538). */
 typedef struct mdbn_cd_args {
+    uint64_t     struct_size; /* = sizeof(mdbn_cd_args) of the header the caller was built with; anything else: MDBN_EINVAL */
     /* data */
     const float *data;        /* [n_data, ldv] training matrix (train_set_x)                    */
     int64_t      n_data;
@@ -115,6 +118,7 @@ typedef struct mdbn_cd_args {
 
 /* Parameter update of src/rbm.py:347-365 from (all-reduced) statistics. */
 typedef struct mdbn_update_args {
+    uint64_t struct_size;           /* = sizeof(mdbn_update_args); anything else: MDBN_EINVAL */
     float *W, *W_speed;             /* [V, ldh] */
     const float *W0;                /* frozen weight-cost snapshot (rbm.py:415) or NULL = live W */
     float *hbias, *hbias_speed;     /* [H] */

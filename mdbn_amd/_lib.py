@@ -16,8 +16,16 @@ class Rng(C.Structure):
                 ("draw", C.c_uint32), ("reserved", C.c_uint32), ("row_offset", C.c_uint64)]
 
 
-class CdArgs(C.Structure):
-    _fields_ = [("data", C.c_void_p), ("n_data", C.c_int64), ("indexes", C.c_void_p),
+class _Sized(C.Structure):
+    """By-pointer argument structs begin with their own size (mdbn_hip.h, MDBN_VERSION 2): set on construction."""
+
+    def __init__(self, *a, **kw):
+        super(_Sized, self).__init__(*a, **kw)
+        self.struct_size = C.sizeof(type(self))
+
+
+class CdArgs(_Sized):
+    _fields_ = [("struct_size", C.c_uint64), ("data", C.c_void_p), ("n_data", C.c_int64), ("indexes", C.c_void_p),
                 ("index_is_64", C.c_int32), ("gauss", C.c_int32), ("add_noise", C.c_int32),
                 ("sample_stats", C.c_int32), ("keep_f32", C.c_int32), ("k", C.c_int32), ("B", C.c_int64), ("V", C.c_int64), ("H", C.c_int64),
                 ("ldv", C.c_int64), ("ldh", C.c_int64),
@@ -32,8 +40,8 @@ class CdArgs(C.Structure):
                 ("v0_ready", C.c_int32), ("ahead_done", C.POINTER(C.c_int32))]
 
 
-class UpdateArgs(C.Structure):
-    _fields_ = [("W", C.c_void_p), ("W_speed", C.c_void_p), ("W0", C.c_void_p),
+class UpdateArgs(_Sized):
+    _fields_ = [("struct_size", C.c_uint64), ("W", C.c_void_p), ("W_speed", C.c_void_p), ("W0", C.c_void_p),
                 ("hbias", C.c_void_p), ("hbias_speed", C.c_void_p),
                 ("vbias", C.c_void_p), ("vbias_speed", C.c_void_p),
                 ("V", C.c_int64), ("H", C.c_int64), ("ldv", C.c_int64), ("ldh", C.c_int64),
@@ -142,8 +150,8 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = C.c_int
-    if lib.mdbn_version() != 1:
-        raise MdbnError("libmdbn_hip.so version mismatch")
+    if lib.mdbn_version() != 2:
+        raise MdbnError("libmdbn_hip.so version mismatch (the ctypes layouts here are those of MDBN_VERSION 2)")
     buf = C.create_string_buffer(80)
     lib.mdbn_source_hash(buf, 80)
     if not _diagnostic and buf.value.decode() != _build.source_hash():

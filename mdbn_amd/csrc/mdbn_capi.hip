@@ -2,7 +2,7 @@
 // planning, workspace carving and the launch sequence of one CD-k step.  No allocation,
 // no synchronisation: every entry point only enqueues kernels on the caller's stream.
 #include <hip/hip_runtime.h>
-#include <emmintrin.h>
+#include "row_pool.h"
 #include <dlfcn.h>
 #include <algorithm>
 #include <atomic>
@@ -1408,6 +1408,9 @@ int mdbn_apply_update(mdbn_ctx* ctx, void* stream, const mdbn_update_args* a)
 
 static int check_update_args(const mdbn_update_args* a)
 {
+    REQUIRE(a->struct_size == sizeof(mdbn_update_args),
+            "mdbn_update_args.struct_size is %llu, this library's struct has %llu bytes (built against another mdbn_hip.h?)",
+            (unsigned long long)a->struct_size, (unsigned long long)sizeof(mdbn_update_args));
     REQUIRE(a->V > 0 && a->H > 0 && a->ldh >= a->H && a->ldv >= a->V && a->ldh % 4 == 0 && a->ldv % 4 == 0,
             "bad shape / leading dims");
     CHECK(check_mat(a->W, a->ldh, a->H, "W"));
@@ -1427,6 +1430,9 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
                         const mdbn_update_args* defer = nullptr)
 {
     REQUIRE(ctx != nullptr && a != nullptr, "NULL argument");
+    REQUIRE(a->struct_size == sizeof(mdbn_cd_args),
+            "mdbn_cd_args.struct_size is %llu, this library's struct has %llu bytes (built against another mdbn_hip.h?)",
+            (unsigned long long)a->struct_size, (unsigned long long)sizeof(mdbn_cd_args));
     const int64_t B = a->B, V = a->V, H = a->H, ldv = a->ldv, ldh = a->ldh;
     REQUIRE(B > 0 && V > 0 && H > 0 && a->k >= 1, "bad shape / k");
     REQUIRE(a->comm_cus >= 0 && a->comm_cus <= 192, "comm_cus must be in [0, 192]");
@@ -1770,108 +1776,7 @@ int mdbn_philox_host(float* out, int64_t rows, int64_t cols, int64_t ld, const m
 // stream (SDMA), the consuming stream waits for the copy's event.  A kernel reading the pinned table over PCIe beside the
 // step slows every GEMM of the step (one-workgroup-per-CU grids: step 145 -> 215 us); an SDMA copy
 // does not (145.7 -> 147.3 us).  The ring is `slots` deep so the copy of minibatch t + 2 runs beside step t.
-namespace {
-struct RowPool {                                  // persistent worker threads: out[r] = table[idx[r]]
-    // Workers SPIN for a job for up to 2 ms after the last one before they sleep on the condition variable: a feed delivers a
-    // minibatch every ~170 us, and waking a sleeping thread costs 50+ us each on the GPU box's host (8.4 MB gathered in
-    // 228 us with sleeping workers, 85 us with spinning ones).  An idle pool sleeps.
-    std::vector<std::thread> workers;
-    std::mutex m;
-    std::condition_variable cv_work;
-    const float* src = nullptr; int64_t ld_src = 0, n_rows = 0, cols = 0;
-    const int64_t* idx = nullptr; int64_t n = 0;
-    float* dst = nullptr; int64_t ld_dst = 0;
-    std::atomic<int64_t> next{0};
-    std::atomic<int> bad{0};
-    std::atomic<uint64_t> generation{0};
-    std::atomic<int> running{0}, sleepers{0};
-    std::atomic<bool> stop{false};
-
-    static void relax() { __builtin_ia32_pause(); }
-    // one row into the staging slot with NON-TEMPORAL stores: the slot is read next by the copy engine, not by a CPU, and a
-    // plain memcpy first reads every destination line for ownership (3 bytes of traffic per byte copied instead of 2)
-    static void copy_row(float* d, const float* s, size_t bytes)
-    {
-        if ((reinterpret_cast<uintptr_t>(d) & 15u) != 0 || bytes < 256) { memcpy(d, s, bytes); return; }
-        const __m128i* sp = reinterpret_cast<const __m128i*>(s);
-        __m128i* dp = reinterpret_cast<__m128i*>(d);
-        size_t q = bytes / 64;
-        for (; q > 0; --q, sp += 4, dp += 4) {
-            const __m128i a = _mm_loadu_si128(sp), b = _mm_loadu_si128(sp + 1), c = _mm_loadu_si128(sp + 2), e = _mm_loadu_si128(sp + 3);
-            _mm_stream_si128(dp, a); _mm_stream_si128(dp + 1, b); _mm_stream_si128(dp + 2, c); _mm_stream_si128(dp + 3, e);
-        }
-        const size_t done = bytes / 64 * 64;
-        if (done < bytes) memcpy(reinterpret_cast<char*>(d) + done, reinterpret_cast<const char*>(s) + done, bytes - done);
-    }
-    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-    explicit RowPool(int threads)
-    {
-        for (int t = 0; t < threads; ++t) workers.emplace_back([this] { loop(); });
-    }
-    ~RowPool()
-    {
-        { std::lock_guard<std::mutex> l(m); stop.store(true); }
-        cv_work.notify_all();
-        for (auto& w : workers) w.join();
-    }
-    void rows()                                   // a few rows at a time: contiguous row copies, dynamic balance
-    {
-        constexpr int64_t CHUNK = 4;
-        for (;;) {
-            const int64_t r0 = next.fetch_add(CHUNK);
-            if (r0 >= n) break;
-            for (int64_t r = r0; r < std::min(n, r0 + CHUNK); ++r) {
-                const int64_t s = idx ? idx[r] : r;
-                if (s < 0 || s >= n_rows) { bad.store(1); continue; }
-                copy_row(dst + r * ld_dst, src + s * ld_src, (size_t)cols * sizeof(float));
-            }
-        }
-        _mm_sfence();                             // the streamed rows are globally visible before this thread checks in
-    }
-    void loop()
-    {
-        uint64_t seen = 0;
-        for (;;) {
-            const double give_up = now() + 2e-3;
-            int spins = 0;
-            while (generation.load(std::memory_order_acquire) == seen && !stop.load()) {
-                relax();
-                if ((++spins & 1023) == 0 && now() > give_up) {
-                    std::unique_lock<std::mutex> l(m);
-                    sleepers.fetch_add(1);
-                    cv_work.wait(l, [&] { return stop.load() || generation.load(std::memory_order_acquire) != seen; });
-                    sleepers.fetch_sub(1);
-                }
-            }
-            if (stop.load()) return;
-            seen = generation.load(std::memory_order_acquire);
-            rows();
-            running.fetch_sub(1, std::memory_order_release);
-        }
-    }
-    // one gather at a time (the feeder's dispatcher, or mdbn_host_gather_rows's private pool)
-    bool gather(const float* src_, int64_t n_rows_, int64_t cols_, int64_t ld_src_, const int64_t* idx_, int64_t n_,
-                float* dst_, int64_t ld_dst_)
-    {
-        src = src_; n_rows = n_rows_; cols = cols_; ld_src = ld_src_; idx = idx_; n = n_; dst = dst_; ld_dst = ld_dst_;
-        next.store(0); bad.store(0);
-        running.store((int)workers.size());
-        {
-            std::lock_guard<std::mutex> l(m);     // a worker between its predicate and its wait holds this lock
-            generation.fetch_add(1, std::memory_order_release);
-        }
-        if (sleepers.load() > 0) cv_work.notify_all();
-        rows();                                   // the calling thread works too
-        int spins = 0;
-        while (running.load(std::memory_order_acquire) != 0) {      // every worker checks in: none still reads this job
-            relax();
-            if ((++spins & 4095) == 0) std::this_thread::yield();
-        }
-        return bad.load() == 0;
-    }
-};
-}  // namespace
+using mdbn_host::RowPool;
 
 struct mdbn_feeder {
     int device = 0;
@@ -2077,6 +1982,14 @@ int mdbn_feeder_acquire(mdbn_feeder* f, int64_t ticket, void* stream, int* slot)
         if (!f->ready.count(ticket) && (int)f->held.size() >= f->slots)
             return fail(MDBN_EINVAL, "row feeder: all %d slots are held; release one before acquiring ticket %lld", f->slots,
                         (long long)ticket);
+        // ... and with every slot taken by EARLIER tickets that only this caller can free (ready or about to be, or held),
+        // a ticket that has not been started yet never will be: refuse instead of blocking for ever (slots = 3, tickets
+        // 0..3 submitted, acquire(3))
+        if (!f->ready.count(ticket) && !f->inflight.count(ticket) &&
+            (int)(f->ready.size() + f->held.size() + f->inflight.size()) >= f->slots)
+            return fail(MDBN_EINVAL, "row feeder: ticket %lld cannot start while %d earlier tickets occupy all %d slots; "
+                        "acquire and release them first (tickets are served in submission order)", (long long)ticket,
+                        (int)(f->ready.size() + f->held.size() + f->inflight.size()), f->slots);
         const double t0 = mdbn_feeder::now();
         f->cv.wait(l, [&] { return f->ready.count(ticket) != 0 || f->stop; });
         f->t_acquire_wait += mdbn_feeder::now() - t0;

@@ -659,6 +659,9 @@ __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t 
 // guarded variant costs the whole-tile case 2.6% through register allocation).
 // PW = producer waves per operand (2: 8-wave block, 4: 12-wave block -- the producers' per-slice latency,
 // which the MFMA waves wait for at the barrier, halves).
+#ifndef X6_STAGE_ACC
+#define X6_STAGE_ACC 1
+#endif
 template <int LA, int LB, int FUSED, int AP = 3, bool RAGGED = false, int PW = 2>
 __global__ __launch_bounds__(64 * (4 + 2 * PW)) void gemm_bf16x6_kernel(GemmArgs g)
 {
@@ -741,20 +744,37 @@ __global__ __launch_bounds__(64 * (4 + 2 * PW)) void gemm_bf16x6_kernel(GemmArgs
             if (pl < AP) FA[pl][a] = *reinterpret_cast<const bf16x8*>((BASE) + pl * X6_PLANE + offA[a][SIDX]); \
             FB[pl][a] = *reinterpret_cast<const bf16x8*>((BASE) + pl * X6_PLANE + offB[a][SIDX]);  \
         }
+        // STAGE_ACC (propup layout: the long reductions over the visible units): the products of one 16-k step are chained
+        // into a step-local accumulator that starts at zero and the step's sum is added to the tile's accumulator by the
+        // VALU -- the tile's accumulator takes one rounding at its own magnitude per step instead of six (three); the
+        // same rule as gemm_planes_kernel (mdbn_planes.hip, PL_STAGE_ACC), so that its 32x32x16 form stays bit-identical.
+        constexpr bool STAGE_ACC = X6_STAGE_ACC && LA == LAY_K && LB == LAY_MN;
+#define X6_CHAIN(T, FA, FB, a, b)                                                                 \
+    do {                                                                                          \
+        if constexpr (AP == 3) {                    /* smallest products first */                 \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[2][a], FB[0][b], T, 0, 0, 0);          \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[2][b], T, 0, 0, 0);          \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][a], FB[1][b], T, 0, 0, 0);          \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][a], FB[0][b], T, 0, 0, 0);          \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[1][b], T, 0, 0, 0);          \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[0][b], T, 0, 0, 0);          \
+        } else {        /* A = a1 exactly: a1 b3 + a1 b2 + a1 b1 is the full product */           \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[2][b], T, 0, 0, 0);          \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[1][b], T, 0, 0, 0);          \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[0][b], T, 0, 0, 0);          \
+        }                                                                                         \
+    } while (0)
 #define X6_MMA(FA, FB)                                                                            \
     _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                 \
-        _Pragma("unroll") for (int b = 0; b < 2; ++b) {     /* smallest products first */         \
-            if constexpr (AP == 3) {                                                              \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[2][a], FB[0][b], acc[a][b], 0, 0, 0); \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[2][b], acc[a][b], 0, 0, 0); \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][a], FB[1][b], acc[a][b], 0, 0, 0); \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][a], FB[0][b], acc[a][b], 0, 0, 0); \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[1][b], acc[a][b], 0, 0, 0); \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[0][b], acc[a][b], 0, 0, 0); \
-            } else {        /* A = a1 exactly: a1 b3 + a1 b2 + a1 b1 is the full product */       \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[2][b], acc[a][b], 0, 0, 0); \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[1][b], acc[a][b], 0, 0, 0); \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[0][b], acc[a][b], 0, 0, 0); \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                           \
+            if constexpr (STAGE_ACC) {                                                            \
+                f32x16 t_;                                                                        \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) t_[e] = 0.f;                       \
+                X6_CHAIN(t_, FA, FB, a, b);                                                       \
+                acc[a][b] += t_;                                                                  \
+                __builtin_amdgcn_sched_barrier(0);  /* one step-local accumulator alive at a time (hipcc otherwise hoists all four chains and spills) */ \
+            } else {                                                                              \
+                X6_CHAIN(acc[a][b], FA, FB, a, b);                                                \
             }                                                                                     \
         }
         __syncthreads();                             // slice 0 staged
@@ -790,6 +810,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * PW)) void gemm_bf16x6_kernel(GemmArgs
         }
 #undef X6_FRAGS
 #undef X6_MMA
+#undef X6_CHAIN
         // accumulator (32x32): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
         if constexpr (FUSED != 0) {
             constexpr int LDT = BN + 8;
@@ -843,6 +864,10 @@ static hipError_t launch_bf16x6_p(const GemmArgs& g, hipStream_t s)
 template <int LA, int LB, int FUSED, int AP, bool RAGGED>
 static hipError_t launch_bf16x6_r(const GemmArgs& g, hipStream_t s)
 {
+    // the step-local accumulators of the propup layout (X6_STAGE_ACC) need 187 VGPRs with six products: that does not fit the
+    // 168-register budget of a 12-wave block, so those instantiations run with two producer waves per operand
+    if constexpr (X6_STAGE_ACC && LA == LAY_K && LB == LAY_MN && AP == 3) return launch_bf16x6_p<LA, LB, FUSED, AP, RAGGED, 2>(g, s);
+    else
     return g.x6_pw == 4 ? launch_bf16x6_p<LA, LB, FUSED, AP, RAGGED, 4>(g, s) : launch_bf16x6_p<LA, LB, FUSED, AP, RAGGED, 2>(g, s);
 }
 
@@ -1186,10 +1211,13 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
         for (int j = 0; j < CW; ++j) bias[j] = c0 + j < e.cols ? e.bias[c0 + j] : 0.f;
         float pre[4][CW];
         const float* base = e.slabs + (int64_t)r0 * e.ld + c0;
+        // the split-K partials are summed in float64 and rounded to float32 ONCE (a single slab passes through unchanged,
+        // so the one-slab form stays bitwise the fused epilogues); the bias is then added in float32 as everywhere else
+        double acc[4][CW];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int j = 0; j < CW; ++j) pre[r][j] = 0.f;
+            for (int j = 0; j < CW; ++j) acc[r][j] = 0.0;
         if (NS > 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1201,7 +1229,7 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
 #pragma unroll
                     for (int sidx = 0; sidx < NS; ++sidx)
 #pragma unroll
-                        for (int j = 0; j < CW; ++j) pre[r][j] += v[sidx][j];
+                        for (int j = 0; j < CW; ++j) acc[r][j] += (double)v[sidx][j];
                 }
             }
         } else {
@@ -1230,13 +1258,13 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
 #pragma unroll
                     for (int u = 0; u < SB; ++u)
 #pragma unroll
-                        for (int j = 0; j < CW; ++j) pre[r][j] += v[r][u][j];
+                        for (int j = 0; j < CW; ++j) acc[r][j] += (double)v[r][u][j];
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int j = 0; j < CW; ++j) pre[r][j] += bias[j];
+            for (int j = 0; j < CW; ++j) pre[r][j] = (float)acc[r][j] + bias[j];
         uint32_t wa[CW][4], wb[CW][4];       // [col][row]
         const bool need_u = MODE < 0 ? (e.sample != nullptr || e.sample_plane != nullptr) : (MODE & 1) != 0;
         const bool need_z = need_u && is_gauss;
@@ -1702,9 +1730,9 @@ __global__ __launch_bounds__(256) void free_energy_kernel(const float* __restric
     const int64_t r = blockIdx.x;
     double acc = 0.0;
     for (int j = threadIdx.x; j < H; j += blockDim.x) {
-        float a = hbias[j];
-        for (int s = 0; s < nsplit; ++s) a += slabs[(int64_t)s * slab_stride + r * ldh + j];
-        acc -= (double)softplusf_(a);
+        double a = (double)hbias[j];      // split-K partials summed in float64, rounded once
+        for (int s = 0; s < nsplit; ++s) a += (double)slabs[(int64_t)s * slab_stride + r * ldh + j];
+        acc -= (double)softplusf_((float)a);
     }
     for (int j = threadIdx.x; j < V; j += blockDim.x) {
         const float xv = x[r * ldv + j], b = vbias[j];

@@ -449,25 +449,68 @@ __device__ __forceinline__ void pl_offsets16(int lane, int wm, int wn, int (&off
     _Pragma("unroll") for (int pl = 0; pl < NB; ++pl)                                         \
         _Pragma("unroll") for (int i = 0; i < NBH; ++i)                                       \
             FB[pl][i] = pl_frag<LB>((BASE) + (3 + pl) * PL_PLANE, offB[NBH * (HALF) + i][0], offB[NBH * (HALF) + i][1]);
+// PL_STAGE_ACC = 1 (default): the products of one 32-deep stage are chained into a STAGE-LOCAL accumulator that starts at
+// zero (smallest products first), and the stage's sum is added to the tile's accumulator with one v_add_f32 per element.
+// A tile's accumulator then takes ONE rounding at its own (large) magnitude per stage instead of six (three): the chained
+// roundings happen at the magnitude of a 32-term partial sum.  At K = 4096 the probabilities' worst error against float64
+// drops from 2.2e-6 to ~1e-6 (SURVEY 8d asks 2e-6); measured cost: see DESIGN.md "Stage-local accumulators".
+#ifndef PL_STAGE_ACC
+#define PL_STAGE_ACC 1
+#endif
+// PL_STAGE_ACC = 1 (default): the products of one 32-deep stage are chained into a STAGE-LOCAL accumulator that starts at
+// zero (smallest products first), and the stage's sum is added to the tile's accumulator with one v_add_f32 per element.
+// A tile's accumulator then takes ONE rounding at its own (large) magnitude per stage instead of six (three): the chained
+// roundings happen at the magnitude of a 32-term partial sum.  At K = 4096 the probabilities' worst error against float64
+// drops from 2.2e-6 to ~1e-6 (SURVEY 8d asks 2e-6); measured cost: see DESIGN.md "Stage-local accumulators".
+#ifndef PL_STAGE_ACC
+#define PL_STAGE_ACC 1
+#endif
+#define MMQ_CHAIN(T, FA, FB, a, b, C0)                                                        \
+    do {                                                                                      \
+        T = (C0);                                                                             \
+        if constexpr (AP == 3) {              /* smallest products first */                   \
+            T = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[2][a], FB[0][b], T, 0, 0, 0);      \
+            T = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[2][b], T, 0, 0, 0);      \
+            T = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[1][a], FB[1][b], T, 0, 0, 0);      \
+            T = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[1][a], FB[0][b], T, 0, 0, 0);      \
+            T = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[1][b], T, 0, 0, 0);      \
+            T = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], T, 0, 0, 0);      \
+        } else if constexpr (AP == 1) {   /* A = a1 exactly: a1 b3 + a1 b2 + a1 b1 is the full product */ \
+            T = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[2][b], T, 0, 0, 0);      \
+            T = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[1][b], T, 0, 0, 0);      \
+            T = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], T, 0, 0, 0);      \
+        } else {        /* bf16 inputs: the leading pieces only */                            \
+            T = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], T, 0, 0, 0);      \
+        }                                                                                     \
+    } while (0)
+#if PL_STAGE_ACC
+// (propup layout only: LA == LAY_K && LB == LAY_MN)
+// tile i's stage sum is added while tile i + 1's chain occupies the matrix pipe (the add would otherwise wait for the
+// last MFMA of its own chain with nothing to issue)
+#define MMQ(FA, FB, AH, BH)                                                                   \
+    do {                                                                                      \
+        if constexpr (AP == 0 || !(LA == LAY_K && LB == LAY_MN)) {                            \
+            _Pragma("unroll") for (int a = 0; a < 2; ++a)                                     \
+                _Pragma("unroll") for (int b = 0; b < NBH; ++b) {                             \
+                    pf32x4a& c = acc[2 * (AH) + a][NBH * (BH) + b];                           \
+                    MMQ_CHAIN(c, FA, FB, a, b, c);                                            \
+                }                                                                             \
+        } else {                                                                              \
+            pf32x4a tq[2 * NBH];                                                              \
+            _Pragma("unroll") for (int i = 0; i <= 2 * NBH; ++i) {                            \
+                if (i < 2 * NBH) MMQ_CHAIN(tq[i], FA, FB, i / NBH, i % NBH, (pf32x4a{0.f, 0.f, 0.f, 0.f})); \
+                if (i > 0) acc[2 * (AH) + (i - 1) / NBH][NBH * (BH) + (i - 1) % NBH] += tq[i - 1]; \
+            }                                                                                 \
+        }                                                                                     \
+    } while (0)
+#else
 #define MMQ(FA, FB, AH, BH)                                                                   \
     _Pragma("unroll") for (int a = 0; a < 2; ++a)                                             \
-        _Pragma("unroll") for (int b = 0; b < NBH; ++b) {   /* smallest products first */     \
+        _Pragma("unroll") for (int b = 0; b < NBH; ++b) {                                     \
             pf32x4a& c = acc[2 * (AH) + a][NBH * (BH) + b];                                   \
-            if constexpr (AP == 3) {                                                          \
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[2][a], FB[0][b], c, 0, 0, 0);  \
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[2][b], c, 0, 0, 0);  \
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[1][a], FB[1][b], c, 0, 0, 0);  \
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[1][a], FB[0][b], c, 0, 0, 0);  \
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[1][b], c, 0, 0, 0);  \
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], c, 0, 0, 0);  \
-            } else if constexpr (AP == 1) {   /* A = a1 exactly: a1 b3 + a1 b2 + a1 b1 is the full product */ \
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[2][b], c, 0, 0, 0);  \
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[1][b], c, 0, 0, 0);  \
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], c, 0, 0, 0);  \
-            } else {        /* bf16 inputs: the leading pieces only */                        \
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[0][a], FB[0][b], c, 0, 0, 0);  \
-            }                                                                                 \
+            MMQ_CHAIN(c, FA, FB, a, b, c);                                                    \
         }
+#endif
 // issue order: the prefetched half's LDS reads one by one under this quarter's MFMAs
 #define ORD(NR)                                                                               \
     _Pragma("unroll") for (int i_ = 0; i_ < ((NR) < NM ? (NR) : NM); ++i_) {                  \
@@ -727,20 +770,32 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
             if (pl < AP) FA[pl][a] = pl_frag<LA>((BASE) + pl * PL_PLANE, offA[a][S][0], offA[a][S][1]); \
             FB[pl][a] = pl_frag<LB>((BASE) + (3 + pl) * PL_PLANE, offB[a][S][0], offB[a][S][1]); \
         }
+#define PL_CHAIN(T, FA, FB, a, b)                                                                \
+    do {                                                                                      \
+        if constexpr (AP == 3) {                /* smallest products first */                 \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[2][a], FB[0][b], T, 0, 0, 0);      \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[2][b], T, 0, 0, 0);      \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][a], FB[1][b], T, 0, 0, 0);      \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][a], FB[0][b], T, 0, 0, 0);      \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[1][b], T, 0, 0, 0);      \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[0][b], T, 0, 0, 0);      \
+        } else {        /* A = a1 exactly: a1 b3 + a1 b2 + a1 b1 is the full product */       \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[2][b], T, 0, 0, 0);      \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[1][b], T, 0, 0, 0);      \
+            T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[0][b], T, 0, 0, 0);      \
+        }                                                                                     \
+    } while (0)
+        // step-local accumulators on the propup layout, exactly as gemm_bf16x6_kernel (X6_STAGE_ACC): same bits
 #define PL_MMA(FA, FB)                                                                        \
     _Pragma("unroll") for (int a = 0; a < 2; ++a)                                             \
-        _Pragma("unroll") for (int b = 0; b < 2; ++b) {     /* smallest products first */     \
-            if constexpr (AP == 3) {                                                          \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[2][a], FB[0][b], acc[a][b], 0, 0, 0); \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[2][b], acc[a][b], 0, 0, 0); \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][a], FB[1][b], acc[a][b], 0, 0, 0); \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][a], FB[0][b], acc[a][b], 0, 0, 0); \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[1][b], acc[a][b], 0, 0, 0); \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[0][b], acc[a][b], 0, 0, 0); \
-            } else {        /* A = a1 exactly: a1 b3 + a1 b2 + a1 b1 is the full product */   \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[2][b], acc[a][b], 0, 0, 0); \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[1][b], acc[a][b], 0, 0, 0); \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][a], FB[0][b], acc[a][b], 0, 0, 0); \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                       \
+            if constexpr (PL_STAGE_ACC && LA == LAY_K && LB == LAY_MN) {                      \
+                pf32x16 t_;                                                                   \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) t_[e] = 0.f;                   \
+                PL_CHAIN(t_, FA, FB, a, b);                                                   \
+                acc[a][b] += t_;                                                              \
+            } else {                                                                          \
+                PL_CHAIN(acc[a][b], FA, FB, a, b);                                            \
             }                                                                                 \
         }
         // issue order: the NEXT step's fragment reads interleaved one by one under this step's MFMAs
@@ -778,6 +833,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
         }
 #undef PL_FRAGS
 #undef PL_MMA
+#undef PL_CHAIN
 #undef PL_ORDER
         // accumulator (32x32): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
         if constexpr (FUSED != 0) {
@@ -1326,6 +1382,7 @@ hipError_t launch_gemm_planes_bal(int la, int lb, const PlaneGemmArgs& g, hipStr
 #undef RD_A
 #undef RD_B
 #undef MMQ
+#undef MMQ_CHAIN
 #undef ORD
 #undef PIN
 #undef PL_STAGE_EVEN

@@ -18,6 +18,17 @@ class _StreamWork(object):
         torch.cuda.current_stream().wait_event(self.event)
 
 
+class _NoWork(object):
+    """Handle of a collective that was not issued (``Group.stub_collective``)."""
+    event = None
+
+    def wait(self):
+        pass
+
+    def is_completed(self):
+        return True
+
+
 class Group(object):
     """The ranks of one data-parallel job.  The collective is ``torch.distributed``'s all-reduce (backend nccl =
     RCCL) by default; with ``MDBN_DP_COLLECTIVE=capi`` (or ``native=True``) it is the library's own
@@ -31,6 +42,9 @@ class Group(object):
         self.native = (os.environ.get("MDBN_DP_COLLECTIVE") == "capi") if native is None else bool(native)
         self._comm_engine = None
         self._side = None
+        # MEASUREMENT ONLY (bench.py `distributed.exposed_comm_us`): True makes both all-reduce calls no-ops, so that the same
+        # step can be timed without its collective.  The statistics are then those of the local shard: results are wrong.
+        self.stub_collective = False
 
     def shard(self, n):
         """Contiguous rows [lo, hi) of an n-row minibatch owned by this rank."""
@@ -68,6 +82,8 @@ class Group(object):
             "torch.distributed all_reduce (%s)" % td.get_backend(self.pg)
 
     def all_reduce_sum(self, tensor, engine=None):
+        if self.stub_collective:
+            return tensor
         if self._native(engine):
             self._native_launch(tensor, engine, torch.cuda.current_stream(engine.device))
             return tensor
@@ -77,6 +93,8 @@ class Group(object):
     def all_reduce_sum_async(self, tensor, engine=None):
         """Start the sum all-reduce and return the work handle; ``handle.wait()`` makes the
         current stream (not the host, on RCCL) wait for the result."""
+        if self.stub_collective:
+            return _NoWork()
         if self._native(engine):
             cur = torch.cuda.current_stream(engine.device)
             self._side.wait_stream(cur)                    # the statistics are complete on the compute stream

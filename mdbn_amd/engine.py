@@ -510,8 +510,10 @@ class HipEngine(object):
         keep = [data, idx, ws]
         if sc.planes is not None and idx is not None and not self.keep_f32 and not self.trace_chain:
             # (the announcing step keeps the matrix and the index tensor alive, so an equal address is the same object)
+            # ... and unchanged: an index buffer refilled IN PLACE between the announcing call and this one has another
+            # version counter, and the rows are gathered afresh
             if ahead is not None and ahead[0].data_ptr() == data.data_ptr() and ahead[1] == data._version and \
-                    self._same_index_tensor(ahead[2], idx):
+                    self._same_index_tensor(ahead[2], idx) and ahead[4] == idx._version:
                 sc.x_buffer = ahead[3]
                 a.v0_ready = 1
             if sc.planes_alt is not None or next_indexes is not None:
@@ -524,7 +526,7 @@ class HipEngine(object):
                     self._ahead_flag = C.c_int32(0)
                     a.ahead_done = C.pointer(self._ahead_flag)
                     keep.append(nxt)
-                    sc._announce = (data, data._version, nxt, 1 - sc.x_buffer)
+                    sc._announce = (data, data._version, nxt, 1 - sc.x_buffer, nxt._version)
         if self.trace_chain:
             if sc.trace_h is None or sc.trace_h.shape[0] != k + 1:
                 sc.trace_h = torch.zeros((k + 1, B, ldh), dtype=torch.float32, device=self.device)

@@ -215,7 +215,8 @@ class StepFunction(object):
             fd = st["feeder"] = self.engine.row_feeder(table.host, table.cols, need)
         for key, h, n_global, lo, hi in shards:
             ticket = fd.submit(h) if hi > lo else None
-            st["queue"].append((key, ticket, n_global, lo, hi))
+            # (the version counter of an announced index TENSOR: a buffer refilled in place afterwards is not the announced list)
+            st["queue"].append((key, ticket, n_global, lo, hi, getattr(key, "_version", None)))
 
     def prefetch(self, indexes):
         """``announce([indexes])``: the next minibatch only."""
@@ -241,8 +242,8 @@ class StepFunction(object):
         if st["held"] is not None:                 # a step that raised before handing its rows back
             self._fed()
         if st["queue"]:
-            key, ticket, n_global, lo, hi = st["queue"][0]
-            if self._same_indexes(key, indexes):
+            key, ticket, n_global, lo, hi, key_version = st["queue"][0]
+            if self._same_indexes(key, indexes) and key_version == getattr(indexes, "_version", None):
                 st["queue"].popleft()
                 if ticket is None:
                     return eng.alloc_matrix(0, table.cols, table.host.stride(0)), n_global, lo, hi

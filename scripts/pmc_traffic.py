@@ -47,5 +47,12 @@ if steps:
     out["step_kernels"] = {k: {"launches_per_step": v["launches"] / steps, "bytes_per_step": v["total"] * v["launches"] / steps}
                            for k, v in out["per_launch_bytes"].items() if v["launches"] * 2 >= steps}
     out["step_bytes"] = sum(v["bytes_per_step"] for v in out["step_kernels"].values())
+try:        # which library was profiled (bench.py compares it with the one it times)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mdbn_amd import build
+    out["source_hash"] = build.source_hash()
+except Exception:
+    pass
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 def test_sizes_and_errors_without_gpu(built_lib):
     from mdbn_amd import _lib
     lib = _lib.load()
-    assert lib.mdbn_version() == 1
+    assert lib.mdbn_version() == 2
     n = C.c_int64()
     assert lib.mdbn_workspace_bytes(512, 4096, 1024, C.byref(n)) == 0 and n.value >= 8 * 512 * 1024 * 4
     assert lib.mdbn_stats_floats(4096, 4096, 1024, C.byref(n)) == 0
@@ -43,13 +43,52 @@ def test_sizes_and_errors_without_gpu(built_lib):
     assert "bad arguments" in _lib.last_error()
 
 
-def test_struct_layouts_match_header():
-    """ctypes mirrors of the by-pointer structs: field order/size as the header lays them out."""
+def test_struct_layouts_match_header(tmp_path):
+    """ctypes mirrors of the by-pointer structs against the header AS A C COMPILER LAYS IT OUT: gcc compiles
+    include/mdbn_hip.h (plain C) and prints sizeof / offsetof of every field; names, order, offsets and sizes must be
+    those of mdbn_amd._lib.  Both structs start with `struct_size` (MDBN_VERSION 2) and the binding fills it in."""
+    import shutil
+    import subprocess
     from mdbn_amd import _lib
     assert C.sizeof(_lib.Rng) == 32
-    assert _lib.CdArgs.rng.offset % 8 == 0 and _lib.CdArgs.trace_h.offset == _lib.CdArgs.rng.offset + 32
-    assert _lib.UpdateArgs.lr.offset == _lib.UpdateArgs.stats.offset + 8
-    assert _lib.UpdateArgs.cost_out.offset % 8 == 0
+    a, u = _lib.CdArgs(), _lib.UpdateArgs()
+    assert a.struct_size == C.sizeof(_lib.CdArgs) and u.struct_size == C.sizeof(_lib.UpdateArgs)
+    assert _lib.CdArgs._fields_[0][0] == "struct_size" and _lib.UpdateArgs._fields_[0][0] == "struct_size"
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    text = open(os.path.join(ROOT, "include", "mdbn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "mdbn_hip.h"', 'int main(void) {']
+    mirrors = {"mdbn_rng": _lib.Rng, "mdbn_cd_args": _lib.CdArgs, "mdbn_update_args": _lib.UpdateArgs}
+    for cname, mirror in mirrors.items():
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S).group(1)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = [n.strip().lstrip("*").strip() for n in decl.split(",")]
+            names[0] = re.split(r"[\s\*]+", names[0])[-1]
+            fields += names
+        assert fields == [f[0] for f in mirror._fields_], cname
+        prog.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in fields:
+            prog.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    prog.append("return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(prog))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call([gcc, "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    for line in subprocess.check_output([exe]).decode().split("\n"):
+        if not line:
+            continue
+        key, val = line.split()
+        if "." in key:
+            cname, f = key.split(".")
+            assert getattr(mirrors[cname], f).offset == int(val), key
+        else:
+            assert C.sizeof(mirrors[key]) == int(val), key
 
 
 def test_engine_fails_loudly_without_gpu(built_lib):

@@ -214,8 +214,14 @@ def test_balanced_launches_match_and_repeat(hip_engine, gauss, V, H, B, k, comm_
         scale = max(1e-3, np.abs(ref[key]).max())
         assert np.isfinite(runs[0][key]).all(), key
         # fp32 summation order only; widest measured 2.3e-5 (hb of the 1024 x 2048 layer, whose reference step runs
-        # propdown unsplit on 128 x 64 tiles while the balanced one sums per-segment slabs)
-        assert np.abs(runs[0][key] - ref[key]).max() <= 4e-5 * scale, key
+        # propdown unsplit on 128 x 64 tiles while the balanced one sums per-segment slabs).  These are FREE-RUNNING
+        # chains of up to 2.4 M Bernoulli draws per step: a draw whose uniform lies within the two launches' rounding
+        # difference of its probability falls the other way in one of them (about one step in four at the largest shape)
+        # and moves that row's whole chain -- a rank-2 change of S of relative size ~1 / B.  That case is told apart by
+        # its signature: the RMS deviation stays at the summation-order level while single entries move up to 1e-3.
+        dev = np.abs(runs[0][key] - ref[key])
+        assert dev.max() <= 4e-5 * scale or (np.sqrt((dev.astype(np.float64) ** 2).mean()) <= 4e-5 * scale and
+                                             dev.max() <= 1e-3 * scale), (key, dev.max(), scale)
     np.testing.assert_allclose(runs[0]["costs"], ref["costs"], rtol=1e-4)
     for other in runs[1:]:
         for key in runs[0]:
@@ -357,8 +363,9 @@ def test_early_parameter_half_is_bitwise_the_epilogue_update(hip_engine, gauss, 
 def test_gather_ahead_is_bitwise_the_gather_launch(built_lib, gauss, V, H, B):
     """fn(indexes=, next_indexes=): the statistics kernel's loader waves gather the next minibatch into the other X2-plane
     buffer, the next step starts without a gather launch.  A product-default engine, 10 steps: with the hint every step,
-    with a WRONG hint every third step (the step must then gather for itself), and without hints -- identical parameters,
-    speeds and costs bit for bit; and the hinted run really took the ahead path."""
+    with a WRONG hint every third step (the step must then gather for itself), and without hints -- with ONE index buffer
+    that the caller refills in place and announces as its own successor (the gathered rows are then stale and must be
+    dropped) -- identical parameters, speeds and costs bit for bit; and the hinted run really took the ahead path."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import mdbn_amd
@@ -366,7 +373,7 @@ def test_gather_ahead_is_bitwise_the_gather_launch(built_lib, gauss, V, H, B):
     eng.set_planes_min_work(1 << 30)
     try:
         runs, took = [], []
-        for mode in ("hint", "wrong", "none"):
+        for mode in ("hint", "wrong", "refill", "none"):
             rs = np.random.RandomState(11)
             N = 4 * B
             data = rs.normal(size=(N, V)).astype(np.float32) if gauss else (rs.uniform(size=(N, V)) < 0.3).astype(np.float32)
@@ -377,13 +384,22 @@ def test_gather_ahead_is_bitwise_the_gather_launch(built_lib, gauss, V, H, B):
             fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=eng), data_parallel=None)
             batches = [eng.index_tensor(rs.permutation(N)[:B]) for _ in range(11)]
             costs, ahead = [], 0
+            if mode == "refill":
+                # ONE index buffer refilled in place before every call: the rows gathered ahead belong to the
+                # buffer's previous contents and must not be used -- the version counter of the tensor tells
+                values, buf = batches, batches[0].clone()
             for t in range(10):
+                if mode == "refill":
+                    buf.copy_(values[t])
+                    costs.append(float(fn(indexes=buf, momentum=0.5, next_indexes=buf)))
+                    ahead += int(eng.last_scratch.ahead is not None)
+                    continue
                 nxt = None if mode == "none" else (batches[(t + 5) % 11] if (mode == "wrong" and t % 3 == 1) else batches[t + 1])
                 costs.append(float(fn(indexes=batches[t], momentum=0.5, next_indexes=nxt)))
                 ahead += int(eng.last_scratch.ahead is not None)
             took.append(ahead)
             runs.append(dict(costs=np.array(costs), W=rbm.W.get_value(), Ws=rbm.W_speed.get_value(), vb=rbm.vbias.get_value()))
-        assert took[0] == 10 and took[1] == 10 and took[2] == 0, took       # (a wrong hint is still gathered, just not used)
+        assert took[0] == 10 and took[1] == 10 and took[3] == 0, took       # (a wrong hint is still gathered, just not used)
         for other in runs[1:]:
             for key in runs[0]:
                 assert np.array_equal(runs[0][key], other[key]), key
