@@ -61,7 +61,7 @@ typedef struct mdbn_cd_args {
     int32_t      add_noise;   /* GRBM only: 1 = error_free False (rbm.py:652-658)                */
     int32_t      sample_stats;/* 1 = negative visible statistics from nv_SAMPLE, not nv_mean: the
                                * chain_end of compute_symbolic_grad (rbm.py:339-342,378-390)      */
-    int32_t      keep_f32;    /* plane path only: 1 = also store the float32 copies of ph_mean, -nh_mean (P2), nv_mean
+    int32_t      keep_f32;    /* plane path and one-launch path (LDS-resident layers): 1 = also store the float32 copies of ph_mean, -nh_mean (P2), nv_mean
                                * (rows B.. of V2) and the chain samples (hs, vs) that only an inspecting caller reads;
                                * 0 = planes only (the statistics are always written; V2 / P2 / hs / vs are then scratch without defined content).  The
                                * f32-operand path always writes them; trace_h / trace_v imply 1                      */

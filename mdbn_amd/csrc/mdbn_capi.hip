@@ -20,6 +20,7 @@
 #include <utility>
 #include <vector>
 #include "mdbn_kernels.h"
+#include "mdbn_small.h"
 
 using namespace mdbn;
 
@@ -207,6 +208,9 @@ bool prefer_skinny(int64_t M, int64_t N, int64_t K)
 static int g_opt_gemm_bf16x6 = 3;
 // mdbn_set_option("gemm_planes"): the CD step runs on pre-split bf16 planes (mdbn_planes.hip) when the caller
 // supplies the plane buffers and the shape is made of whole 128-row / 128-column tiles (default on)
+// mdbn_set_option("small_fused"): layers whose W fits one CU's LDS run the whole CD-k chain in ONE launch + a small finish
+// launch (mdbn_small.hip); 0 = the multi-launch path (register-streaming GEMMs, fused epilogues)
+static int g_opt_small_fused = 1;
 static int g_opt_gemm_planes = 1;
 // mdbn_set_option("planes_mfma"): MFMA shape of the plane GEMMs: 16 = v_mfma_f32_16x16x32_bf16 (default: the chip holds
 // a higher clock on it), 32 = v_mfma_f32_32x32x16_bf16 (the products and order of gemm_bf16x6_kernel: same bits as the
@@ -363,6 +367,8 @@ WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
         s.slab = std::max(s.slab, (kMaxBalBlocks / td + 2) * B * ldv);
         s.slab = std::max<int64_t>(s.slab, (int64_t)kMaxBalBlocks * 2 * 16384);
     }
+    if (small_shape_ok(B, V, H, 0) || small_shape_ok(B, V, H, 1))       // one S partial per workgroup of the one-launch step
+        s.slab = std::max<int64_t>(s.slab, (int64_t)small_blocks(B) * V * ldh);
     s.slab = std::max<int64_t>(s.slab, 4 * std::max(ldv, ldh) * 8);
     s.cost = std::max<int64_t>(256, (((B + 3) / 4) * std::max(ldv, ldh) + 63) / 64) + 64;   // worst case: one column per thread, 64-thread blocks
     // fused epilogues write one partial per block: 128 x 64 tiles, or 32-column strips (skinny)
@@ -1032,6 +1038,10 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
         g_opt_comm_cus = (int)value;
         return MDBN_OK;
     }
+    if (strcmp(name, "small_fused") == 0) {
+        g_opt_small_fused = value != 0;
+        return MDBN_OK;
+    }
     if (strcmp(name, "gemm_planes") == 0) {
         g_opt_gemm_planes = value != 0;
         return MDBN_OK;
@@ -1426,6 +1436,75 @@ static int check_update_args(const mdbn_update_args* a)
     return MDBN_OK;
 }
 
+// ---------------------------------------------------------------------------------- one-launch step (LDS-resident layers)
+static bool small_eligible(const mdbn_cd_args* a, const Workspace& ws)
+{
+    if (!g_opt_small_fused || g_opt_bf16_inputs) return false;
+    if (a->persistent || a->sample_stats || (a->gauss && a->add_noise)) return false;
+    if (!a->gauss && a->vs == nullptr) return false;
+    if (a->B > 65535 * 16 || !small_shape_ok(a->B, a->V, a->H, a->gauss)) return false;
+    const int nb = small_blocks(a->B);
+    return (int64_t)nb * a->V * a->ldh <= ws.slab_floats && nb <= ws.cost_floats && nb <= row_groups(a->B);
+}
+
+// mode 0: the whole step; 1: the chain + partials only (mdbn_cd_forward); 2: the finish launch (mdbn_cd_statistics).
+// upd: single-device step, the finish launch applies the update; else it stores [S | s_h | s_v | cost] into a->stats.
+static int cd_step_small(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const mdbn_update_args* upd, const Workspace& ws,
+                         int mode, const mdbn_update_args* defer)
+{
+    const int64_t B = a->B, V = a->V, H = a->H, ldv = a->ldv, ldh = a->ldh;
+    const int nb = small_blocks(B);
+    if (mode != 2) {
+        SmallCdArgs k{};
+        k.data = a->data; k.n_data = a->n_data; k.ld_data = ldv;
+        k.idx = a->indexes; k.idx64 = a->index_is_64;
+        k.B = (int)B; k.V = (int)V; k.H = (int)H; k.k = a->k; k.gauss = a->gauss;
+        k.keep = a->keep_f32 != 0 || a->trace_h || a->trace_v;     // inspection copies of v0 / nv / ph / -nh / samples (as the plane path)
+        k.ldv = ldv; k.ldh = ldh;
+        k.W = a->W; k.hbias = a->hbias; k.vbias = a->vbias;
+        k.rng = make_key(a->rng, 0u);
+        k.part_S = ws.slabs; k.posP = ws.colPpos; k.negP = ws.colPneg; k.partV = ws.colV; k.cost_partials = ws.cost_partials;
+        k.V2 = a->V2; k.P2 = a->P2; k.hs = a->hs; k.vs = a->vs;
+        k.trace_h = a->trace_h; k.trace_v = a->gauss ? nullptr : a->trace_v;
+        k.stamps = g_stamps;
+        HIP_OK(launch_small_cd(k, s));
+    }
+    if (mode == 1) {
+        ctx->pending_n_cost = nb; ctx->pending_stats = a->stats;
+        return MDBN_OK;
+    }
+    if (mode == 2) { ctx->pending_n_cost = -1; ctx->pending_stats = nullptr; }
+    // the previous step's deferred update (data-parallel order) is its own launch here, ahead of the finish launch
+    if (defer) HIP_OK(launch_update(*defer, s, nullptr, 1, 0, reinterpret_cast<unsigned short*>(defer->W_planes)));
+    float* s_h = a->stats + V * ldh;
+    float* s_v = s_h + ldh;
+    float* cost = s_v + ldv;
+    SmallFinArgs f{};
+    f.part = ws.slabs; f.nparts = nb; f.part_stride = V * ldh; f.n4 = V * ldh / 4;
+    f.S_out = a->stats;
+    BiasUpd bu;
+    // mdbn_set_option("fused_update", 0): the statistics are materialised and the update is its own launch (update_kernel)
+    const bool fuse_upd = upd && g_opt_fused_update;
+    if (fuse_upd) {
+        f.do_upd = 1;
+        f.upd.W = upd->W; f.upd.Ws = upd->W_speed; f.upd.W0 = upd->W0; f.upd.ld = ldh; f.upd.rows = (int)V;
+        f.upd.lr = upd->lr; f.upd.l1 = upd->lambda_1; f.upd.l2 = upd->lambda_2; f.upd.wc = upd->weightcost;
+        f.upd.mu = upd->momentum; f.upd.inv_bs = 1.0f / upd->batch_size;
+        f.upd.Wp = reinterpret_cast<unsigned short*>(upd->W_planes); f.upd.wp_stride = V * ldh;
+        bu.hb = upd->hbias; bu.hbs = upd->hbias_speed; bu.vb = upd->vbias; bu.vbs = upd->vbias_speed;
+        bu.H = H; bu.V = V; bu.lr = upd->lr; bu.mu = upd->momentum; bu.inv_rows = 1.0f / upd->n_rows;
+        bu.cost_scale = upd->cost_scale; bu.cost_out = upd->cost_out;
+    }
+    f.fin = make_fin_args(ws.colPpos, ws.colPneg, ws.colV, nb, ldh, ldv, ws.cost_partials, nb, s_h, s_v, cost, fuse_upd ? &bu : nullptr);
+    HIP_OK(launch_small_finish(f, s));
+    if (upd && !fuse_upd) {
+        mdbn_update_args u = *upd;
+        u.phase = 0;
+        HIP_OK(launch_update(u, s, nullptr, 1, 0, reinterpret_cast<unsigned short*>(u.W_planes)));
+    }
+    return MDBN_OK;
+}
+
 static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, const mdbn_update_args* upd, int mode = 0,
                         const mdbn_update_args* defer = nullptr)
 {
@@ -1471,6 +1550,7 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
         REQUIRE(defer->W == a->W && defer->ldh == ldh && defer->ldv == ldv && defer->V == V && defer->H == H,
                 "deferred update does not match the step's parameters");
     }
+    if (small_eligible(a, ws) && !(upd && g_opt_update_overlap)) return cd_step_small(ctx, s, a, upd, ws, mode, defer);
     if (planes_eligible(a) && !(upd && g_opt_update_overlap)) {
         const int rc = cd_step_planes(ctx, s, a, upd, ws, mode, defer);
         if (mode != 1) { ctx->pending_n_cost = -1; ctx->pending_stats = nullptr; }

@@ -12,7 +12,7 @@ Each build runs the c2 step under `rocprofv3 --kernel-trace --stats`; the propup
 import csv, glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out = os.path.join(ROOT, "gpurun_out"); os.makedirs(out, exist_ok=True)
-src = [os.path.join(ROOT, "mdbn_amd", "csrc", f) for f in ("mdbn_kernels.hip", "mdbn_planes.hip", "mdbn_capi.hip")]
+src = [os.path.join(ROOT, "mdbn_amd", "csrc", f) for f in ("mdbn_kernels.hip", "mdbn_planes.hip", "mdbn_small.hip", "mdbn_capi.hip")]
 
 if len(sys.argv) > 1 and sys.argv[1] == "--run":
     sys.path.insert(0, ROOT)
