@@ -69,6 +69,41 @@ __device__ __forceinline__ int64_t sm_src_row(const SmallCdArgs& a, int row)
 //
 // No operand masking anywhere: the pad columns of the 16-row buffers hold exact zeros (every writer keeps them so), W's
 // index is clamped into the matrix, and a column n >= N computes a copy of column N - 1 that `epi` discards.
+// The reduction loop of a pass: `rounds` rounds of two k-steps for TG tiles that share the A operand.  Two register sets
+// alternate, so the operands of round r + 1 (and r + 2) are in flight while the MFMAs of round r issue, and no copy ties a
+// round's MFMAs to the NEXT round's loads (hipcc's in-order lgkmcnt then waits only for the set it is about to use).  The
+// look-ahead past the last round re-reads the last round (valid addresses, values unused) instead of branching.
+template <int TG>
+__device__ __forceinline__ void sm_kloop(sf32x4 (&acc)[TG], lds_cf* ap0, lds_cf* const (&bp0)[TG], int b1off, int bround, int rounds)
+{
+    struct Frag { float a0, a1, b0[TG], b1[TG]; };
+    auto load = [&](Frag& f, int q) {
+        f.a0 = ap0[8 * q]; f.a1 = ap0[8 * q + 4];
+#pragma unroll
+        for (int j = 0; j < TG; ++j) { f.b0[j] = bp0[j][q * bround]; f.b1[j] = bp0[j][q * bround + b1off]; }
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a0, f.b0[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a1, f.b1[j], acc[j], 0, 0, 0);
+    };
+    if (rounds <= 0) return;
+    Frag f0, f1;
+    load(f0, 0);
+    for (int r = 0; r + 2 <= rounds; r += 2) {       // (scheduling barriers: hipcc otherwise sinks each load to its first use)
+        load(f1, r + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        load(f0, min(r + 2, rounds - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (rounds & 1) mma(f0);
+}
+
 template <int TG>
 __device__ __forceinline__ void sm_up_loop(lds_cf* A, int lda, lds_cf* Wl, int ldw, int K, int N, int tiles, int ks,
                                            lds_f* part, int pld, int wave, int lane)
@@ -90,32 +125,8 @@ __device__ __forceinline__ void sm_up_loop(lds_cf* A, int lda, lds_cf* Wl, int l
             const int n = min((grp * TG + j) * 16 + c16, N - 1);
             bp[j] = Wl + (4 * s0 + kq) * ldw + n;
         }
-        lds_cf* ap = A + c16 * lda + 4 * s0 + kq;
         const int rounds = (s1f - s0) >> 1;
-        float a0 = 0.f, a1 = 0.f, b0[TG], b1[TG];
-        if (rounds > 0) {
-            a0 = ap[0]; a1 = ap[4];
-#pragma unroll
-            for (int j = 0; j < TG; ++j) { b0[j] = bp[j][0]; b1[j] = bp[j][bstep]; }
-        }
-        for (int r = 0; r < rounds; ++r) {
-            float na0 = 0.f, na1 = 0.f, nb0[TG], nb1[TG];
-            ap += 8;
-#pragma unroll
-            for (int j = 0; j < TG; ++j) bp[j] += 2 * bstep;
-            if (r + 1 < rounds) {                        // the next round's operands, ahead of this round's MFMAs
-                na0 = ap[0]; na1 = ap[4];
-#pragma unroll
-                for (int j = 0; j < TG; ++j) { nb0[j] = bp[j][0]; nb1[j] = bp[j][bstep]; }
-            }
-#pragma unroll
-            for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[j], acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[j], acc[j], 0, 0, 0);
-            a0 = na0; a1 = na1;
-#pragma unroll
-            for (int j = 0; j < TG; ++j) { b0[j] = nb0[j]; b1[j] = nb1[j]; }
-        }
+        sm_kloop<TG>(acc, A + c16 * lda + 4 * s0 + kq, bp, bstep, 2 * bstep, rounds);
         for (int s = s0 + 2 * rounds; s < s1; ++s) {     // odd step, and the K tail (W index clamped; A's pad is zero)
             const int k = 4 * s + kq, kc = k < K ? k : K - 1;
             const float av = A[c16 * lda + k];
@@ -179,32 +190,8 @@ __device__ __forceinline__ void sm_down(lds_cf* A, int lda, lds_cf* Wl, int ldw,
             bp[j] = Wl + min(n, N - 1) * ldw + kq;
             fetched[j] = pre(4 * kq, n);
         }
-        lds_cf* ap = A + c16 * lda + kq;
         const int rounds = kfull >> 1;
-        float a0 = 0.f, a1 = 0.f, b0[TG], b1[TG];
-        if (rounds > 0) {
-            a0 = ap[0]; a1 = ap[4];
-#pragma unroll
-            for (int j = 0; j < TG; ++j) { b0[j] = bp[j][0]; b1[j] = bp[j][4]; }
-        }
-        for (int r = 0; r < rounds; ++r) {
-            float na0 = 0.f, na1 = 0.f, nb0[TG], nb1[TG];
-            ap += 8;
-#pragma unroll
-            for (int j = 0; j < TG; ++j) bp[j] += 8;
-            if (r + 1 < rounds) {
-                na0 = ap[0]; na1 = ap[4];
-#pragma unroll
-                for (int j = 0; j < TG; ++j) { nb0[j] = bp[j][0]; nb1[j] = bp[j][4]; }
-            }
-#pragma unroll
-            for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[j], acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[j], acc[j], 0, 0, 0);
-            a0 = na0; a1 = na1;
-#pragma unroll
-            for (int j = 0; j < TG; ++j) { b0[j] = nb0[j]; b1[j] = nb1[j]; }
-        }
+        sm_kloop<TG>(acc, A + c16 * lda + kq, bp, 4, 8, rounds);
         for (int s = 2 * rounds; s < ksteps; ++s) {
             const int k = 4 * s + kq, kc = k < K ? k : K - 1;
             const float av = A[c16 * lda + k];
@@ -458,6 +445,14 @@ __global__ __launch_bounds__(SM_NT) void small_cd_kernel(SmallCdArgs a)
 
     // ---- the first slab's source rows, then W (+ biases) and the slab's rows in ONE burst of loads; the column-sum partials
     //      start at zero.  W rows are float4-aligned in LDS (pitch ldw >= ldh; the pad columns of W are zero in memory)
+    {   // W first (the long burst), the small loads behind it: vector-memory loads return in order, so a short dependent
+        // load (index -> LDS) issued ahead of the burst would hold every W store back by its own latency
+        const int q4 = (int)(ldh >> 2);
+        for (int e = tid; e < V * q4; e += SM_NT) {
+            const int r = e / q4, c4 = e - r * q4;
+            *(lds_f4*)(c.Wl + r * L.ldw + 4 * c4) = *reinterpret_cast<const sf32x4*>(a.W + (int64_t)r * ldh + 4 * c4);
+        }
+    }
     if (tid < SM_ROWS) {
         const int row = (int)blockIdx.x * SM_ROWS + tid;
         srcl[tid] = row < B ? sm_src_row(a, row) : 0;
@@ -465,13 +460,6 @@ __global__ __launch_bounds__(SM_NT) void small_cd_kernel(SmallCdArgs a)
     for (int e = tid; e < L.Hp; e += SM_NT) c.hbl[e] = e < H ? a.hbias[e] : 0.f;
     for (int e = tid; e < L.Vp; e += SM_NT) { c.vbl[e] = e < V ? a.vbias[e] : 0.f; c.csV[e] = 0.f; }
     for (int e = tid; e < 4 * L.Hp; e += SM_NT) { c.csP[e] = 0.f; c.csN[e] = 0.f; }
-    {
-        const int q4 = (int)(ldh >> 2);
-        for (int e = tid; e < V * q4; e += SM_NT) {
-            const int r = e / q4, c4 = e - r * q4;
-            *(lds_f4*)(c.Wl + r * L.ldw + 4 * c4) = *reinterpret_cast<const sf32x4*>(a.W + (int64_t)r * ldh + 4 * c4);
-        }
-    }
     sf32x4 accS[SM_MAXS];
 #pragma unroll
     for (int u = 0; u < SM_MAXS; ++u) accS[u] = sf32x4{0.f, 0.f, 0.f, 0.f};
