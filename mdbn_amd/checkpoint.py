@@ -11,9 +11,13 @@ epoch are lost, so it cannot resume).  ``save_network(..., resume=True)`` adds
 (rbm.py:415) of every RBM layer; ``load_network`` restores them when present, and the next
 ``get_cost_updates`` of a restored layer reuses that W0 instead of snapshotting the resumed W.
 
-NOT saved (a resumed ``DBN.training`` starts these afresh): the index of the layer in training, the
-epoch and iteration counters, the early-stopping state (patience limit, best cost) and the state of
-the shuffle RNG.  Resume therefore continues a layer's step function exactly, not the trainer's loop."""
+Trainer-loop resume (round 4): while ``DBN.training(..., on_step=)`` runs, ``dbn.trainer_state`` holds where its loop
+stands -- layer index, epoch, next minibatch, the early-stopping state (patience limit, best cost), the state of the
+shuffle generator when the epoch's order was drawn, the records so far and the finished layers' histories.
+``save_network(..., resume=True)`` stores it as ``<name>_trainer``; ``load_network`` hands it back as
+``dbn.trainer_state`` and ``dbn.training(<same arguments>, resume=dbn.trainer_state)`` continues the interrupted run with
+the same minibatch order and validation points: parameters and histories equal the uninterrupted run's bit for bit
+(tests/test_plumbing.py, tests/test_gpu_parity.py)."""
 import numpy
 
 from .dbn import DBN
@@ -49,6 +53,10 @@ def save_network(output_file, networks, classes=None, holdout=0.0, repeats=1, co
         blob[name + '_params'] = numpy.array([{p.name: p.get_value()} for p in dbn.params], dtype=object)
         if resume:
             blob[name + '_resume'] = numpy.array(_resume_state(dbn), dtype=object)
+            if getattr(dbn, 'trainer_state', None) is not None:
+                holder = numpy.empty(1, dtype=object)          # (one pickled dict: lists of tuples, a RandomState tuple)
+                holder[0] = dbn.trainer_state
+                blob[name + '_trainer'] = holder
     numpy.savez(output_file, **blob)
 
 
@@ -80,6 +88,8 @@ def load_network(input_file, names=None, engine=None):
                 r._rng_step, r._n_updates, r.bit_i_idx = int(st['rng_step']), int(st['n_updates']), int(st['bit_i_idx'])
                 if st.get('W0') is not None:
                     r._resume_W0 = st['W0']
+        if name + '_trainer' in npz.files:
+            dbn.trainer_state = npz[name + '_trainer'][0]
         out[name] = dbn
     for key in ('classes', 'holdout', 'repeats'):
         if key in npz.files:

@@ -110,6 +110,7 @@ class DBN(object):
                             W=sigmoid_layer.W, hbias=sigmoid_layer.b, engine=self.engine)
             self.rbm_layers.append(rbm_layer)
         self._lower_cache = {}
+        self.trainer_state = None    # where DBN.training stands (set while it runs with on_step; see training())
 
     def _print(self, *a, **kw):
         if self.verbose:
@@ -190,9 +191,15 @@ class DBN(object):
 
     def training(self, train_set_x, batch_size, k, pretraining_epochs, pretrain_lr,
                  lambda_1=0.0, lambda_2=0.1, validation_set_x=None, monitor=False,
-                 graph_output=False):
+                 graph_output=False, resume=None, on_step=None):
         '''Greedy layer-wise pre-training (dbn.py:334-517).  Returns, per layer, the list of
-        (iteration, cost, free_energy_gap) records taken at the validation points.'''
+        (iteration, cost, free_energy_gap) records taken at the validation points.
+
+        Added (the reference cannot resume, AMLsm2.py:112-205 saves W and b only): after every step ``self.trainer_state``
+        describes where the loop stands -- layer, epoch, next minibatch, early-stopping state, the shuffle generator's state
+        at the start of the epoch, the records so far -- and ``on_step(self)`` is called (e.g. to write a checkpoint:
+        ``checkpoint.save_network(..., resume=True)`` stores the trainer state with the layers' own).  ``resume=state``
+        continues such a run: same minibatch order, same validation points, same parameters bit for bit.'''
         data = shared(train_set_x, engine=self.engine)
         held_out = None if validation_set_x is None else shared(validation_set_x, engine=self.engine)
         self._print('... getting the pretraining functions')
@@ -203,33 +210,67 @@ class DBN(object):
                                                        lambda_1=lambda_1, lambda_2=lambda_2, monitor=monitor)
         self._print('... pre-training the model')
         t_start = timeit.default_timer()
-        # the batch count is fixed once, from a first split that is otherwise unused (dbn.py:404-406)
-        n_batches = len(get_minibatches_idx(data.shape[0], batch_size, shuffle=True, rng=self.shuffle_rng)[1])
-        history = [self._pretrain_layer(i, step_fns[i], energy_fns[i], data, held_out, batch_size, n_batches,
-                                        pretraining_epochs[i], pretrain_lr[i])
-                   for i in range(self.n_layers)]
+        if resume is None:
+            # the batch count is fixed once, from a first split that is otherwise unused (dbn.py:404-406)
+            n_batches = len(get_minibatches_idx(data.shape[0], batch_size, shuffle=True, rng=self.shuffle_rng)[1])
+            history, first = [], 0
+        else:
+            n_batches, first = int(resume['n_batches']), int(resume['layer'])
+            history = [[tuple(r) for r in h] for h in resume['history']]
+            if resume.get('epoch') is None:                  # interrupted between two layers
+                self._set_shuffle_state(resume['shuffle_state'])
+        for i in range(first, self.n_layers):
+            at = resume if (resume is not None and i == first and resume.get('epoch') is not None) else None
+            history.append(self._pretrain_layer(i, step_fns[i], energy_fns[i], data, held_out, batch_size, n_batches,
+                                                pretraining_epochs[i], pretrain_lr[i], history, at, on_step))
+        self.trainer_state = None
         if self.verbose:
             print('The pretraining ran for %.2fm' % ((timeit.default_timer() - t_start) / 60.), file=sys.stderr)
         return history
 
-    def _pretrain_layer(self, i, step_fn, energy_fn, data, held_out, batch_size, n_batches, epoch_budget, lr):
+    def _shuffle_state(self):
+        return self.shuffle_rng.get_state() if self.shuffle_rng is not None else numpy.random.get_state()
+
+    def _set_shuffle_state(self, state):
+        if self.shuffle_rng is not None:
+            self.shuffle_rng.set_state(state)
+        else:
+            numpy.random.set_state(state)
+
+    def _pretrain_layer(self, i, step_fn, energy_fn, data, held_out, batch_size, n_batches, epoch_budget, lr,
+                        history=(), at=None, on_step=None):
         """One layer of dbn.py:426-508: epochs of reshuffled minibatches under the layer's momentum
-        schedule until the epoch budget or the early-stopping state (``_Patience``) ends it."""
+        schedule until the epoch budget or the early-stopping state (``_Patience``) ends it.  ``at``: the trainer
+        state of an interrupted run of THIS layer (epoch, next minibatch, patience, records, shuffle state)."""
         bernoulli = not isinstance(self.rbm_layers[i], GRBM)
         stop = _Patience(epoch_budget, n_batches)
         self._print('Validation frequency: %d' % stop.every)
         hinted = getattr(step_fn, "accepts_next_indexes", False)     # step functions are duck-typed: fn(indexes=, momentum=, lr=)
         records = []
-        for epoch in range(1, epoch_budget + 1):
+        first_epoch, first_mb = 1, 0
+        if at is not None:
+            first_epoch, first_mb = int(at['epoch']), int(at['next_mb'])
+            stop.limit, stop.best = at['patience']
+            records = [tuple(r) for r in at['records']]
+            self._set_shuffle_state(at['shuffle_state'])              # ... as it was when this epoch's order was drawn
+
+        def state(epoch, next_mb, shuffle_state, layer=i, recs=None):
+            self.trainer_state = {'layer': layer, 'epoch': epoch, 'next_mb': next_mb, 'n_batches': n_batches,
+                                  'patience': (stop.limit, stop.best), 'shuffle_state': shuffle_state,
+                                  'records': list(records if recs is None else recs), 'history': [list(h) for h in history]}
+
+        for epoch in range(first_epoch, epoch_budget + 1):
             # Gaussian layer: no momentum at all; Bernoulli layers 0.6, 0.9 from the sixth epoch (dbn.py:430-433,452-453)
             momentum = 0.0 if not bernoulli else (0.6 if epoch < 6 else 0.9)
+            drawn_from = self._shuffle_state()
             batches = get_minibatches_idx(data.shape[0], batch_size, shuffle=True, rng=self.shuffle_rng)[1]
             order = self.engine.index_tensor(numpy.concatenate(batches))
             bounds = numpy.cumsum([0] + [len(b) for b in batches])
             views = [order[bounds[mb]:bounds[mb + 1]] for mb in range(len(batches))]
+            start = first_mb if epoch == first_epoch else 0
             if hasattr(step_fn, "announce"):            # the epoch's order (a host-resident table starts feeding its rows)
-                step_fn.announce(views, host_indexes=batches)
-            for mb in range(len(batches)):
+                step_fn.announce(views[start:], host_indexes=batches[start:])
+            for mb in range(start, len(batches)):
                 hint = {}
                 if hinted and mb + 1 < len(batches):    # the next minibatch of the epoch (a pure hint: StepFunction.__call__)
                     hint["next_indexes"] = views[mb + 1]
@@ -245,7 +286,19 @@ class DBN(object):
                         self._print('Free energy gap (layer %i, epoch %i): ' % (i, epoch), end=' ')
                         self._print(gap)
                     records.append((it, cost, gap))
-                if stop.exhausted(it):
+                done = stop.exhausted(it)
+                if on_step is not None or done:
+                    if done or (epoch == epoch_budget and mb + 1 == len(batches)):
+                        # the layer is finished: the state points at the start of the next one
+                        self.trainer_state = {'layer': i + 1, 'epoch': None, 'next_mb': 0, 'n_batches': n_batches,
+                                              'patience': None, 'shuffle_state': self._shuffle_state(), 'records': [],
+                                              'history': [list(h) for h in history] + [list(records)]}
+                    else:
+                        state(epoch, mb + 1, drawn_from)
+                    if on_step is not None:
+                        step_fn.flush()                 # (an overlapped data-parallel step: its deferred half belongs to this state)
+                        on_step(self)
+                if done:
                     break
             else:
                 continue

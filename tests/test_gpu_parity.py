@@ -922,3 +922,11 @@ def test_bf16x6_ragged_shapes_match_exact_kernel(hip_engine):
             base_a = a._base if a._base is not None else a
             if base_a.shape[1] > a.shape[1]:
                 assert float(base_a[:, a.shape[1]:].abs().max()) == 0.0, "pad columns must stay zero"
+
+
+def test_trainer_loop_resume_is_exact_on_device(hip_engine, tmp_path):
+    """f2 "epoch": DBN.training interrupted after a mid-epoch step of its second layer, written with
+    save_network(resume=True), reloaded into a fresh DBN and resumed -- records, parameters, update and RNG counters equal the
+    uninterrupted run's bit for bit (the device state is float32, as the checkpoint)."""
+    from test_plumbing import _interrupted_vs_straight
+    _interrupted_vs_straight(hip_engine, tmp_path, exact=True)

@@ -260,3 +260,63 @@ def test_host_row_gather_threads(built_lib):
     assert lib.mdbn_host_gather_rows(C.c_void_p(table.ctypes.data), N, cols, ld, C.c_void_p(bad.ctypes.data), 3,
                                      C.c_void_p(out.ctypes.data), ld_out, 2) == -1
     assert "out of range" in _lib.last_error()
+
+
+def _interrupted_vs_straight(engine, tmp_path, exact):
+    """DBN.training interrupted after a mid-epoch step of the SECOND layer, checkpointed, reloaded and resumed, against the
+    same training run straight through (f2: AMLsm2.py:112-205 cannot resume at all; dbn.py:426-508 is the loop)."""
+    DBN.verbose = False
+    rs = np.random.RandomState(11)
+    train = rs.normal(size=(70, 12)).astype(np.float32)
+    val = rs.normal(size=(9, 12)).astype(np.float32)
+    args = dict(batch_size=16, k=1, pretraining_epochs=[14, 14], pretrain_lr=[0.004, 0.05], lambda_2=0.1, validation_set_x=val)
+
+    def fresh():
+        d = DBN(numpy_rng=np.random.RandomState(5), n_ins=12, hidden_layers_sizes=[7], n_outs=4, engine=engine)
+        d.shuffle_rng = np.random.RandomState(17)
+        return d
+
+    straight = fresh()
+    want = straight.training(train, **args)
+
+    class Interrupt(Exception):
+        pass
+
+    path = str(tmp_path / "mid.npz")
+    seen = []
+
+    def on_step(d):
+        seen.append((d.trainer_state['layer'], d.trainer_state['epoch'], d.trainer_state['next_mb']))
+        if d.trainer_state['layer'] == 1 and d.trainer_state['epoch'] == 2 and d.trainer_state['next_mb'] == 3:
+            checkpoint.save_network(path, {'ge': d}, resume=True)
+            raise Interrupt()
+
+    first = fresh()
+    with pytest.raises(Interrupt):
+        first.training(train, on_step=on_step, **args)
+    assert seen[0] == (0, 1, 1) and (1, None, 0) in seen           # every step reported; the layer boundary too
+    second = checkpoint.load_network(path, engine=engine)['ge']
+    second.shuffle_rng = np.random.RandomState(999)                # (its state comes from the checkpoint, not from here)
+    state = second.trainer_state
+    assert (state['layer'], state['epoch'], state['next_mb']) == (1, 2, 3)
+    got = second.training(train, resume=state, **args)
+    assert second.trainer_state is None
+    if exact:
+        assert got == want
+    else:
+        assert [[r[0] for r in h] for h in got] == [[r[0] for r in h] for h in want]
+        for hg, hw in zip(got, want):
+            np.testing.assert_allclose([r[1] for r in hg], [r[1] for r in hw], rtol=1e-5)
+    for a, b in zip(second.params, straight.params):
+        if exact:
+            assert np.array_equal(a.get_value(), b.get_value()), a.name
+        else:
+            np.testing.assert_allclose(a.get_value(), b.get_value(), rtol=1e-5, atol=1e-7)
+    for ra, rb in zip(second.rbm_layers, straight.rbm_layers):
+        assert ra._n_updates == rb._n_updates and ra._rng_step == rb._rng_step
+    return got
+
+
+def test_trainer_loop_resume_on_the_checker_engine(tmp_path, oracle_engine):
+    # (the CPU checker computes in float64 while a checkpoint holds float32: equal to rounding; exact on the HIP engine)
+    _interrupted_vs_straight(oracle_engine, tmp_path, exact=False)
