@@ -29,6 +29,18 @@ def source_hash():
     return h.hexdigest()
 
 
+def audit_verdicts():
+    """The ISA-audit verdicts of the objects the current library was linked from ({source: report})."""
+    import glob
+    import json
+    out = {}
+    for path in glob.glob(os.path.join(CSRC, ".obj", "*.audit.json")):
+        with open(path) as fh:
+            r = json.load(fh)
+        out[r.get("source", os.path.basename(path))] = r
+    return out
+
+
 def built_hash(path=LIB):
     """The source hash compiled into an existing library, or None."""
     # Read from the file's bytes, never through dlopen: glibc keys loaded objects by name, so a handle opened
@@ -82,12 +94,41 @@ def build_lib(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             jobs.append((subprocess.Popen(cmd, cwd=CSRC), obj))
+    # ISA audit of the sources that hide loads from hipcc (inline-asm global_load + hand-counted waits, isa_audit.py): the
+    # assembly hipcc makes of them HERE, with these flags, is proven free of premature uses of a load's destination; a
+    # finding fails the build.  The verdict is cached beside the object (same content hash) with the compiler's version.
+    import json
+    from . import isa_audit
+    audits = []
+    for src, obj in zip(srcs, objs):
+        path = os.path.join(CSRC, src)
+        verdict = obj[:-2] + ".audit.json"
+        if isa_audit.needs_audit(path) and (force or not os.path.exists(verdict)):
+            asm = obj[:-2] + ".audit.tmp%d.s" % os.getpid()
+            cmd = [hipcc] + [f for f in cflags if f != "-fPIC"] + ["-S", "--cuda-device-only", "-o", asm, src]
+            audits.append((subprocess.Popen(cmd, cwd=CSRC, stderr=subprocess.DEVNULL), src, asm, verdict))
     for proc, obj in jobs:
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, "hipcc -c (%s)" % os.path.basename(obj))
         os.replace(obj + ".tmp%d" % os.getpid(), obj)
-    for old in os.listdir(objdir):          # drop objects of superseded sources
-        if os.path.join(objdir, old) not in objs and old.endswith(".o"):
+    for proc, src, asm, verdict in audits:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, "hipcc -S for the ISA audit (%s)" % src)
+        with open(asm) as fh:
+            report = isa_audit.audit_assembly(fh.read())
+        os.remove(asm)
+        report["source"], report["hipcc"] = src, isa_audit.hipcc_version(hipcc)
+        if report["findings"] or not report["loads"]:
+            raise RuntimeError("ISA audit of %s failed with %s (%d asm loads in %d kernels):\n  %s" % (
+                src, report["hipcc"], report["loads"], len(report["kernels"]),
+                "\n  ".join(report["findings"][:20]) or "no asm load found although the source has some"))
+        with open(verdict, "w") as fh:
+            json.dump(report, fh, indent=1)
+        if verbose:
+            print("ISA audit of %s: %d asm loads in %d kernels, no finding (%s)" % (src, report["loads"], len(report["kernels"]), report["hipcc"]))
+    keep = set(objs) | set(o[:-2] + ".audit.json" for o in objs)
+    for old in os.listdir(objdir):          # drop objects (and audit verdicts) of superseded sources
+        if os.path.join(objdir, old) not in keep and (old.endswith(".o") or old.endswith(".audit.json")):
             os.remove(os.path.join(objdir, old))
     tmp = LIB + ".tmp%d" % os.getpid()
     cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + objs + ["-ldl"]

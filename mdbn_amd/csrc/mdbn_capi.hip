@@ -780,7 +780,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
         if (g.upd.early && g_opt_gather_ahead && a->next_indexes && Xother && !keep) {
             const int nwg = g.tiles_m * g.tiles_n, nt = (int)(2 * B / 32);
             const int rpw = (int)((B + nwg - 1) / nwg), passes = (int)((ldv / 8 + 255) / 256);
-            if (rpw * passes <= 4 && 16 / (nt >= 20 ? 1 : 2) + rpw * passes + 1 <= nt - 3) {      // (the kernel unrolls <= 4 units)
+            if (rpw * passes <= 4 && 16 / (nt >= 20 ? 1 : 2) + 4 + 1 <= nt - 3) {      // (the kernel runs four unit slots, always)
                 g.ga.src = a->data; g.ga.n_rows = a->n_data; g.ga.ld_src = ldv;
                 g.ga.idx = a->next_indexes; g.ga.idx64 = a->index_is_64;
                 g.ga.B = (int)B; g.ga.rpw = rpw; g.ga.passes = passes;

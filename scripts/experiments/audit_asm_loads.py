@@ -1,63 +1,23 @@
 #!/usr/bin/env python
-"""ISA audit of the inline-asm loads in the statistics kernel's loader waves (mdbn_planes.hip, EARLYW): between an asm
-`global_load_dwordx4` and the counted wait that covers it, hipcc must neither read nor write the destination registers
-(it believes they are written when the statement ends).  Compiles mdbn_planes.hip to assembly and scans the kernel.
+"""ISA audit of the inline-asm loads (mdbn_amd/isa_audit.py) as a command: compiles every kernel source that hides loads
+from hipcc to gfx950 assembly with the build's flags and proves, by a dataflow over each kernel's control-flow graph, that
+no instruction names a load's destination register before a wait retires the load on every path.  The build runs the same
+audit (mdbn_amd/build.py); this prints the report.
     python scripts/experiments/audit_asm_loads.py          (exit status 1 if anything is found)"""
-import os, re, subprocess, sys, tempfile
+import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-src = os.path.join(ROOT, "mdbn_amd", "csrc", "mdbn_planes.hip")
-out = os.path.join(tempfile.gettempdir(), "mdbn_planes_audit.s")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
-                      cwd=os.path.dirname(src), stderr=subprocess.DEVNULL)
-text = open(out).read()
-kerns = ["_ZN4mdbn18gemm_planes_kernelILi1ELi1ELi3ELi2ELi16ELi128EEEvNS_13PlaneGemmArgsE",      # statistics + fused update
-         "_ZN4mdbn18gemm_planes_kernelILi1ELi1ELi3ELi0ELi16ELi128EEEvNS_13PlaneGemmArgsE",      # statistics, data-parallel (deferred update)
-         "_ZN4mdbn22gemm_planes_bal_kernelILi1ELi1ELi3ELi1EEEvNS_13PlaneGemmArgsE"]             # the same on balanced launches
-body = ""
-for kern in kerns:
-    part = text[text.index("\n" + kern + ":"):]
-    body += part[:part.index(".end_amdhsa_kernel")] + "\n;;#ASMSTART\ns_waitcnt vmcnt(0)\n;;#ASMEND\n;;#ASMSTART\ns_waitcnt vmcnt(0)\n;;#ASMEND\n"
-
-
-def regs(tok):
-    tok = tok.strip(",")
-    m = re.match(r"v\[(\d+):(\d+)\]", tok)
-    if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.match(r"v(\d+)$", tok)
-    return {int(m.group(1))} if m else set()
-
-
-inasm, pend, bad, nloads = False, [], [], 0
-for i, line in enumerate(body.split("\n")):
-    t = line.strip()
-    if t.startswith(";;#ASMSTART"):
-        inasm = True; continue
-    if t.startswith(";;#ASMEND"):
-        inasm = False; continue
-    if not t or t[0] in ";.":
+sys.path.insert(0, ROOT)
+from mdbn_amd import build, isa_audit
+bad = 0
+for src in build.SOURCES:
+    path = os.path.join(build.CSRC, src)
+    if not isa_audit.needs_audit(path):
         continue
-    parts = re.split(r"[ ,]+", t)
-    if inasm and parts[0] == "global_load_dwordx4":
-        pend.append([i, regs(parts[1]), 0]); nloads += 1; continue
-    if inasm and parts[0] == "s_waitcnt":
-        # an item's loads survive the ring wait of the next stage (vmcnt(12)) and are covered by the next item wait; the
-        # last item of a phase is covered by a vmcnt(12) item wait: count ring waits as 1, item waits as 2, retire at 3
-        m = re.search(r"vmcnt\((\d+)\)", t)
-        if m is None:                       # an lgkmcnt-only wait (LDS reads of the MFMA waves): no VMEM retires
-            continue
-        n = int(m.group(1))
-        for p in pend:
-            p[2] += 1 if n == 12 else 2
-        pend = [p for p in pend if p[2] < 3]
-        continue
-    touched = set()
-    for tok in parts[1:]:
-        touched |= regs(tok)
-    for p in pend:
-        if touched & p[1]:
-            bad.append((i + 1, t[:80], p[0] + 1))
-print("%d asm loads; %d touches of a pending destination register" % (nloads, len(bad)))
-for b in bad[:40]:
-    print("  line %d: %s   (load at line %d)" % b)
+    r = isa_audit.audit_source(path, build.HIPCC_FLAGS)
+    print("%s: %d asm loads in %d kernels; %d findings   [%s]" % (src, r["loads"], len(r["kernels"]), len(r["findings"]), r["hipcc"]))
+    for k, n in sorted(r["kernels"].items()):
+        print("   %4d  %s" % (n, k))
+    for f in r["findings"][:40]:
+        print("  !!", f)
+    bad += len(r["findings"]) + (0 if r["loads"] else 1)
 sys.exit(1 if bad else 0)

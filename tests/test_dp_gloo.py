@@ -105,20 +105,23 @@ def run_mdbn(group_mode):
     return {"p%d" % i: w for i, w in enumerate(Ws)} | {"out": top.get_output(joint)}
 
 
-def run_modalities(group_mode):
+def run_modalities(group_mode, engine=None, rows=24, batch=8, widths=((16, [5], 3), (20, [8, 4], 1), (10, [6, 3], 1))):
     """configs[4]'s three modalities placed MODALITY-PARALLEL (MDBN.train_modalities): rank i % N trains modality i alone,
-    parameters are broadcast once, the joint layer follows on the concatenated outputs."""
+    parameters are broadcast once, the joint layer follows on the concatenated outputs.  ``engine``: the CPU checker by
+    default; tests/test_gpu_dp.py passes a HipEngine (device tensors through the same broadcasts)."""
     import mdbn_amd
     from mdbn_amd import MDBN
-    from _oracle_engine import OracleEngine
-    mdbn_amd.set_engine(OracleEngine())
+    if engine is None:
+        from _oracle_engine import OracleEngine
+        engine = OracleEngine()
+    mdbn_amd.set_engine(engine)
     mdbn_amd.DBN.verbose = False
     rs = np.random.RandomState(0)
     rng = np.random.RandomState(123)
     specs = []
-    for width, sizes, k in ((16, [5], 3), (20, [8, 4], 1), (10, [6, 3], 1)):
-        x = rs.normal(size=(24, width))
-        specs.append(dict(train_set=x, validation_set=x[:6], batch_size=8, k=k, layers_sizes=sizes,
+    for width, sizes, k in widths:
+        x = rs.normal(size=(rows, width)).astype(np.float32)
+        specs.append(dict(train_set=x, validation_set=x[:6], batch_size=batch, k=k, layers_sizes=sizes,
                           pretraining_epochs=[4] * len(sizes), pretrain_lr=[0.005] + [0.1] * (len(sizes) - 1),
                           lambda_1=0.01, lambda_2=0.1))
     trained = MDBN.train_modalities(specs, rng, group="auto" if group_mode else None, shuffle_seed=0)
@@ -134,7 +137,7 @@ def run_modalities(group_mode):
     joint = np.concatenate([t[1] for t in trained], axis=1)
     top = mdbn_amd.DBN(numpy_rng=rng, n_ins=joint.shape[1], gauss=False, hidden_layers_sizes=[6], n_outs=3)
     top.shuffle_rng = np.random.RandomState(99)
-    top.training(mdbn_amd.shared(joint), batch_size=8, k=1, pretraining_epochs=[3, 3], pretrain_lr=[0.1, 0.1])
+    top.training(mdbn_amd.shared(joint), batch_size=batch, k=1, pretraining_epochs=[3, 3], pretrain_lr=[0.1, 0.1])
     for i, p in enumerate(top.params):
         out["top_p%d" % i] = p.get_value()
     out["classes"] = top.get_output(joint)

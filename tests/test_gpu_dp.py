@@ -233,3 +233,46 @@ def test_channel_capped_rccl_communicator(built_lib):
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(capped_worker, args=(1, free_port(), d), nprocs=1, join=True)
         assert bool(np.load(os.path.join(d, "ok.npy"))[0])
+
+
+# ---------------------------------------------------------------------------------- modality-parallel placement on the device
+MODALITY_SHAPES = dict(rows=96, batch=32, widths=((512, [40], 2), (260, [64, 24], 1), (128, [48, 12], 1)))
+
+
+def modality_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", MDBN_COMM_CUS="0")
+    import mdbn_amd
+    from mdbn_amd import dist
+    from test_dp_gloo import run_modalities
+    dist.init_from_env(backend="gloo")
+    out = run_modalities(True, engine=mdbn_amd.HipEngine(), **MODALITY_SHAPES)
+    np.savez(os.path.join(outdir, "mod%d.npz" % rank), **out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_modality_parallel_placement_on_device(built_lib):
+    """MDBN.train_modalities (SURVEY 8e's second placement of configs[4]) with the HIP engine under two ranks: rank 0 trains
+    modalities 0 and 2, rank 1 modality 1, each alone on the device; the broadcasts move the PADDED device storages and the
+    host counters, W's bf16 planes are invalidated by the version bump.  Every modality's parameters, speeds, counters and
+    outputs equal the sequential single-process run BIT FOR BIT on both ranks; the joint layer (row-sharded over the ranks
+    again) agrees to summation order."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, HERE)
+    import mdbn_amd
+    from test_dp_gloo import run_modalities
+    single = run_modalities(False, engine=mdbn_amd.HipEngine(), **MODALITY_SHAPES)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(modality_worker, args=(2, free_port(), d), nprocs=2, join=True)
+        r0, r1 = [dict(np.load(os.path.join(d, "mod%d.npz" % k))) for k in range(2)]
+    for k in single:
+        assert np.array_equal(r0[k], r1[k]), "replicas differ: " + k
+        if k.startswith("m"):
+            assert np.array_equal(r0[k], single[k]), k
+        else:
+            scale = max(1.0, np.abs(single[k]).max())
+            assert np.abs(r0[k] - single[k]).max() <= 5e-5 * scale, k

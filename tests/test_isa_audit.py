@@ -1,8 +1,9 @@
-"""The statistics kernels' loader waves hide their side work behind inline-asm loads that hipcc does not count
-(csrc/mdbn_planes.hip, EARLYW): between such a load and the counted wait that covers it, no instruction may read or
-write its destination registers -- hipcc believes they are written when the asm statement ends, and a copy or a reuse in
-between is silent corruption (the first version of the gather-ahead faulted exactly so).  This test compiles the file to
-assembly and runs the audit; it needs hipcc, not a GPU."""
+"""The loader waves of the statistics kernels hide their side work behind inline-asm loads that hipcc does not count
+(csrc/mdbn_planes.hip, EARLYW): between such a load and the counted wait that covers it no instruction may name its
+destination registers -- hipcc believes they are written when the asm statement ends, and a copy or a reuse in between is
+silent corruption (the first version of the gather-ahead faulted exactly so).  mdbn_amd/isa_audit.py proves it on the
+assembly of the build; these tests pin the auditor itself on hand-written assembly, then run it on the real sources.  They
+need hipcc, not a GPU."""
 import os
 import subprocess
 import sys
@@ -10,12 +11,86 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mdbn_amd import isa_audit   # noqa: E402
 
 
-def test_no_instruction_touches_a_pending_asm_load_destination():
-    if not os.path.exists("/opt/rocm/bin/hipcc"):
-        pytest.skip("hipcc not installed")
+def kernel(body):
+    return "\t.amdhsa_kernel k\n\t.end_amdhsa_kernel\nk:\n" + body + "\ts_endpgm\n.Lfunc_end0:\n"
+
+
+LOAD = ";;#ASMSTART\n\tglobal_load_dwordx4 v[8:11], v[0:1], off\n;;#ASMEND\n"
+WAIT = lambda n: ";;#ASMSTART\n\ts_waitcnt vmcnt(%d)\n;;#ASMEND\n" % n     # noqa: E731
+DMA = "\tglobal_load_lds_dwordx4 v[34:35], off\n"
+
+
+def findings(body):
+    r = isa_audit.audit_assembly(kernel(body))
+    assert r["loads"] >= 1, "the auditor did not find the asm load"
+    return r["findings"]
+
+
+def test_counted_wait_retires_the_load():
+    assert findings(LOAD + DMA * 3 + WAIT(3) + "\tv_add_f32_e32 v20, v8, v9\n") == []
+    assert findings(LOAD + DMA * 3 + WAIT(0) + "\tv_mov_b32_e32 v8, 0\n") == []
+
+
+def test_use_before_the_wait_is_found():
+    f = findings(LOAD + DMA * 3 + "\tv_add_f32_e32 v20, v8, v9\n" + WAIT(3))
+    assert len(f) == 1 and "names a destination register" in f[0]
+    # a REUSE of the destination (as an address here) is the same hazard: the load lands later and clobbers it
+    assert len(findings(LOAD + "\tv_mov_b32_e32 v10, v33\n" + DMA * 3 + WAIT(3))) == 1
+
+
+def test_a_wait_that_is_too_weak_does_not_retire():
+    # three younger operations but the wait lets four fly: the load may still be in flight
+    assert len(findings(LOAD + DMA * 3 + WAIT(4) + "\tv_add_f32_e32 v20, v8, v9\n" + WAIT(0))) == 1
+
+
+def test_younger_operations_on_a_skippable_path_do_not_count():
+    # two of the three younger operations sit in a branch another path skips: on that path vmcnt(3) retires nothing
+    body = LOAD + DMA + "\ts_cbranch_scc1 .LBB0_2\n" + DMA * 2 + ".LBB0_2:\n" + WAIT(3) + "\tv_add_f32_e32 v20, v8, v9\n" + WAIT(0)
+    assert len(findings(body)) == 1
+    # ... and a wait inside such a branch retires the load on that path only
+    body = LOAD + DMA * 3 + "\ts_cbranch_scc1 .LBB0_2\n" + WAIT(3) + ".LBB0_2:\n" + "\tv_add_f32_e32 v20, v8, v9\n" + WAIT(0)
+    assert len(findings(body)) == 1
+
+
+def test_out_of_line_block_is_not_a_loop():
+    # hipcc places a cold block behind the kernel's tail: forward jump, jump back.  The pending load must be tracked through it.
+    body = (LOAD + DMA * 3 + "\ts_cbranch_execnz .LBB0_9\n.LBB0_1:\n" + WAIT(3) + "\tv_add_f32_e32 v20, v8, v9\n\ts_branch .LBB0_10\n"
+            ".LBB0_9:\n\tglobal_store_dword v[40:41], v42, off\n\ts_branch .LBB0_1\n.LBB0_10:\n")
+    assert findings(body) == []
+    bad = body.replace("global_store_dword v[40:41], v42, off", "global_store_dword v[40:41], v9, off")
+    assert len(findings(bad)) == 1
+
+
+def test_a_load_nobody_waits_for_is_found():
+    f = findings(LOAD + DMA)
+    assert len(f) == 1 and "still be pending at s_endpgm" in f[0]
+
+
+def test_kernels_are_discovered_not_listed():
+    two = kernel(LOAD + WAIT(0)).replace("k:", "first:").replace("kernel k", "kernel first") + \
+        kernel("\tv_mov_b32_e32 v1, v2\n").replace("k:", "second:").replace("kernel k", "kernel second").replace("func_end0", "func_end1")
+    r = isa_audit.audit_assembly(two)
+    assert list(r["kernels"]) == ["first"] and r["loads"] == 1
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_the_real_sources_pass_and_every_family_is_covered():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "experiments", "audit_asm_loads.py")],
-                         capture_output=True, text=True, timeout=600)
+                         capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert " asm loads; 0 touches" in out.stdout and not out.stdout.startswith("0 asm loads"), out.stdout
+    assert "; 0 findings" in out.stdout
+    # the kernel families known to carry asm loads today must be among the discovered ones (the list lives HERE, as an
+    # expectation -- the auditor itself has none: a new kernel with asm loads is audited without anybody naming it)
+    for family in ("gemm_planes_kernelILi1ELi1ELi3ELi2ELi16", "gemm_planes_kernelILi1ELi1ELi3ELi0ELi16", "gemm_planes_bal_kernelILi1ELi1ELi3E"):
+        assert family in out.stdout, family
+
+
+def test_the_build_records_its_verdict(built_lib):
+    from mdbn_amd import build
+    v = build.audit_verdicts()
+    assert "mdbn_planes.hip" in v and v["mdbn_planes.hip"]["loads"] > 0 and v["mdbn_planes.hip"]["findings"] == []
+    assert "clang" in v["mdbn_planes.hip"]["hipcc"].lower() or "hip" in v["mdbn_planes.hip"]["hipcc"].lower()
