@@ -510,9 +510,6 @@ typedef float f32x4n __attribute__((ext_vector_type(4)));
 constexpr int X6_KB = 32, X6_ROWB = 80, X6_PLANE = 128 * X6_ROWB, X6_BUF = 6 * X6_PLANE;
 
 // split two floats into three packed-bf16 pairs (lo half = first value)
-#ifndef X6_ABLATE
-#define X6_ABLATE 0     // diagnostic builds only: 1 = no split arithmetic, 2 = no producer LDS stores
-#endif
 __device__ __forceinline__ void x6_split2(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3)
 {
     // Truncating split on full-rate integer / f32 instructions: piece = value & 0xffff0000 (the upper half of
@@ -521,10 +518,6 @@ __device__ __forceinline__ void x6_split2(float a, float b, unsigned& p1, unsign
     // rounding conversion v_cvt_pk_bf16_f32 and v_dot2c_f32_bf16 are quarter-rate: with them the producer
     // waves needed ~2300 cycles per slice for split + store and the MFMA waves waited at every barrier.)
     const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
-#if X6_ABLATE == 1
-    p1 = p2 = p3 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
-    return;
-#endif
     const float ra = a - __builtin_bit_cast(float, ua & 0xffff0000u);
     const float rb = b - __builtin_bit_cast(float, ub & 0xffff0000u);
     const unsigned va = __builtin_bit_cast(unsigned, ra), vb = __builtin_bit_cast(unsigned, rb);
@@ -576,7 +569,7 @@ __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t 
     for (int it = 0; it < nt; ++it) {                                                             \
         STAMP(0);                                                                                 \
         X6_DIAG_WAIT();                                                                           \
-        if (it + 1 < nt && X6_ABLATE != 2) { X6_STORE(r0, (it + 1) & 1); }                        \
+        if (it + 1 < nt) { X6_STORE(r0, (it + 1) & 1); }                                          \
         STAMP(1);                                                                                 \
         if (it + 3 < nt) { X6_LOAD(r0, it + 3); }                                                 \
         STAMP(2);                                                                                 \
@@ -585,7 +578,7 @@ __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t 
         if (++it >= nt) break;                                                                    \
         STAMP(0);                                                                                 \
         X6_DIAG_WAIT();                                                                           \
-        if (it + 1 < nt && X6_ABLATE != 2) { X6_STORE(r1, (it + 1) & 1); }                        \
+        if (it + 1 < nt) { X6_STORE(r1, (it + 1) & 1); }                                          \
         STAMP(1);                                                                                 \
         if (it + 3 < nt) { X6_LOAD(r1, it + 3); }                                                 \
         STAMP(2);                                                                                 \
@@ -800,11 +793,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * PW)) void gemm_bf16x6_kernel(GemmArgs
                 }
             __syncthreads();                         // (waits for F1: every read of this slice's buffer is done)
             STAMP(2);
-#ifdef X6_GUARD_RELOAD      // diagnostic build only: the guarded reload that gave wrong results (root cause)
-            if (it + 1 < nt) { X6_FRAGS(f0a, f0b, next, 0); }
-#else
             X6_FRAGS(f0a, f0b, next, 0);
-#endif
             X6_MMA(f1a, f1b);
             STAMP(3);
         }

@@ -40,9 +40,6 @@ typedef float pf32x16 __attribute__((ext_vector_type(16)));
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PL_PLANE = 8192, PL_STAGE = 6 * PL_PLANE, PL_NSTAGE = 3, PL_LW = 4;
-#ifndef PL_RAMP_SPLIT
-#define PL_RAMP_SPLIT 1      // loader ramp-up: stage 0 alone before the first barrier (pl_loader)
-#endif
 
 __device__ __forceinline__ void pl_glds16(const void* g, unsigned lds_off, char* smem)
 {
@@ -162,23 +159,12 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
     // waves are running on it.
     PL_STAMP(1);
     PL_ISSUE(0);
-#if PL_RAMP_SPLIT
     PL_STAMP(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PL_STAMP(3);
     __builtin_amdgcn_s_barrier();                    // stage 0 landed
     if (nt > 1) { PL_ISSUE(1); }
     if (nt > 2) { PL_ISSUE(2); }
-#else
-    if (nt > 1) { PL_ISSUE(1); }
-    if (nt > 2) { PL_ISSUE(2); }
-    PL_STAMP(2);
-    if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER) : "memory");
-    else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PL_STAMP(3);
-    __builtin_amdgcn_s_barrier();                    // stage 0 landed
-#endif
     // EARLYW side work, one ITEM per stage: first the chunk items of the W tile (CPI 8-row chunks each, 16 / CPI items),
     // then the gather-ahead units (one 256-octet pass of one row of the next minibatch each).  An item's loads are issued
     // ONE STAGE BEFORE it is applied, ahead of that stage's DMAs, so a whole MFMA stage (~1.1 us) hides their HBM latency;
@@ -623,21 +609,12 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
 
-// How a split-K partial tile (FUSED == 0) reaches its slab: 0 = straight from the accumulator registers (64 dword stores
-// per lane, 64-byte segments); 1 = through the LDS-parked tile, whole rows, 16 bytes per lane, by all 8 waves; 2 = the same
-// with WRITE-THROUGH (sc1) stores: the partials stream to memory while the tail of the launch still issues stores, instead
-// of sitting dirty in L2 until the end-of-kernel write-back (16.8 MB per forward pass at c2: ~3.5 us of the launch,
-// scripts/experiments/fixed_cost_probe.py; MI355X_MICROARCH.md "publish-large")
-#ifndef PL_SLAB_STORE
-#define PL_SLAB_STORE 0
-#endif
-    constexpr bool parked_slab = FUSED == 0 && PL_SLAB_STORE != 0 && MS == 16;
     EarlySpeed es;
     (void)es;
     if (wave >= 4) {
         pl_loader<LA, LB, AP, MS, (FUSED == 2 || (FUSED == 0 && LA == LAY_MN && LB == LAY_MN && AP == 3)) && MS == 16, BN>(
             g, smem, wave - 4, lane, m0, n0, kbeg, nt, &es);
-        if constexpr (FUSED == 0 && !parked_slab) return;
+        if constexpr (FUSED == 0) return;
     } else {
         const int r = lane & 31, h = lane >> 5;
         const int wm = (wave >> 1) * 64, wn = (wave & 1) * (BN / 2);
@@ -689,7 +666,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
 #endif
             // accumulator (16x16): col = lane & 15, row = 4 * (lane >> 4) + e
             const int c16 = lane & 15, q4 = lane >> 4;
-            if constexpr (FUSED != 0 || parked_slab) {
+            if constexpr (FUSED != 0) {
                 float* T = reinterpret_cast<float*>(smem);
                 constexpr int LDT = BN + 8;
 #pragma unroll
@@ -700,20 +677,14 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
                         for (int e = 0; e < 4; ++e)
                             T[(wm + 16 * a + 4 * q4 + e) * LDT + wn + 16 * b + c16] = acc[a][b][e];
             } else {
-                // diagnostic builds (wrong results; scripts/experiments/fixed_cost_probe.py): PL_DIAG_DIRTY = 1: every split
-                // stores into slab 0 (an eighth of the dirty bytes at the end of the launch), 2: no stores at all
-#ifndef PL_DIAG_DIRTY
-#define PL_DIAG_DIRTY 0
-#endif
-                float* C = g.C + (PL_DIAG_DIRTY ? (int64_t)0 : (int64_t)ks * g.slab_stride);
+                float* C = g.C + (int64_t)ks * g.slab_stride;
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = 0; b < NBB; ++b)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (PL_DIAG_DIRTY != 2 || acc[a][b][e] == 12345.678f)
-                                C[(int64_t)(m0 + wm + 16 * a + 4 * q4 + e) * g.ldc + n0 + wn + 16 * b + c16] = acc[a][b][e];
+                            C[(int64_t)(m0 + wm + 16 * a + 4 * q4 + e) * g.ldc + n0 + wn + 16 * b + c16] = acc[a][b][e];
                 PL_MSTAMP(11);
 #ifdef MDBN_STAMP
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -862,23 +833,6 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
         }
             }
     }
-    if constexpr (parked_slab) {    // whole rows of the parked partial tile -> slab ks, 16 bytes per lane, all 8 waves
-        __syncthreads();
-        typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
-        const float* T = reinterpret_cast<const float*>(smem);
-        constexpr int NT = 64 * (4 + PL_LW), LDT = 128 + 8;
-        // descriptor over this tile's 128 rows (128 x ldc floats: far below 2 GiB for any ldc this path accepts)
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            g.C + (int64_t)ks * g.slab_stride + (int64_t)m0 * g.ldc + n0, 0, (int)(128 * g.ldc * 4), 0x00020000);
-#pragma unroll
-        for (int i = 0; i < 128 * 32 / NT; ++i) {
-            const int idx = threadIdx.x + i * NT, row = idx >> 5, c4 = idx & 31;
-            const pu32x4 v = *reinterpret_cast<const pu32x4*>(T + row * LDT + 4 * c4);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)((row * g.ldc + 4 * c4) * 4), 0,
-                                                   PL_SLAB_STORE == 2 ? 16 /* sc1 */ : 0);
-        }
-        return;
-    }
     if constexpr (FUSED != 0) {     // all 8 waves work on the parked tile (every DMA has landed: the loaders drained vmcnt)
         __syncthreads();
         float* T = reinterpret_cast<float*>(smem);
@@ -894,12 +848,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
         if constexpr (FUSED == 1 && BN == 64) fused_tile_epilogue_4x4<NT>(g.epi, T, m0, n0);     // one pass, loads up front
         else if constexpr (FUSED == 1) fused_tile_epilogue<128, BN, NT>(g.epi, T, m0, n0);
         else if (MS == 16 && g.upd.early == 1) {     // W went early (pl_loader); the loader waves hold speed_old (+ W0)
-// diagnostic builds (wrong results; scripts/experiments/fixed_cost_probe.py stats): 1 = the new speed is formed but not
-// stored, 2 = no speed epilogue at all -- what the tail of the statistics launch costs
-#ifndef PL_DIAG_STATS
-#define PL_DIAG_STATS 0
-#endif
-            if (wave >= 4 && PL_DIAG_STATS != 2) {
+            if (wave >= 4) {
                 const int lt = (wave - 4) * 64 + lane;
                 constexpr int LDT = 128 + 8;
 #pragma unroll
@@ -910,8 +859,7 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         setc(sn, c, upd_speed(upd_grad(comp(st, c), g.upd.inv_bs, g.upd.wc, comp(es.w0[j], c)), comp(es.sp[j], c), g.upd.mu));
-                    if (PL_DIAG_STATS == 0 || sn.x == 12345.678f)
-                        *reinterpret_cast<float4*>(g.upd.Ws + (int64_t)(m0 + row) * g.upd.ld + n0 + 4 * c4) = sn;
+                    *reinterpret_cast<float4*>(g.upd.Ws + (int64_t)(m0 + row) * g.upd.ld + n0 + 4 * c4) = sn;
                 }
             }
         }

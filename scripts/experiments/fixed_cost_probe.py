@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""Where the fixed cost of a forward GEMM launch sits OUTSIDE the kernel's own instructions.
+"""(Needs the diagnostic variants: `git apply scripts/experiments/diagnostic_variants.patch` first -- they no longer live in
+the product kernels.)
+Where the fixed cost of a forward GEMM launch sits OUTSIDE the kernel's own instructions.
 
 In-kernel stamps (planes_stamps.py) see first-workgroup-start -> last-store-acknowledged = 21.9 us of the 25.6 us the
 kernel trace reports for the propup launch.  This probe prices the rest with diagnostic builds that change only how many

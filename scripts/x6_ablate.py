@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""Diagnostic: bf16x6 GEMM timing with producer ablations (-DX6_ABLATE=1 no split arithmetic, =2 no producer
+"""(Needs the diagnostic variants: `git apply scripts/experiments/diagnostic_variants.patch` first -- they no longer live in
+the product kernels.)
+Diagnostic: bf16x6 GEMM timing with producer ablations (-DX6_ABLATE=1 no split arithmetic, =2 no producer
 LDS stores; results are wrong in those builds).  Builds three libraries on the GPU box."""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
