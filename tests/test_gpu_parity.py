@@ -31,8 +31,16 @@ def state64(W, hb, vb, gauss):
 
 
 def ptol(K):
-    """Probability tolerance: 2e-6 abs up to K = 1024, growing as sqrt(K) beyond --
-    a K-long fp32 fma chain carries ~1e-7 * sqrt(K) * |pre| of rounding into sigmoid'(pre) <= 1/4."""
+    """Probability tolerance: SURVEY 8d's 2e-6 abs at EVERY reduction length (round 4).  Rounds 2-3 let it grow as sqrt(K)
+    beyond K = 1024 (4e-6 at V = 4096: measured 2.2e-6); the error was the accumulator's: six roundings at its own magnitude
+    per 32-deep stage.  With the stage-local accumulators of the propup layout (one such rounding per stage) V = 4096
+    measures 8e-7."""
+    return 2e-6
+
+
+def gtol(K):
+    """One f32 GEMM against ANOTHER f32 GEMM (the bf16-split kernels beside the exact-f32 MFMA kernel, whose K-long chain
+    of f32 additions has no stage-local accumulators): 2e-6 of the scale up to K = 1024, growing as sqrt(K) beyond."""
     return 2e-6 * max(1.0, (K / 1024.0) ** 0.5)
 
 
@@ -659,8 +667,8 @@ def test_skinny_gemm_matches_oracle_and_tile_kernel(hip_engine, V, H, B):
         eng.set_option("skinny_gemm", 1)
     pre_up = vn.astype(np.float64) @ Wn.astype(np.float64) + hbn
     pre_dn = hn.astype(np.float64) @ Wn.astype(np.float64).T + vbn
-    tol_up = 4 * ptol(V) * max(1.0, np.abs(pre_up).max())     # pre-activation, not probability
-    tol_dn = 4 * ptol(H) * max(1.0, np.abs(pre_dn).max())
+    tol_up = 4 * gtol(V) * max(1.0, np.abs(pre_up).max())     # pre-activation, not probability
+    tol_dn = 4 * gtol(H) * max(1.0, np.abs(pre_dn).max())
     for kern in (1, 0):
         assert np.abs(out[kern][0] - pre_up).max() <= tol_up
         assert np.abs(out[kern][3] - pre_dn).max() <= tol_dn
@@ -724,7 +732,7 @@ def test_large_shapes_against_rocblas(hip_engine, V, H, B):
     from mdbn_amd.engine import RngAddr
     pre, mean, sample = eng.propup(x, Wd, hb, rng=RngAddr(3, 0, 1, 0))
     ref = x.double() @ W.double() + hb.double()
-    tol = 4 * ptol(V) * max(1.0, float(ref.abs().max()))
+    tol = 4 * gtol(V) * max(1.0, float(ref.abs().max()))
     assert float((pre[:, :H].double() - ref).abs().max()) <= tol
     assert float((mean[:, :H] - torch.sigmoid(pre[:, :H])).abs().max()) <= 2e-6
     u = eng.rng_uniform(B, H, RngAddr(3, 0, 1, 0))
@@ -732,7 +740,7 @@ def test_large_shapes_against_rocblas(hip_engine, V, H, B):
     assert float((sample[:, :H] != expect).float().mean()) == 0.0
     dpre, dmean, dsample = eng.propdown(h, Wd, vb, gauss=False, rng=RngAddr(3, 0, 1, 1))
     dref = h.double() @ W.double().t() + vb.double()
-    dtol = 4 * ptol(H) * max(1.0, float(dref.abs().max()))
+    dtol = 4 * gtol(H) * max(1.0, float(dref.abs().max()))
     assert float((dpre[:, :V].double() - dref).abs().max()) <= dtol
     assert float((dmean[:, :V] - torch.sigmoid(dpre[:, :V])).abs().max()) <= 2e-6
 
@@ -820,7 +828,7 @@ def test_bf16x6_gemm_is_f32_grade(hip_engine, V, H, B):
     finally:
         eng.set_option("gemm_bf16x6", 3)
     for e6, e0, K in zip(err[3], err[0], (V, H, 2 * B)):
-        assert e6 <= 4 * ptol(K)                       # the f32 bar
+        assert e6 <= 4 * gtol(K)                       # the f32 bar
         assert e6 <= 4 * e0 + 1e-7                     # and not materially worse than the exact-f32 MFMA kernel
 
 
@@ -918,7 +926,7 @@ def test_bf16x6_ragged_shapes_match_exact_kernel(hip_engine):
             eng.set_option("gemm_bf16x6", 3)
         for a, b, K in zip(out[3], out[0], (V, H)):
             scale = max(1.0, float(b.abs().max()))
-            assert float((a - b).abs().max()) <= 4 * ptol(K) * scale, (V, H, B)
+            assert float((a - b).abs().max()) <= 4 * gtol(K) * scale, (V, H, B)
             base_a = a._base if a._base is not None else a
             if base_a.shape[1] > a.shape[1]:
                 assert float(base_a[:, a.shape[1]:].abs().max()) == 0.0, "pad columns must stay zero"
