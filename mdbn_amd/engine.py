@@ -239,7 +239,8 @@ class HipEngine(object):
 
     # ------------------------------------------------------------------ scratch
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # (torch.cuda.current_stream() builds a Stream object: 5 us per call -- a sixth of a small layer's step)
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(self.device.index))
 
     def workspace(self, B, V, H):
         """One shared workspace, grown to the largest requirement seen.  The requirement is NOT monotone in (B, V, H) (a
@@ -586,12 +587,7 @@ class HipEngine(object):
         # Step costs are 0-d views into a block of 1024 floats.  A block is never reused: when it is full a fresh one is
         # allocated (4 KB per 1024 steps) and the old one lives as long as a caller still holds one of its views, so a
         # cost kept unread for any number of steps can never show another step's value.
-        if self._cost_slot >= self._cost_ring.numel():
-            self._cost_ring = torch.zeros(1024, dtype=torch.float32, device=self.device)
-            self._cost_slot = 0
-        slot = self._cost_slot
-        self._cost_slot = slot + 1
-        cost = self._cost_ring[slot]
+        cost = self._next_cost_slot()
         u = _lib.UpdateArgs()
         u.W, u.W_speed = W.data_ptr(), W_speed.data_ptr()
         u.W0 = W0.data_ptr() if W0 is not None else None
@@ -608,12 +604,43 @@ class HipEngine(object):
         u.W_planes = wp.data_ptr() if wp is not None else None    # kept in step with W by every update that writes W
         return u, cost
 
+    def _next_cost_slot(self):
+        # Step costs are 0-d views into a block of 1024 floats.  A block is never reused: when it is full a fresh one is
+        # allocated (4 KB per 1024 steps) and the old one lives as long as a caller still holds one of its views.
+        if self._cost_slot >= self._cost_ring.numel():
+            self._cost_ring = torch.zeros(1024, dtype=torch.float32, device=self.device)
+            self._cost_slot = 0
+        slot = self._cost_slot
+        self._cost_slot = slot + 1
+        return self._cost_ring[slot]
+
+    def cd_train_step_cached(self, cache, data, idx, rng_step, lr, momentum):
+        """The step of ``cd_train_step`` through argument structs a step function keeps from its previous call
+        (``cache`` = what ``cd_train_step(..., cache_out=)`` left): for small layers, whose step is two short launches, the
+        host side -- building two ctypes structs of ~70 fields, resolving scratch, statistics and workspace buffers -- was
+        32 us per call, more than the GPU's time.  Only what changes from call to call is set: the index list, the Philox
+        step, lr / momentum and the cost slot.  Returns None when the cache does not apply (the caller takes the full path)."""
+        a, u, a_ref, u_ref, key, sc, keep = cache[:7]
+        if key != (data.data_ptr(), data.shape[0], idx.dtype, idx.numel(), self._workspace.data_ptr() if self._workspace is not None else 0,
+                   self.keep_f32, self.trace_chain):
+            return None
+        a.indexes = idx.data_ptr()
+        a.rng.step = rng_step & 0xFFFFFFFF
+        u.lr, u.momentum = float(lr), float(momentum)
+        cost = self._next_cost_slot()
+        u.cost_out = cost.data_ptr()
+        self.last_scratch = sc
+        _lib.check(self.lib.mdbn_cd_train_step(self.ctx, self._stream(), a_ref, u_ref), "mdbn_cd_train_step")
+        return cost
+
     def cd_train_step(self, data, indexes, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, gauss, k,
                       rng, lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale,
-                      sample_stats=False, next_indexes=None):
+                      sample_stats=False, next_indexes=None, cache_out=None):
         """The whole single-device step function (mdbn_cd_train_step): cd_step + update, with the
         finalize / parameter half of the update overlapped under the statistics GEMM.  Returns the
-        monitoring cost (0-d device tensor)."""
+        monitoring cost (0-d device tensor).  ``cache_out``: a list that receives the argument structs of this call when
+        the next call of the same step function may reuse them (``cd_train_step_cached``): index list given, no plane
+        buffers (the plane path's arguments change from step to step: gather-ahead), no chain taps."""
         a, stats, sc, _keep = self._cd_args(data, indexes, W, hbias, vbias, gauss, k, rng, None, False, 0,
                                             sample_stats, next_indexes=next_indexes)
         sc._announce, announce = None, getattr(sc, "_announce", None)
@@ -625,6 +652,13 @@ class HipEngine(object):
         self._w_planes_written(W)
         if announce is not None and a.ahead_done and self._ahead_flag.value:
             sc.ahead = announce              # the next call finds its rows in the other X2 buffer
+        if cache_out is not None:
+            del cache_out[:]
+            idx = _keep[1]
+            if idx is not None and sc.planes is None and not a.W_planes and not self.trace_chain and not sample_stats:
+                dm = _keep[0]
+                key = (dm.data_ptr(), dm.shape[0], idx.dtype, idx.numel(), self._workspace.data_ptr(), self.keep_f32, self.trace_chain)
+                cache_out.extend([a, u, C.byref(a), C.byref(u), key, sc, (dm, stats, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed)])
         return cost
 
     def apply_update(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats,

@@ -113,6 +113,7 @@ class StepFunction(object):
         # update reads them a whole call later, so another step function of the same shape (two
         # equal-sized modalities, alternating layers) must not share them
         self._stats_slots = [None, None]
+        self._fast = []                     # argument structs of the previous single-device call (engine.cd_train_step_cached)
         # nan_guard: check cost and parameters for NaN / Inf after every call (synchronises; what the
         # reference's commented-out NanGuardMode would do, rbm.py:542-543, dbn.py:311)
         self.nan_guard = bool(getattr(self.engine, "nan_guard", False))
@@ -339,6 +340,13 @@ class StepFunction(object):
                 persistent = persistent[lo:hi]
         if not distributed and p.persistent is None and hi > lo:
             # single device: the whole step function in one library call (mdbn_cd_train_step)
+            if len(self._fast) == 8 and idx is not None and staged_slot is None and not self.nan_guard and self._fast[7] == \
+                    (batch_size, n_global, rbm.W.tensor.data_ptr(), rbm.hbias.tensor.data_ptr(), rbm.vbias.tensor.data_ptr()):
+                # the argument structs of the previous call (small layers are host-bound: engine.cd_train_step_cached)
+                out = eng.cd_train_step_cached(self._fast, data, idx, step, lr, momentum)
+                if out is not None:
+                    rbm._n_updates += 1
+                    return out
             cost_scale = 1.0 / (n_global * rbm.n_visible) if rbm.gauss else 1.0 / n_global
             out = eng.cd_train_step(data, idx, rbm.W.tensor, rbm.W_speed.tensor,
                                     p.W0.tensor if p.W0 is not None else None,
@@ -347,8 +355,11 @@ class StepFunction(object):
                                     RngAddr(rbm.theano_rng.seed, rbm.stream_id, step, 0, lo),
                                     lr, p.lambda_1, p.lambda_2, p.weightcost, momentum, batch_size,
                                     n_global, cost_scale, sample_stats=p.symbolic_grad,
-                                    **({"next_indexes": next_indexes} if (next_indexes is not None and idx is not None
-                                                                          and staged_slot is None) else {}))
+                                    **dict({"next_indexes": next_indexes} if (next_indexes is not None and idx is not None
+                                                                              and staged_slot is None) else {},
+                                           **({"cache_out": self._fast} if hasattr(eng, "cd_train_step_cached") else {})))
+            if self._fast:        # (what else must stay as it was for the structs to be reused)
+                self._fast.append((batch_size, n_global, rbm.W.tensor.data_ptr(), rbm.hbias.tensor.data_ptr(), rbm.vbias.tensor.data_ptr()))
             rbm._n_updates += 1
             if staged_slot is not None:
                 self._fed()

@@ -57,7 +57,7 @@ class ShadowEngine(mdbn_amd.HipEngine):
     # -- single-device step function
     def cd_train_step(self, data, indexes, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, gauss, k,
                       rng, lr, lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale,
-                      sample_stats=False, next_indexes=None):     # (the chain taps keep the gather-ahead off)
+                      sample_stats=False, next_indexes=None, cache_out=None):     # (the chain taps keep the gather-ahead and the struct cache off)
         st = self._state(W, hbias, vbias, gauss, (W_speed, hbias_speed, vbias_speed))
         st.W0 = None if W0 is None else W0.cpu().numpy().astype(np.float64)
         v0 = self._rows(data, indexes)

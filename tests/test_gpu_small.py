@@ -99,3 +99,32 @@ def test_one_launch_step_draws_the_uniforms_of_the_multi_launch_path(hip_engine,
     if differ == 0 and k == 1:
         scale = max(1.0, np.abs(b["stats"]).max())
         assert np.abs(a["stats"] - b["stats"]).max() <= 2e-5 * scale
+
+
+def test_cached_argument_structs_give_the_same_training_run(hip_engine):
+    """Small layers are host-bound: a step function reuses the argument structs of its previous call (only the index list, the
+    Philox step, lr / momentum and the cost slot change).  Twelve steps with changing index tensors, momentum and lr through the
+    cached path equal the same steps with the cache switched off, bit for bit -- and the cache really was used."""
+    import mdbn_amd
+    eng = mdbn_amd.HipEngine()                                   # product defaults (no inspection copies, no taps)
+    runs, used = [], []
+    for cached in (True, False):
+        rs = np.random.RandomState(4)
+        data = (rs.uniform(size=(400, 100)) < 0.3).astype(np.float32)
+        rbm = mdbn_amd.RBM(n_visible=100, n_hidden=24, numpy_rng=np.random.RandomState(123), theano_rng=mdbn_amd.RandomStreams(9),
+                           engine=eng)
+        _, up = rbm.get_cost_updates(k=1, batch_size=20, lr=0.05, weightcost=2e-4)
+        fn = mdbn_amd.function(up, mdbn_amd.shared(data, engine=eng), data_parallel=None)
+        batches = [eng.index_tensor(rs.permutation(400)[:20]) for _ in range(12)]
+        costs, hits = [], 0
+        for t in range(12):
+            if not cached:
+                del fn._fast[:]
+            hits += int(len(fn._fast) == 8)
+            costs.append(float(fn(indexes=batches[t], momentum=0.5 if t < 6 else 0.9, lr=0.05 if t % 2 else 0.02)))
+        used.append(hits)
+        runs.append(dict(costs=np.array(costs), W=rbm.W.get_value(), Ws=rbm.W_speed.get_value(), hb=rbm.hbias.get_value(),
+                         vbs=rbm.vbias_speed.get_value(), n=np.array([rbm._n_updates, rbm._rng_step])))
+    assert used == [11, 0], used
+    for key in runs[0]:
+        assert np.array_equal(runs[0][key], runs[1][key]), key
