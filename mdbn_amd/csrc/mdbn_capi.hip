@@ -1442,7 +1442,7 @@ static bool small_eligible(const mdbn_cd_args* a, const Workspace& ws)
     if (!g_opt_small_fused || g_opt_bf16_inputs) return false;
     if (a->persistent || a->sample_stats || (a->gauss && a->add_noise)) return false;
     if (!a->gauss && a->vs == nullptr) return false;
-    if (a->B > 65535 * 16 || !small_shape_ok(a->B, a->V, a->H, a->gauss)) return false;
+    if (a->B > 65535 * 16 || !small_shape_ok(a->B, a->V, a->H, a->gauss) || !small_ld_ok(a->V, a->H, a->ldv, a->ldh)) return false;
     const int nb = small_blocks(a->B);
     return (int64_t)nb * a->V * a->ldh <= ws.slab_floats && nb <= ws.cost_floats && nb <= row_groups(a->B);
 }

@@ -4,17 +4,25 @@
 // joint layer), each step a scan of k gibbs_hvh (rbm.py:318-336).  On the multi-launch path such a step is 2 k + 4 dependent
 // launches that each sit on the 5-7 us floor of a dependent tiny kernel (512 -> 40, CD-5, B = 512: 14 launches, 128 us for
 // 0.27 GFLOP).  Here W (f32, <= ~100 KB) is staged into LDS once per workgroup, and a workgroup runs the WHOLE chain for
-// 16-row slabs of the minibatch -- gather, positive phase, k x (propdown, propup) with the fused activations and the Philox
+// FOUR-row slabs of the minibatch -- gather, positive phase, k x (propdown, propup) with the fused activations and the Philox
 // draws, the reconstruction cost, and its share of the statistics S = v0^T ph - nv^T nh, accumulated in registers over its
-// slabs -- on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32) with every operand read from LDS.  It writes ONE partial
-// [S | s_h | s_v | cost] per workgroup; a second, small launch (small_finish_kernel) sums the partials in workgroup order
-// and applies the parameter update (or stores the statistics for a data-parallel all-reduce).  No workgroup waits for
-// another.  Same Philox addressing as every other path (counter = (column, global row >> 2, draw, step)): the same uniforms
-// meet probabilities that differ from the multi-launch path's by fp32 summation order only.
+// slabs -- on the exact-f32 MFMA with every operand read from LDS.  It writes ONE partial [S | s_h | s_v | cost] per
+// workgroup; a second, small launch (small_finish_kernel) sums the partials in a fixed order and applies the parameter
+// update (or stores the statistics for a data-parallel all-reduce).  No workgroup waits for another.  Same Philox addressing
+// as every other path (counter = (column, global row >> 2, draw, step)): the same uniforms meet probabilities that differ
+// from the multi-launch path's by fp32 summation order only.
 //
-// MFMA operand layout (16x16x4 f32): A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15],
-// D[m = 4 (lane >> 4) + e][n = lane & 15] -- a lane's four accumulator registers are four CONSECUTIVE ROWS of one column,
-// exactly the four rows one Philox block serves.
+// Why four rows.  The chain of a slab is a string of dependent passes; its length is what a step costs, and with 16-row
+// slabs on v_mfma_f32_16x16x4_f32 (round 4's first version: 59 us for 512 -> 40 CD-5 at B = 512 on 32 workgroups) every pass
+// sat on the f32 matrix pipe of ONE CU: 3 072 cycles per pass, 7/8 of the chip idle.  v_mfma_f32_4x4x1_16b_f32 computes 16
+// independent 4 x 4 x 1 blocks; with the A operand BROADCAST from one block to all (cbsz = 4, abid = u) an instruction is a
+// rank-1 update of a 4-row x 64-column tile -- 4 rows are exactly one Philox block -- so a minibatch of 512 rows is 128
+// workgroups and a pass costs a quarter of the MFMA time.  One A register (lane 4 b + i holds X[i][k0 + b]) carries the A
+// operands of 16 k-steps: 16 MFMAs name it with abid = 0 .. 15 (probe of the layouts and the issue cost -- 9.5 cycles per
+// MFMA and wave on two accumulator chains: scripts/experiments/mfma4x4_probe.hip).
+//
+// MFMA operand layout (4x4x1, 16 blocks): A[block b = lane >> 2][i = lane & 3], B[b][j = lane & 3], D[b][i = register e][j]:
+// a lane's four accumulator registers are the FOUR ROWS of output column 4 b + j = lane -- one Philox block.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <stdint.h>
@@ -55,266 +63,185 @@ __device__ __forceinline__ int64_t sm_src_row(const SmallCdArgs& a, int row)
     return s < 0 ? 0 : (s >= a.n_data ? a.n_data - 1 : s);
 }
 
-// One pass of the chain, D[16][N] = A[16][K] * op(W), in two forms:
-//
-// sm_up (propup, K = V long, N = H a few tiles): work items = (group of TG tiles, K chunk) dealt over the waves -- the tiles of
-// a group share the A operand (one LDS read feeds TG MFMAs) and give the wave TG independent accumulator chains; operands
-// of round r + 1 are read before the MFMAs of round r are issued.  Partial tiles go through `part`; after a barrier the
-// (row quad, column) pairs are dealt over the threads, each sums its ks partials in chunk order and applies `epi` ONCE
-// (one copy of the epilogue's code: a workgroup runs every phase once per slab, its instructions are fetched cold).
-//
-// sm_down (propdown, K = H short, N = V many tiles): work items = groups of 4 tiles over the whole K; the wave applies `epi`
-// to its accumulator registers (a lane holds rows 4 q .. 4 q + 3 of a column); `pre` is called before the reduction loop so
-// that the epilogue's global loads fly under it.
-//
-// No operand masking anywhere: the pad columns of the 16-row buffers hold exact zeros (every writer keeps them so), W's
-// index is clamped into the matrix, and a column n >= N computes a copy of column N - 1 that `epi` discards.
-// The reduction loop of a pass: `rounds` rounds of two k-steps for TG tiles that share the A operand.  Two register sets
-// alternate, so the operands of round r + 1 (and r + 2) are in flight while the MFMAs of round r issue, and no copy ties a
-// round's MFMAs to the NEXT round's loads (hipcc's in-order lgkmcnt then waits only for the set it is about to use).  The
-// look-ahead past the last round re-reads the last round (valid addresses, values unused) instead of branching.
-template <int TG>
-__device__ __forceinline__ void sm_kloop(sf32x4 (&acc)[TG], lds_cf* ap0, lds_cf* const (&bp0)[TG], int b1off, int bround, int rounds)
-{
-    struct Frag { float a0, a1, b0[TG], b1[TG]; };
-    auto load = [&](Frag& f, int q) {
-        f.a0 = ap0[8 * q]; f.a1 = ap0[8 * q + 4];
-#pragma unroll
-        for (int j = 0; j < TG; ++j) { f.b0[j] = bp0[j][q * bround]; f.b1[j] = bp0[j][q * bround + b1off]; }
-    };
-    auto mma = [&](const Frag& f) {
-#pragma unroll
-        for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a0, f.b0[j], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a1, f.b1[j], acc[j], 0, 0, 0);
-    };
-    if (rounds <= 0) return;
-    Frag f0, f1;
-    load(f0, 0);
-    for (int r = 0; r + 2 <= rounds; r += 2) {       // (scheduling barriers: hipcc otherwise sinks each load to its first use)
-        load(f1, r + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(f0);
-        __builtin_amdgcn_sched_barrier(0);
-        load(f0, min(r + 2, rounds - 1));
-        __builtin_amdgcn_sched_barrier(0);
-        mma(f1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (rounds & 1) mma(f0);
-}
+// 16 rank-1 updates of a 4 x 64 tile: A register `A_` (16 k-steps, one per block), B values B_(0) .. B_(15); two accumulator
+// chains (even / odd k) so that an MFMA never waits for the one before it.  (abid must be an immediate: spelled out.)
+#define SM_MMA1(ACC, A_, BV, U) ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(A_, BV, ACC, 4, U, 0)
+#define SM_MMA16(ACC0, ACC1, A_, B_)                                                                                   \
+    SM_MMA1(ACC0, A_, B_(0), 0);   SM_MMA1(ACC1, A_, B_(1), 1);   SM_MMA1(ACC0, A_, B_(2), 2);   SM_MMA1(ACC1, A_, B_(3), 3);   \
+    SM_MMA1(ACC0, A_, B_(4), 4);   SM_MMA1(ACC1, A_, B_(5), 5);   SM_MMA1(ACC0, A_, B_(6), 6);   SM_MMA1(ACC1, A_, B_(7), 7);   \
+    SM_MMA1(ACC0, A_, B_(8), 8);   SM_MMA1(ACC1, A_, B_(9), 9);   SM_MMA1(ACC0, A_, B_(10), 10); SM_MMA1(ACC1, A_, B_(11), 11); \
+    SM_MMA1(ACC0, A_, B_(12), 12); SM_MMA1(ACC1, A_, B_(13), 13); SM_MMA1(ACC0, A_, B_(14), 14); SM_MMA1(ACC1, A_, B_(15), 15)
 
-template <int TG>
-__device__ __forceinline__ void sm_up_loop(lds_cf* A, int lda, lds_cf* Wl, int ldw, int K, int N, int tiles, int ks,
-                                           lds_f* part, int pld, int wave, int lane)
-{
-    const int c16 = lane & 15, kq = lane >> 4;
-    const int ksteps = (K + 3) >> 2, kfull = K >> 2;
-    const int per = (ksteps + ks - 1) / ks;
-    const int groups = (tiles + TG - 1) / TG;
-    const int bstep = 4 * ldw;
-    for (int item = wave; item < groups * ks; item += SM_NW) {
-        SM_CLK_BEGIN();
-        const int grp = item % groups, ch = item / groups;
-        const int s0 = ch * per, s1 = min(ksteps, s0 + per), s1f = min(s1, kfull);
-        sf32x4 acc[TG];
-        lds_cf* bp[TG];
-#pragma unroll
-        for (int j = 0; j < TG; ++j) {
-            acc[j] = sf32x4{0.f, 0.f, 0.f, 0.f};
-            const int n = min((grp * TG + j) * 16 + c16, N - 1);
-            bp[j] = Wl + (4 * s0 + kq) * ldw + n;
-        }
-        const int rounds = (s1f - s0) >> 1;
-        sm_kloop<TG>(acc, A + c16 * lda + 4 * s0 + kq, bp, bstep, 2 * bstep, rounds);
-        for (int s = s0 + 2 * rounds; s < s1; ++s) {     // odd step, and the K tail (W index clamped; A's pad is zero)
-            const int k = 4 * s + kq, kc = k < K ? k : K - 1;
-            const float av = A[c16 * lda + k];
-#pragma unroll
-            for (int j = 0; j < TG; ++j) {
-                const int n = min((grp * TG + j) * 16 + c16, N - 1);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wl[kc * ldw + n], acc[j], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < TG; ++j) {
-            const int tile = grp * TG + j;
-            if (tile < tiles) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) part[(ch * SM_ROWS + 4 * kq + e) * pld + tile * 16 + c16] = acc[j][e];
-            }
-        }
-        SM_CLK_ADD(48);
-    }
-}
+// One pass of the chain, D[4][N] = A[4][K] * op(W), in two forms.  No operand masking anywhere: the pad columns of the
+// 4-row buffers and the pad rows / columns of W's image hold exact zeros (every writer keeps them so), a lane's column index
+// is clamped into the image, and a column n >= N computes something finite that `epi` discards.
+//
+// sm_up (propup, K = V long, N = H: one or two 64-column tiles): work items = (tile, K chunk) dealt over the waves; a lane
+// reads W[k][its column] (lanes side by side: no conflicts), 16 k-steps per A register, the next group's operands in flight
+// under the MFMAs of this one.  The chunk partials go through `part` as one float4 per (chunk, column); after a barrier
+// thread c sums the chunks of column c in chunk order and applies `epi` ONCE.
+//
+// sm_down (propdown, K = H short, N = V: up to 8 tiles, one per wave): a lane reads 16 bytes of ITS row of W (its output
+// column) per 4 k-steps; the wave applies `epi` to its accumulator registers.
+struct UpFrag { float a; float b[16]; };
 
 template <class Epi>
-__device__ __forceinline__ void sm_up(lds_cf* A, int lda, lds_cf* Wl, int ldw, int K, int N, int tiles, int tg, int ks,
-                                      lds_f* part, int pld, int wave, int lane, Epi&& epi)
+__device__ __forceinline__ void sm_up(lds_cf* X, lds_cf* Wl, const SmallLayout& L, lds_f* part, int wave, int lane, Epi&& epi)
 {
-    if (tg >= 4) sm_up_loop<4>(A, lda, Wl, ldw, K, N, tiles, ks, part, pld, wave, lane);
-    else if (tg == 3) sm_up_loop<3>(A, lda, Wl, ldw, K, N, tiles, ks, part, pld, wave, lane);
-    else if (tg == 2) sm_up_loop<2>(A, lda, Wl, ldw, K, N, tiles, ks, part, pld, wave, lane);
-    else sm_up_loop<1>(A, lda, Wl, ldw, K, N, tiles, ks, part, pld, wave, lane);
+    const int bi = (lane & 3) * L.ldx + (lane >> 2);
+    const int ldw = L.ldw;
+    for (int item = wave; item < L.tiles_up * L.ks_up; item += SM_NW) {
+        SM_CLK_BEGIN();
+        const int tile = item % L.tiles_up, ch = item / L.tiles_up;
+        const int k0 = ch * L.per_up;
+        const int groups = (min(L.Vp, k0 + L.per_up) - k0) >> 4;
+        lds_cf* ap = X + bi + k0;
+        lds_cf* bp = Wl + k0 * ldw + min(64 * tile + lane, ldw - 1);
+        sf32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        auto load = [&](UpFrag& f, int g) {
+            f.a = ap[16 * g];
+            lds_cf* q = bp + 16 * g * ldw;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) f.b[u] = q[u * ldw];
+        };
+        UpFrag f0, f1;
+        load(f0, 0);
+        for (int g = 0; g + 2 <= groups; g += 2) {       // (scheduling barriers: hipcc otherwise sinks each load to its first use)
+            load(f1, g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#define SM_B(U) f0.b[U]
+            SM_MMA16(acc0, acc1, f0.a, SM_B);
+#undef SM_B
+            __builtin_amdgcn_sched_barrier(0);
+            load(f0, min(g + 2, groups - 1));
+            __builtin_amdgcn_sched_barrier(0);
+#define SM_B(U) f1.b[U]
+            SM_MMA16(acc0, acc1, f1.a, SM_B);
+#undef SM_B
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (groups & 1) {
+#define SM_B(U) f0.b[U]
+            SM_MMA16(acc0, acc1, f0.a, SM_B);
+#undef SM_B
+        }
+        *(lds_f4*)(part + 4 * (ch * L.H64 + 64 * tile + lane)) = acc0 + acc1;
+        SM_CLK_ADD(48);
+    }
     { SM_CLK_BEGIN(); SM_SYNC(); SM_CLK_ADD(49); }
     SM_CLK_BEGIN();
-    const int ncol = tiles * 16;
-    for (int q = threadIdx.x; q < 4 * ncol; q += SM_NT) {
-        const int col = q % ncol, rq = q / ncol;
-        sf32x4 x = {0.f, 0.f, 0.f, 0.f};
-        for (int ch = 0; ch < ks; ++ch)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] += part[(ch * SM_ROWS + 4 * rq + e) * pld + col];
-        epi(x, 4 * rq, col);
+    for (int col = threadIdx.x; col < L.H64; col += SM_NT) {
+        sf32x4 x = *(const lds_f4*)(part + 4 * col);
+        for (int ch = 1; ch < L.ks_up; ++ch) x += *(const lds_f4*)(part + 4 * (ch * L.H64 + col));
+        epi(x, col);
     }
     SM_CLK_ADD(50);
     { SM_CLK_BEGIN(); SM_SYNC(); SM_CLK_ADD(51); }
 }
 
-template <class Pre, class Epi>
-__device__ __forceinline__ void sm_down(lds_cf* A, int lda, lds_cf* Wl, int ldw, int K, int N, int tiles,
-                                        int wave, int lane, Pre&& pre, Epi&& epi)
+template <class Epi>
+__device__ __forceinline__ void sm_down(lds_cf* Hs, lds_cf* Wl, const SmallLayout& L, int wave, int lane, Epi&& epi)
 {
-    constexpr int TG = SM_TG;
-    const int c16 = lane & 15, kq = lane >> 4;
-    const int ksteps = (K + 3) >> 2, kfull = K >> 2;
-    const int groups = (tiles + TG - 1) / TG;
-    for (int grp = wave; grp < groups; grp += SM_NW) {
+    const int bi = (lane & 3) * L.ldhs + (lane >> 2);
+    const int groups = L.Hp >> 4;
+    for (int tile = wave; tile < L.tiles_dn; tile += SM_NW) {
         SM_CLK_BEGIN();
-        sf32x4 acc[TG], fetched[TG];
-        lds_cf* bp[TG];
+        lds_cf* ap = Hs + bi;
+        const lds_f4* bp = (const lds_f4*)(Wl + min(64 * tile + lane, L.Vp - 1) * L.ldw);
+        sf32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        struct Frag { float a; sf32x4 b[4]; };
+        auto load = [&](Frag& f, int g) {
+            f.a = ap[16 * g];
 #pragma unroll
-        for (int j = 0; j < TG; ++j) {
-            acc[j] = sf32x4{0.f, 0.f, 0.f, 0.f};
-            const int n = (grp * TG + j) * 16 + c16;
-            bp[j] = Wl + min(n, N - 1) * ldw + kq;
-            fetched[j] = pre(4 * kq, n);
+            for (int q = 0; q < 4; ++q) f.b[q] = bp[4 * g + q];
+        };
+        Frag f0, f1;
+        load(f0, 0);
+        for (int g = 0; g + 2 <= groups; g += 2) {
+            load(f1, g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#define SM_B(U) f0.b[(U) >> 2][(U) & 3]
+            SM_MMA16(acc0, acc1, f0.a, SM_B);
+#undef SM_B
+            __builtin_amdgcn_sched_barrier(0);
+            load(f0, min(g + 2, groups - 1));
+            __builtin_amdgcn_sched_barrier(0);
+#define SM_B(U) f1.b[(U) >> 2][(U) & 3]
+            SM_MMA16(acc0, acc1, f1.a, SM_B);
+#undef SM_B
+            __builtin_amdgcn_sched_barrier(0);
         }
-        const int rounds = kfull >> 1;
-        sm_kloop<TG>(acc, A + c16 * lda + kq, bp, 4, 8, rounds);
-        for (int s = 2 * rounds; s < ksteps; ++s) {
-            const int k = 4 * s + kq, kc = k < K ? k : K - 1;
-            const float av = A[c16 * lda + k];
-#pragma unroll
-            for (int j = 0; j < TG; ++j) {
-                const int n = min((grp * TG + j) * 16 + c16, N - 1);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wl[n * ldw + kc], acc[j], 0, 0, 0);
-            }
+        if (groups & 1) {
+#define SM_B(U) f0.b[(U) >> 2][(U) & 3]
+            SM_MMA16(acc0, acc1, f0.a, SM_B);
+#undef SM_B
         }
         SM_CLK_ADD(52);
-        const int nt = min(TG, tiles - grp * TG);
-        for (int j = 0; j < nt; ++j) {                   // (a rolled loop: ONE copy of the epilogue's code)
-            const sf32x4 x = j == 0 ? acc[0] : j == 1 ? acc[1] : j == 2 ? acc[2] : acc[3];
-            const sf32x4 f = j == 0 ? fetched[0] : j == 1 ? fetched[1] : j == 2 ? fetched[2] : fetched[3];
-            epi(x, f, 4 * kq, (grp * TG + j) * 16 + c16);
-        }
+        epi(acc0 + acc1, 64 * tile + lane);
         SM_CLK_ADD(53);
     }
     { SM_CLK_BEGIN(); SM_SYNC(); SM_CLK_ADD(54); }
 }
 
-// S tiles += X^T M over the slab's 16 rows.  Wave w owns the 16-row tiles ti = w, w + NW, ... of S (rt of them) times ALL TH
-// tiles along H: the M fragments (TH x 4 k-steps) are read once per call, an X fragment serves TH MFMAs.
-template <int TH>
-__device__ __forceinline__ void sm_stats_t(lds_cf* Xl, int ldx, lds_cf* Ml, int ldh, int tiles_v,
-                                           sf32x4 (&accS)[SM_MAXS], int wave, int lane)
+// S tile += X^T M over the slab's 4 rows, for the positive and the negative pair at once.  Work item = (64 rows of S, 64
+// columns of S), one per wave (small_shape_ok: at most 8 items).  Here the HIDDEN means are the broadcast operand (A register:
+// lane l holds M[r][64 th + l], block u = hidden columns 4 u .. 4 u + 3) and the visible row is B (lane l = visible unit
+// 64 tv + l), so accumulator u of lane l is S[64 tv + l][64 th + 4 u .. + 3]: 16 bytes of ONE row of S, stored as such.
+__device__ __forceinline__ void sm_stats(sf32x4 (&accS)[SM_MAXQ], lds_cf* X0, lds_cf* M0, lds_cf* Xn, lds_cf* Mn,
+                                         const SmallLayout& L, int nq, int wave, int lane)
 {
-    const int c16 = lane & 15, kq = lane >> 4;
-    float b[TH][4];
+    if (wave >= L.tiles_dn * L.tiles_up) return;
+    const int tv = wave % L.tiles_dn, th = wave / L.tiles_dn;
+    float a[8], b[8];
 #pragma unroll
-    for (int tj = 0; tj < TH; ++tj)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) b[tj][s] = Ml[(4 * s + kq) * ldh + tj * 16 + c16];
-#pragma unroll
-    for (int r = 0; r < SM_MAXS / TH; ++r) {
-        const int ti = wave + SM_NW * r;
-        if (ti < tiles_v) {
-            float av[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) av[s] = Xl[(4 * s + kq) * ldx + ti * 16 + c16];
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int tj = 0; tj < TH; ++tj)
-                    accS[r * TH + tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b[tj][s], accS[r * TH + tj], 0, 0, 0);
-        }
+    for (int r = 0; r < 4; ++r) {
+        a[r] = M0[r * L.ldhs + 64 * th + lane]; b[r] = X0[r * L.ldx + 64 * tv + lane];
+        a[4 + r] = Mn[r * L.ldhs + 64 * th + lane]; b[4 + r] = Xn[r * L.ldx + 64 * tv + lane];
     }
+#define SM_STAT(U)                                                                                                     \
+    if ((U) < nq) {                                                                                                    \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) accS[U] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], b[r], accS[U], 4, U, 0); \
+    }
+    SM_STAT(0) SM_STAT(1) SM_STAT(2) SM_STAT(3) SM_STAT(4) SM_STAT(5) SM_STAT(6) SM_STAT(7)
+    SM_STAT(8) SM_STAT(9) SM_STAT(10) SM_STAT(11) SM_STAT(12) SM_STAT(13) SM_STAT(14) SM_STAT(15)
+#undef SM_STAT
 }
-
-// the finished S tiles of this wave into an LDS image [V][ld] (pad columns zero), for a coalesced copy to memory
-template <int TH>
-__device__ __forceinline__ void sm_park_t(lds_f* img, int ld, int V, int H, int tiles_v, const sf32x4 (&accS)[SM_MAXS], int wave, int lane)
-{
-    const int c16 = lane & 15, kq = lane >> 4;
-#pragma unroll
-    for (int r = 0; r < SM_MAXS / TH; ++r) {
-        const int ti = wave + SM_NW * r;
-        if (ti < tiles_v) {
-#pragma unroll
-            for (int tj = 0; tj < TH; ++tj) {
-                const int j = tj * 16 + c16;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = ti * 16 + 4 * kq + e;
-                    if (i < V && j < ld) img[i * ld + j] = j < H ? accS[r * TH + tj][e] : 0.f;
-                }
-            }
-        }
-    }
-}
-
-#define SM_TH_SWITCH(TH_, CALL)                                                               \
-    switch (TH_) {                                                                            \
-        case 1: { constexpr int TH = 1; CALL; } break;                                        \
-        case 2: { constexpr int TH = 2; CALL; } break;                                        \
-        case 3: { constexpr int TH = 3; CALL; } break;                                        \
-        case 4: { constexpr int TH = 4; CALL; } break;                                        \
-        case 5: { constexpr int TH = 5; CALL; } break;                                        \
-        case 6: { constexpr int TH = 6; CALL; } break;                                        \
-        case 7: { constexpr int TH = 7; CALL; } break;                                        \
-        default: { constexpr int TH = 8; CALL; } break;                                       \
-    }
 
 // what the passes of one slab share (plain pointers and sizes: copied into registers once)
 struct SmCtx {
-    lds_f *Wl, *Xa, *Xb, *Hs, *Ml, *part, *csP, *csN, *csV, *hbl, *vbl;
-    const int64_t* srcl;
+    lds_f *Wl, *X0, *Xa, *Xb, *Hs, *M0, *Mn, *part, *csP, *csN, *csV, *hbl, *vbl;
     int row0; uint64_t grow0;
 };
 
 // v_t | h_{t-1}: RBM sigmoid + Bernoulli (draw 2t-1), GRBM linear mean (rbm.py:647-660, error_free).  LAST: the chain's last
 // step also yields the reconstruction cost (rbm.py:372-374,449-482; GRBM :690-699: a sigmoid is applied to the linear
-// mean), the column sums of v0 - nv, and (RBM) the visible MEAN for the statistics.  TAPS: inspection copies / chain taps.
-// The flags are compile-time: a pass executes only the instructions it needs (at ~5 cycles per instruction and wave the
-// generic epilogue cost as much as the pass's MFMAs).
+// mean) against v0 (still in LDS: X0), the column sums of v0 - nv, and (RBM) the visible MEAN for the statistics.  TAPS:
+// inspection copies / chain taps.  The flags are compile-time: a pass executes only the instructions it needs (at ~5 cycles
+// per instruction and wave a generic epilogue costs more than the pass's MFMAs).
 template <bool GAUSS, bool LAST, bool TAPS>
 __device__ __forceinline__ void sm_step_down(const SmallCdArgs& a, const SmCtx& c, int t, float& cost, int wave, int lane)
 {
     const SmallLayout& L = a.L;
     const int V = a.V, B = a.B;
     const int64_t ldv = a.ldv;
-    const sf32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    sm_down(c.Hs, L.ldhs, c.Wl, L.ldw, a.H, V, L.tiles_dn, wave, lane,
-            [&](int r0, int col) -> sf32x4 {
-                sf32x4 tg = zero4;          // the reconstruction target (v0 through the minibatch index), requested early
-                if (LAST && col < V) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (c.row0 + r0 + e < B) tg[e] = a.data[c.srcl[r0 + e] * a.ld_data + col];
-                }
-                return tg;
-            },
-            [&](const sf32x4& x, const sf32x4& tg, int r0, int col) {
+    sm_down(c.Hs, c.Wl, L, wave, lane,
+            [&](const sf32x4& x, int col) {
                 // (every LDS read first, every LDS write last: hipcc cannot tell the buffers apart and would otherwise
                 // serialise a read behind each write -- a round trip per element)
                 const bool live = col < V;
                 const float bias = c.vbl[col];
+                float tg[4] = {0.f, 0.f, 0.f, 0.f};
+                if (LAST) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tg[e] = c.X0[e * L.ldx + col];
+                }
+                const float cs0 = LAST ? c.csV[col] : 0.f;
                 uint32_t w[4] = {0u, 0u, 0u, 0u};
-                if (!GAUSS) philox_rows4(a.rng, (uint32_t)(2 * t - 1), c.grow0 + (uint64_t)r0, (uint32_t)col, w);
+                if (!GAUSS) philox_rows4(a.rng, (uint32_t)(2 * t - 1), c.grow0, (uint32_t)col, w);
                 float m[4], sv[4], cs = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const bool ok = live && c.row0 + r0 + e < B;
+                    const bool ok = live && c.row0 + e < B;
                     const float pre = x[e] + bias;
                     sv[e] = 0.f;
                     if (GAUSS) m[e] = ok ? pre : 0.f;
@@ -330,13 +257,14 @@ __device__ __forceinline__ void sm_step_down(const SmallCdArgs& a, const SmCtx& 
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    c.Xa[(r0 + e) * L.ldx + col] = GAUSS ? m[e] : sv[e];
-                    if (!GAUSS && LAST) c.Xb[(r0 + e) * L.ldx + col] = m[e];
+                    c.Xa[e * L.ldx + col] = GAUSS ? m[e] : sv[e];
+                    if (!GAUSS && LAST) c.Xb[e * L.ldx + col] = m[e];
                 }
+                if (LAST) c.csV[col] = cs0 + cs;        // (a column belongs to one lane)
                 if (TAPS && col < (int)ldv) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int row = c.row0 + r0 + e;
+                        const int row = c.row0 + e;
                         if (row < B) {
                             if (LAST && a.keep) a.V2[(int64_t)(B + row) * ldv + col] = m[e];
                             if (!GAUSS) {
@@ -346,11 +274,6 @@ __device__ __forceinline__ void sm_step_down(const SmallCdArgs& a, const SmCtx& 
                         }
                     }
                 }
-                if (LAST) {     // the four row quads of this column are lanes c, c + 16, c + 32, c + 48 of this wave
-                    const float q0 = __shfl(cs, lane & 15, 64), q1 = __shfl(cs, (lane & 15) + 16, 64);
-                    const float q2 = __shfl(cs, (lane & 15) + 32, 64), q3 = __shfl(cs, (lane & 15) + 48, 64);
-                    if (lane < 16) c.csV[col] += (q0 + q1) + (q2 + q3);
-                }
             });
 }
 
@@ -358,40 +281,42 @@ __device__ __forceinline__ void sm_step_down(const SmallCdArgs& a, const SmCtx& 
 // positive phase (mean kept for the statistics + sample, draw 0); 1: a middle step (sample only, draw 2t); 2: the chain's
 // end (-nh for the statistics, no sample: CD does not materialise it).
 template <int KIND, bool TAPS>
-__device__ __forceinline__ void sm_step_up(const SmallCdArgs& a, const SmCtx& c, int t, int wave, int lane)
+__device__ __forceinline__ void sm_step_up(const SmallCdArgs& a, const SmCtx& c, lds_cf* X, int t, int wave, int lane)
 {
     const SmallLayout& L = a.L;
     const int H = a.H, B = a.B;
     const int64_t ldh = a.ldh;
-    sm_up(c.Xa, L.ldx, c.Wl, L.ldw, a.V, H, L.tiles_up, L.tg_up, L.ks_up, c.part, L.pld, wave, lane,
-          [&](const sf32x4& x, int r0, int col) {
+    sm_up(X, c.Wl, L, c.part, wave, lane,
+          [&](const sf32x4& x, int col) {
               const bool live = col < H;
               const float bias = c.hbl[col];
+              lds_f* cd = (KIND == 2 ? c.csN : c.csP) + col;
+              const float cs0 = KIND != 1 ? *cd : 0.f;
               uint32_t w[4] = {0u, 0u, 0u, 0u};
-              if (KIND != 2) philox_rows4(a.rng, (uint32_t)(2 * t), c.grow0 + (uint64_t)r0, (uint32_t)col, w);
+              if (KIND != 2) philox_rows4(a.rng, (uint32_t)(2 * t), c.grow0, (uint32_t)col, w);
               float m[4], sv[4], cs = 0.f;
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                  const bool ok = live && c.row0 + r0 + e < B;
+                  const bool ok = live && c.row0 + e < B;
                   const float p = ok ? sigmoidf_(x[e] + bias) : 0.f;
                   m[e] = KIND == 2 ? -p : p;
                   cs += m[e];
                   sv[e] = (KIND != 2 && ok && philox_u01(w[e]) < p) ? 1.0f : 0.0f;
               }
               if (KIND != 1) {
+                  lds_f* Ml = KIND == 2 ? c.Mn : c.M0;
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) c.Ml[(r0 + e) * L.ldhs + col] = m[e];
-                  lds_f* cd = (KIND == 2 ? c.csN : c.csP) + (r0 >> 2) * L.Hp + col;
-                  *cd += cs;
+                  for (int e = 0; e < 4; ++e) Ml[e * L.ldhs + col] = m[e];
+                  *cd = cs0 + cs;
               }
               if (KIND != 2) {
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) c.Hs[(r0 + e) * L.ldhs + col] = sv[e];
+                  for (int e = 0; e < 4; ++e) c.Hs[e * L.ldhs + col] = sv[e];
               }
               if (TAPS && col < (int)ldh) {
 #pragma unroll
                   for (int e = 0; e < 4; ++e) {
-                      const int row = c.row0 + r0 + e;
+                      const int row = c.row0 + e;
                       if (row < B) {
                           if (KIND != 1 && a.keep) a.P2[(int64_t)((KIND == 2 ? B : 0) + row) * ldh + col] = m[e];
                           if (KIND != 2) {
@@ -414,19 +339,19 @@ __global__ __launch_bounds__(SM_NT) void small_cd_kernel(SmallCdArgs a)
     lds_f* const lds = (lds_f*)sm;
     SmCtx c;
     c.Wl = lds + L.oW;
-    c.Xa = lds + L.oXa;             // visible operand of the next propup (v0; GRBM: nv mean; RBM: v sample)
+    c.X0 = lds + L.oX0;             // v0: operand of the positive phase, target of the reconstruction cost, statistics
+    c.Xa = lds + L.oXa;             // visible operand of the next propup (GRBM: nv mean; RBM: v sample)
     c.Xb = lds + L.oXb;             // RBM, last Gibbs step: nv MEAN (the statistics use the mean, the chain the sample)
     c.Hs = lds + L.oHs;             // hidden sample (operand of the next propdown)
-    c.Ml = lds + L.oMl;             // hidden mean for the statistics: ph, then -nh
+    c.M0 = lds + L.oM0;             // ph
+    c.Mn = lds + L.oMn;             // -nh
     c.part = lds + L.oPart;
-    c.csP = lds + L.oCsP;           // [4][Hp] per-row-quad column sums of  ph
-    c.csN = lds + L.oCsN;           // [4][Hp]                              -nh
-    c.csV = lds + L.oCsV;           // [Vp] column sums of v0 - nv (the four row quads of a column sit in one wave)
+    c.csP = lds + L.oCsP;           // [H64] column sums of  ph over this workgroup's slabs
+    c.csN = lds + L.oCsN;           //                       -nh
+    c.csV = lds + L.oCsV;           // [V64] column sums of v0 - nv
     c.hbl = lds + L.oHb;
     c.vbl = lds + L.oVb;
     float* const red = sm + L.oRed;
-    int64_t* const srcl = reinterpret_cast<int64_t*>(sm + L.oSrc);
-    c.srcl = srcl;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int V = a.V, H = a.H, B = a.B;
     const int64_t ldv = a.ldv, ldh = a.ldh;
@@ -443,89 +368,88 @@ __global__ __launch_bounds__(SM_NT) void small_cd_kernel(SmallCdArgs a)
 #endif
     SM_STAMP();
 
-    // ---- the first slab's source rows, then W (+ biases) and the slab's rows in ONE burst of loads; the column-sum partials
-    //      start at zero.  W rows are float4-aligned in LDS (pitch ldw >= ldh; the pad columns of W are zero in memory)
-    {   // W first (the long burst), the small loads behind it: vector-memory loads return in order, so a short dependent
-        // load (index -> LDS) issued ahead of the burst would hold every W store back by its own latency
-        const int q4 = (int)(ldh >> 2);
-        for (int e = tid; e < V * q4; e += SM_NT) {
-            const int r = e / q4, c4 = e - r * q4;
-            *(lds_f4*)(c.Wl + r * L.ldw + 4 * c4) = *reinterpret_cast<const sf32x4*>(a.W + (int64_t)r * ldh + 4 * c4);
+    // ---- W (+ biases) into LDS: image [Vp][ldw], rows >= V and columns >= ldh zero (the pad columns of W below ldh are zero
+    //      in memory); the column-sum partials start at zero
+    {
+        const int q4w = L.ldw >> 2, q4 = (int)(ldh >> 2);
+        const int total = L.Vp * q4w + 4;                            // (+ the slack behind the last row)
+        int r = tid / q4w, c4 = tid - r * q4w;
+        const int dr = SM_NT / q4w, dc = SM_NT - dr * q4w;
+        for (int e = tid; e < total; e += SM_NT) {
+            sf32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < V && c4 < q4) v = *reinterpret_cast<const sf32x4*>(a.W + (int64_t)r * ldh + 4 * c4);
+            *(lds_f4*)(c.Wl + 4 * e) = v;
+            r += dr; c4 += dc;
+            if (c4 >= q4w) { c4 -= q4w; ++r; }
         }
     }
-    if (tid < SM_ROWS) {
-        const int row = (int)blockIdx.x * SM_ROWS + tid;
-        srcl[tid] = row < B ? sm_src_row(a, row) : 0;
-    }
-    for (int e = tid; e < L.Hp; e += SM_NT) c.hbl[e] = e < H ? a.hbias[e] : 0.f;
-    for (int e = tid; e < L.Vp; e += SM_NT) { c.vbl[e] = e < V ? a.vbias[e] : 0.f; c.csV[e] = 0.f; }
-    for (int e = tid; e < 4 * L.Hp; e += SM_NT) { c.csP[e] = 0.f; c.csN[e] = 0.f; }
-    sf32x4 accS[SM_MAXS];
+    for (int e = tid; e < L.H64; e += SM_NT) { c.hbl[e] = e < H ? a.hbias[e] : 0.f; c.csP[e] = 0.f; c.csN[e] = 0.f; }
+    for (int e = tid; e < L.V64; e += SM_NT) { c.vbl[e] = e < V ? a.vbias[e] : 0.f; c.csV[e] = 0.f; }
+    sf32x4 accS[SM_MAXQ];
 #pragma unroll
-    for (int u = 0; u < SM_MAXS; ++u) accS[u] = sf32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < SM_MAXQ; ++u) accS[u] = sf32x4{0.f, 0.f, 0.f, 0.f};
     float cost = 0.f;
+    // 4-column groups of S this wave's statistics tile holds (the columns up to ldh are stored: pads as exact zeros)
+    const int th_w = wave / L.tiles_dn, tv_w = wave - th_w * L.tiles_dn;
+    const int nq = max(0, min(SM_MAXQ, ((int)ldh - 64 * th_w) >> 2));
 
     for (int slab = blockIdx.x; slab < nslabs; slab += gridDim.x) {
         c.row0 = slab * SM_ROWS;
         c.grow0 = a.rng.row_offset + (uint64_t)c.row0;                 // global row of the slab's first row (Philox address)
-        if (slab != (int)blockIdx.x) {
-            SM_SYNC();                                                // (the previous slab's last readers are done)
-            if (tid < SM_ROWS) srcl[tid] = c.row0 + tid < B ? sm_src_row(a, c.row0 + tid) : 0;
-        }
-        SM_SYNC();
+        if (slab != (int)blockIdx.x) SM_SYNC();                        // (the previous slab's last readers are done)
         SM_STAMP();
-        // ---- x = train_set_x[indexes] (dbn.py:307): 16 rows into LDS
+        // ---- x = train_set_x[indexes] (dbn.py:307): 4 rows into LDS (every thread resolves its own source row)
         {
             const int q4 = L.ldx >> 2, dq4 = (int)(ldv >> 2);
             for (int e = tid; e < SM_ROWS * q4; e += SM_NT) {
                 const int r = e / q4, c4 = e - r * q4;
                 sf32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (c.row0 + r < B && c4 < dq4) {
-                    v = *reinterpret_cast<const sf32x4*>(a.data + srcl[r] * a.ld_data + 4 * c4);
+                    v = *reinterpret_cast<const sf32x4*>(a.data + sm_src_row(a, c.row0 + r) * a.ld_data + 4 * c4);
                     if (TAPS && a.keep) *reinterpret_cast<sf32x4*>(a.V2 + (int64_t)(c.row0 + r) * ldv + 4 * c4) = v;
                 }
-                *(lds_f4*)(c.Xa + r * L.ldx + 4 * c4) = v;
+                *(lds_f4*)(c.X0 + r * L.ldx + 4 * c4) = v;
             }
         }
         SM_SYNC();
         SM_STAMP();
-        // ---- positive phase (rbm.py:303), S += v0^T ph
-        sm_step_up<0, TAPS>(a, c, 0, wave, lane);
-        SM_STAMP();
-        SM_TH_SWITCH(L.tiles_up, (sm_stats_t<TH>(c.Xa, L.ldx, c.Ml, L.ldhs, L.tiles_dn, accS, wave, lane)));
-        SM_SYNC();
+        // ---- positive phase (rbm.py:303)
+        sm_step_up<0, TAPS>(a, c, c.X0, 0, wave, lane);
         SM_STAMP();
         // ---- k x gibbs_hvh (rbm.py:242-248, GRBM :662-671)
         for (int t = 1; t < k_steps; ++t) {
             sm_step_down<GAUSS, false, TAPS>(a, c, t, cost, wave, lane);
             SM_STAMP();
-            sm_step_up<1, TAPS>(a, c, t, wave, lane);
+            sm_step_up<1, TAPS>(a, c, c.Xa, t, wave, lane);
             SM_STAMP();
         }
         sm_step_down<GAUSS, true, TAPS>(a, c, k_steps, cost, wave, lane);
         SM_STAMP();
-        sm_step_up<2, TAPS>(a, c, k_steps, wave, lane);
+        sm_step_up<2, TAPS>(a, c, c.Xa, k_steps, wave, lane);
         SM_STAMP();
-        // ---- S += nv_mean^T (-nh_mean)
-        SM_TH_SWITCH(L.tiles_up, (sm_stats_t<TH>(GAUSS ? c.Xa : c.Xb, L.ldx, c.Ml, L.ldhs, L.tiles_dn, accS, wave, lane)));
+        // ---- S += v0^T ph + nv_mean^T (-nh_mean)
+        sm_stats(accS, c.X0, c.M0, GAUSS ? c.Xa : c.Xb, c.Mn, L, nq, wave, lane);
         SM_STAMP();
     }
-    SM_SYNC();
 
-    // ---- this workgroup's partials: S through an LDS image (the W region is free now) in whole 16-byte pieces, the column
-    //      sums (quads combined in a fixed order), the cost
-    {
-        SM_TH_SWITCH(L.tiles_up, (sm_park_t<TH>(c.Wl, (int)ldh, V, H, L.tiles_dn, accS, wave, lane)));
-        SM_SYNC();
-        sf32x4* Sp = reinterpret_cast<sf32x4*>(a.part_S + (int64_t)blockIdx.x * V * ldh);
-        const int n4 = V * (int)(ldh >> 2);
-        for (int e = tid; e < n4; e += SM_NT) Sp[e] = *(const lds_f4*)(c.Wl + 4 * e);
-        for (int j = tid; j < (int)ldh; j += SM_NT) {
-            const bool in = j < L.Hp;
-            a.posP[(int64_t)blockIdx.x * ldh + j] = in ? (c.csP[j] + c.csP[L.Hp + j]) + (c.csP[2 * L.Hp + j] + c.csP[3 * L.Hp + j]) : 0.f;
-            a.negP[(int64_t)blockIdx.x * ldh + j] = in ? (c.csN[j] + c.csN[L.Hp + j]) + (c.csN[2 * L.Hp + j] + c.csN[3 * L.Hp + j]) : 0.f;
+    // ---- this workgroup's partials: a lane holds 16-byte pieces of ONE row of S (64 tv + lane), stored as such; the column
+    //      sums; the cost
+    if (wave < L.tiles_dn * L.tiles_up) {
+        const int v = 64 * tv_w + lane;
+        if (v < V) {
+            sf32x4* Sp = reinterpret_cast<sf32x4*>(a.part_S + (int64_t)blockIdx.x * V * ldh + (int64_t)v * ldh + 64 * th_w);
+#define SM_PUT(U) if ((U) < nq) Sp[U] = accS[U];
+            SM_PUT(0) SM_PUT(1) SM_PUT(2) SM_PUT(3) SM_PUT(4) SM_PUT(5) SM_PUT(6) SM_PUT(7)
+            SM_PUT(8) SM_PUT(9) SM_PUT(10) SM_PUT(11) SM_PUT(12) SM_PUT(13) SM_PUT(14) SM_PUT(15)
+#undef SM_PUT
         }
-        for (int i = tid; i < (int)ldv; i += SM_NT) a.partV[(int64_t)blockIdx.x * ldv + i] = i < L.Vp ? c.csV[i] : 0.f;
+    }
+    for (int j = tid; j < (int)ldh; j += SM_NT) {
+        a.posP[(int64_t)blockIdx.x * ldh + j] = j < L.H64 ? c.csP[j] : 0.f;
+        a.negP[(int64_t)blockIdx.x * ldh + j] = j < L.H64 ? c.csN[j] : 0.f;
+    }
+    for (int i = tid; i < (int)ldv; i += SM_NT) a.partV[(int64_t)blockIdx.x * ldv + i] = i < L.V64 ? c.csV[i] : 0.f;
+    {
         const float tot = block_sum(cost, red);
         if (tid == 0) a.cost_partials[blockIdx.x] = tot;
     }
@@ -544,16 +468,22 @@ int small_blocks(int64_t B)
 
 bool small_shape_ok(int64_t B, int64_t V, int64_t H, int gauss)
 {
-    if (B < 1 || V < 1 || H < 1 || V > 4096 || H > 4096) return false;
+    if (B < 1 || V < 1 || H < 1 || V > 512 || H > 512) return false;
     const SmallLayout L = small_layout((int)V, (int)H, gauss != 0);
     if (L.bytes > SM_MAX_LDS) return false;
-    return L.tiles_up <= SM_MAXTH && L.rt * L.tiles_up <= SM_MAXS;
+    return L.tiles_dn * L.tiles_up <= SM_NW;        // one 64 x 64 tile of S per wave
+}
+
+bool small_ld_ok(int64_t V, int64_t H, int64_t ldv, int64_t ldh)
+{
+    const SmallLayout L = small_layout((int)V, (int)H, false);
+    return ldh % 4 == 0 && ldv % 4 == 0 && ldh >= H && ldv >= V && ldh <= L.ldw && ldh <= L.H64 && ldv <= L.ldx;
 }
 
 hipError_t launch_small_cd(const SmallCdArgs& a, hipStream_t s)
 {
     const SmallLayout L = small_layout(a.V, a.H, a.gauss != 0);
-    if (!small_shape_ok(a.B, a.V, a.H, a.gauss)) return hipErrorInvalidValue;
+    if (!small_shape_ok(a.B, a.V, a.H, a.gauss) || !small_ld_ok(a.V, a.H, a.ldv, a.ldh)) return hipErrorInvalidValue;
     const bool taps = a.keep || a.trace_h || a.trace_v;
     const int variant = (a.gauss ? 2 : 0) | (taps ? 1 : 0);
     static bool attr_set[4] = {false, false, false, false};
@@ -577,26 +507,38 @@ hipError_t launch_small_cd(const SmallCdArgs& a, hipStream_t s)
 }
 
 // ----------------------------------------------------------------------------------
-// Second launch: S = sum of the workgroups' partials (workgroup order), then either the parameter update of rbm.py:347-365
-// on it (single device: update_rule4, as update_kernel) or a plain store into the statistics buffer (data-parallel: the
-// all-reduce follows); the trailing blocks run the finalize units (bias statistics, cost, bias half of the update).
+// Second launch: S = sum of the workgroups' partials, then either the parameter update of rbm.py:347-365 on it (single
+// device: update_rule4, as update_kernel) or a plain store into the statistics buffer (data-parallel: the all-reduce
+// follows); the trailing blocks run the finalize units (bias statistics, cost, bias half of the update).  `lanes` threads
+// share one float4 of S: each sums a contiguous run of the partials in workgroup order (8 loads in flight), the runs are
+// combined by a butterfly -- a fixed tree, the same in every lane -- so up to 128 partials cost two rounds of loads.
 // ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinArgs f)
 {
-    const int nbw = (int)((f.n4 + 255) / 256);
+    const int G = f.lanes, ipb = 256 / G;
+    const int nbw = (int)((f.n4 + ipb - 1) / ipb);
     if ((int)blockIdx.x < nbw) {
-        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-        if (i >= f.n4) return;
+        const int sub = threadIdx.x & (G - 1);
+        const int64_t i = (int64_t)blockIdx.x * ipb + threadIdx.x / G;
+        const bool in = i < f.n4;
+        const int per = (f.nparts + G - 1) / G;
+        const int pb = sub * per, pe = min(f.nparts, pb + per);
         const float4* P = reinterpret_cast<const float4*>(f.part);
+        const int64_t ps4 = f.part_stride >> 2;
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int p0 = 0; p0 < f.nparts; p0 += 8) {         // 8 loads in flight, summed in workgroup order
+        for (int p0 = pb; p0 < pe; p0 += 8) {
             float4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                v[u] = p0 + u < f.nparts ? P[i + (int64_t)(p0 + u) * (f.part_stride >> 2)] : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[u] = (in && p0 + u < pe) ? P[i + (int64_t)(p0 + u) * ps4] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int u = 0; u < 8; ++u) { s4.x += v[u].x; s4.y += v[u].y; s4.z += v[u].z; s4.w += v[u].w; }
         }
+        for (int off = 1; off < G; off <<= 1) {
+            s4.x += __shfl_xor(s4.x, off, 64); s4.y += __shfl_xor(s4.y, off, 64);
+            s4.z += __shfl_xor(s4.z, off, 64); s4.w += __shfl_xor(s4.w, off, 64);
+        }
+        if (!in || sub != 0) return;
         if (!f.do_upd) {
             reinterpret_cast<float4*>(f.S_out)[i] = s4;
             return;
@@ -615,9 +557,12 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinArgs f)
     }
 }
 
-hipError_t launch_small_finish(const SmallFinArgs& f, hipStream_t s)
+hipError_t launch_small_finish(const SmallFinArgs& f0, hipStream_t s)
 {
-    const int nbw = (int)((f.n4 + 255) / 256);
+    SmallFinArgs f = f0;
+    f.lanes = f.nparts >= 32 ? 8 : f.nparts >= 12 ? 4 : f.nparts >= 4 ? 2 : 1;
+    const int ipb = 256 / f.lanes;
+    const int nbw = (int)((f.n4 + ipb - 1) / ipb);
     const int nbf = ((int)((f.fin.ldh + f.fin.ldv + 15) / 16) + 1 + 3) / 4;       // fin_units + the cost unit, four waves per block
     hipLaunchKernelGGL(small_finish_kernel, dim3(nbw + nbf), dim3(256), 0, s, f);
     return hipGetLastError();

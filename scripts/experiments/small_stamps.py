@@ -39,7 +39,7 @@ names = ["stage W", "gather"]
 for t in range(K + 1):
     if t > 0: names.append("down t=%d" % t)
     names.append("up t=%d" % t)
-    if t == 0 or t == K: names.append("stats")
+    if t == K: names.append("stats")
 names.append("write partials")
 print("shape %s: total %.1f us in workgroup 0; shader clock over the kernel: %.0f MHz" % (os.environ.get("MDBN_AB_SHAPE"), d.sum(), mhz))
 print("  wave 0 cycles per step: up k-loop %d, sync %d, up epilogue %d, sync %d | down k-loop %d (cumulative), +epilogue %d, sync %d"
