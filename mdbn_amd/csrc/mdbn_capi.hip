@@ -368,7 +368,7 @@ WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
         s.slab = std::max<int64_t>(s.slab, (int64_t)kMaxBalBlocks * 2 * 16384);
     }
     if (small_shape_ok(B, V, H, 0) || small_shape_ok(B, V, H, 1))       // one S partial per workgroup of the one-launch step
-        s.slab = std::max<int64_t>(s.slab, (int64_t)small_blocks(B) * V * ldh);
+        s.slab = std::max<int64_t>(s.slab, (int64_t)small_blocks(B) * ((V + 63) & ~int64_t(63)) * ldh);   // (pad lanes included)
     s.slab = std::max<int64_t>(s.slab, 4 * std::max(ldv, ldh) * 8);
     s.cost = std::max<int64_t>(256, (((B + 3) / 4) * std::max(ldv, ldh) + 63) / 64) + 64;   // worst case: one column per thread, 64-thread blocks
     // fused epilogues write one partial per block: 128 x 64 tiles, or 32-column strips (skinny)
@@ -1444,7 +1444,7 @@ static bool small_eligible(const mdbn_cd_args* a, const Workspace& ws)
     if (!a->gauss && a->vs == nullptr) return false;
     if (a->B > 65535 * 16 || !small_shape_ok(a->B, a->V, a->H, a->gauss) || !small_ld_ok(a->V, a->H, a->ldv, a->ldh)) return false;
     const int nb = small_blocks(a->B);
-    return (int64_t)nb * a->V * a->ldh <= ws.slab_floats && nb <= ws.cost_floats && nb <= row_groups(a->B);
+    return (int64_t)nb * ((a->V + 63) & ~int64_t(63)) * a->ldh <= ws.slab_floats && nb <= ws.cost_floats && nb <= row_groups(a->B);
 }
 
 // mode 0: the whole step; 1: the chain + partials only (mdbn_cd_forward); 2: the finish launch (mdbn_cd_statistics).
@@ -1480,7 +1480,11 @@ static int cd_step_small(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, co
     float* s_v = s_h + ldh;
     float* cost = s_v + ldv;
     SmallFinArgs f{};
-    f.part = ws.slabs; f.nparts = nb; f.part_stride = V * ldh; f.n4 = V * ldh / 4;
+    {
+        const SmallLayout L = small_layout((int)V, (int)H, a->gauss != 0);
+        f.part = ws.slabs; f.nparts = nb; f.n4p = small_part_quads(L, (int)ldh);
+        f.V = (int)V; f.q4 = (int)(ldh >> 2); f.tiles_dn = L.tiles_dn;
+    }
     f.S_out = a->stats;
     BiasUpd bu;
     // mdbn_set_option("fused_update", 0): the statistics are materialised and the update is its own launch (update_kernel)

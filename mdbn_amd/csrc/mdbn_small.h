@@ -31,8 +31,15 @@ __host__ __device__ inline SmallLayout small_layout(int V, int H, bool gauss)
     SmallLayout L;
     L.Vp = (V + 15) & ~15; L.Hp = (H + 15) & ~15;
     L.V64 = (V + 63) & ~63; L.H64 = (H + 63) & ~63;
-    L.ldw = (H + 3) & ~3;
-    if (((L.ldw >> 2) & 1) == 0) L.ldw += 4;
+    // a few fixed pitches for the usual widths (propup's loop is compiled for each: immediate offsets instead of address adds)
+    if (H <= 20) L.ldw = 20;
+    else if (H <= 44) L.ldw = 44;
+    else if (H <= 68) L.ldw = 68;
+    else if (H <= 132) L.ldw = 132;
+    else {
+        L.ldw = (H + 3) & ~3;
+        if (((L.ldw >> 2) & 1) == 0) L.ldw += 4;
+    }
     L.ldx = L.V64 + 8; L.ldhs = L.H64 + 8;
     L.tiles_up = L.H64 / 64; L.tiles_dn = L.V64 / 64;
     {
@@ -68,7 +75,7 @@ struct SmallCdArgs {
     PhiloxKey rng;                                   // .draw unused (the step numbers its own draws)
     SmallLayout L;                                   // LDS layout (small_layout; filled in by launch_small_cd)
     // one partial per workgroup
-    float* part_S;                                   // [blocks][V * ldh]
+    float* part_S;                                   // [blocks][small_part_quads] float4, in the lanes' order (mdbn_small.hip)
     float* posP; float* negP;                        // [blocks][ldh]: sum_rows ph, sum_rows -nh
     float* partV;                                    // [blocks][ldv]: sum_rows (v0 - nv)
     float* cost_partials;                            // [blocks]
@@ -78,11 +85,15 @@ struct SmallCdArgs {
     unsigned long long* stamps;                      // diagnostics (mdbn_set_stamp_buffer): wall-clock stamps of workgroup 0's phases
 };
 
+// 16-byte pieces of one workgroup's S partial: ldh / 4 pieces for each of the V64 lanes (pad lanes hold zeros)
+__host__ __device__ inline int small_part_quads(const SmallLayout& L, int ldh) { return (ldh >> 2) * L.V64; }
+
 struct SmallFinArgs {
-    const float* part; int nparts; int64_t part_stride;      // S partials
-    int64_t n4;                                               // V * ldh / 4
-    int lanes;                                                // threads that share the sum of one float4 of S (1, 2, 4 or 8)
-    float* S_out;                                             // do_upd == 0: the summed S goes here
+    const float* part; int nparts;                            // S partials, small_part_quads float4 each, in the lanes' order
+    int64_t n4p;                                              // small_part_quads
+    int V, q4, tiles_dn;                                      // rows of S, ldh / 4, V64 / 64: to decode a position
+    int lanes;                                                // threads that share the sum of one float4 of S (1, 2, 4, 8 or 16)
+    float* S_out;                                             // do_upd == 0: the summed S goes here ([V][ldh])
     int do_upd;
     UpdEpi upd;
     FinArgs fin;

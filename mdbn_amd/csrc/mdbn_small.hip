@@ -85,11 +85,14 @@ __device__ __forceinline__ int64_t sm_src_row(const SmallCdArgs& a, int row)
 // column) per 4 k-steps; the wave applies `epi` to its accumulator registers.
 struct UpFrag { float a; float b[16]; };
 
-template <class Epi>
-__device__ __forceinline__ void sm_up(lds_cf* X, lds_cf* Wl, const SmallLayout& L, lds_f* part, int wave, int lane, Epi&& epi)
+// LDW: W's LDS pitch as a compile-time constant (small_layout hands out 20 / 44 / 68 / 132 for H <= 132) -- the 16 reads of a
+// group are then one base register + immediate offsets; with a run-time pitch (LDW = 0) each read costs an address add, and
+// the loop is bound by its instruction count (57 instead of 34 per 16 MFMAs: 0.96 us per pass at 512 -> 40, stamped).
+template <int LDW>
+__device__ __forceinline__ void sm_up_loop(lds_cf* X, lds_cf* Wl, const SmallLayout& L, lds_f* part, int wave, int lane)
 {
     const int bi = (lane & 3) * L.ldx + (lane >> 2);
-    const int ldw = L.ldw;
+    const int ldw = LDW ? LDW : L.ldw;
     for (int item = wave; item < L.tiles_up * L.ks_up; item += SM_NW) {
         SM_CLK_BEGIN();
         const int tile = item % L.tiles_up, ch = item / L.tiles_up;
@@ -127,6 +130,18 @@ __device__ __forceinline__ void sm_up(lds_cf* X, lds_cf* Wl, const SmallLayout& 
         }
         *(lds_f4*)(part + 4 * (ch * L.H64 + 64 * tile + lane)) = acc0 + acc1;
         SM_CLK_ADD(48);
+    }
+}
+
+template <class Epi>
+__device__ __forceinline__ void sm_up(lds_cf* X, lds_cf* Wl, const SmallLayout& L, lds_f* part, int wave, int lane, Epi&& epi)
+{
+    switch (L.ldw) {
+        case 20: sm_up_loop<20>(X, Wl, L, part, wave, lane); break;
+        case 44: sm_up_loop<44>(X, Wl, L, part, wave, lane); break;
+        case 68: sm_up_loop<68>(X, Wl, L, part, wave, lane); break;
+        case 132: sm_up_loop<132>(X, Wl, L, part, wave, lane); break;
+        default: sm_up_loop<0>(X, Wl, L, part, wave, lane); break;
     }
     { SM_CLK_BEGIN(); SM_SYNC(); SM_CLK_ADD(49); }
     SM_CLK_BEGIN();
@@ -368,23 +383,56 @@ __global__ __launch_bounds__(SM_NT) void small_cd_kernel(SmallCdArgs a)
 #endif
     SM_STAMP();
 
-    // ---- W (+ biases) into LDS: image [Vp][ldw], rows >= V and columns >= ldh zero (the pad columns of W below ldh are zero
-    //      in memory); the column-sum partials start at zero
+    // ---- every first-touch load of the workgroup in ONE burst (a round trip to memory another XCD just wrote is ~2 us, and
+    //      four dependent ones -- W, biases, index, rows -- were 3.6 us of a 17-us kernel): the first slab's source-row indices
+    //      first, the biases and the first batch of W behind them, then the slab's rows as soon as the indices are back
+    //      (vector-memory loads return in order: waiting for the oldest does not wait for the rest).
+    const int q4x = L.ldx >> 2, dq4 = (int)(ldv >> 2);
+    auto gather_where = [&](int j, int row0, int& r, int& c4) -> bool {      // element j of this thread: (row r, 16-byte piece c4)
+        const int e = tid + j * SM_NT;
+        r = e / q4x; c4 = e - r * q4x;
+        return e < SM_ROWS * q4x && row0 + r < B && c4 < dq4;
+    };
+    const int row0_first = (int)blockIdx.x * SM_ROWS;
+    int64_t srow[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { int r, c4; if (gather_where(j, row0_first, r, c4)) srow[j] = sm_src_row(a, row0_first + r); }
+    const float hb_r = tid < H ? a.hbias[tid] : 0.f, vb_r = tid < V ? a.vbias[tid] : 0.f;       // (H, V <= 512 = SM_NT)
+    sf32x4 xg[2];
     {
+        // W image [Vp][ldw]: rows >= V and columns >= ldh zero (the pad columns of W below ldh are zero in memory).  Batches
+        // of SM_WB loads per thread in flight, then their LDS stores.
         const int q4w = L.ldw >> 2, q4 = (int)(ldh >> 2);
         const int total = L.Vp * q4w + 4;                            // (+ the slack behind the last row)
-        int r = tid / q4w, c4 = tid - r * q4w;
         const int dr = SM_NT / q4w, dc = SM_NT - dr * q4w;
-        for (int e = tid; e < total; e += SM_NT) {
-            sf32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < V && c4 < q4) v = *reinterpret_cast<const sf32x4*>(a.W + (int64_t)r * ldh + 4 * c4);
-            *(lds_f4*)(c.Wl + 4 * e) = v;
-            r += dr; c4 += dc;
-            if (c4 >= q4w) { c4 -= q4w; ++r; }
+        int r = tid / q4w, c4 = tid - r * q4w;
+        constexpr int SM_WB = 12;
+        for (int e0 = tid; e0 < total || e0 == tid; e0 += SM_WB * SM_NT) {
+            sf32x4 v[SM_WB];
+#pragma unroll
+            for (int u = 0; u < SM_WB; ++u) {
+                v[u] = sf32x4{0.f, 0.f, 0.f, 0.f};
+                if (r < V && c4 < q4) v[u] = *reinterpret_cast<const sf32x4*>(a.W + (int64_t)r * ldh + 4 * c4);
+                r += dr; c4 += dc;
+                if (c4 >= q4w) { c4 -= q4w; ++r; }
+            }
+            if (e0 == tid) {                                         // the first slab's rows ride behind the first batch
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    int rr, cc;
+                    xg[j] = sf32x4{0.f, 0.f, 0.f, 0.f};
+                    if (gather_where(j, row0_first, rr, cc)) xg[j] = *reinterpret_cast<const sf32x4*>(a.data + srow[j] * a.ld_data + 4 * cc);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < SM_WB; ++u)
+                if (e0 + u * SM_NT < total) *(lds_f4*)(c.Wl + 4 * (e0 + u * SM_NT)) = v[u];
         }
     }
-    for (int e = tid; e < L.H64; e += SM_NT) { c.hbl[e] = e < H ? a.hbias[e] : 0.f; c.csP[e] = 0.f; c.csN[e] = 0.f; }
-    for (int e = tid; e < L.V64; e += SM_NT) { c.vbl[e] = e < V ? a.vbias[e] : 0.f; c.csV[e] = 0.f; }
+    if (tid < L.H64) { c.hbl[tid] = hb_r; c.csP[tid] = 0.f; c.csN[tid] = 0.f; }
+    if (tid < L.V64) { c.vbl[tid] = vb_r; c.csV[tid] = 0.f; }
     sf32x4 accS[SM_MAXQ];
 #pragma unroll
     for (int u = 0; u < SM_MAXQ; ++u) accS[u] = sf32x4{0.f, 0.f, 0.f, 0.f};
@@ -398,17 +446,24 @@ __global__ __launch_bounds__(SM_NT) void small_cd_kernel(SmallCdArgs a)
         c.grow0 = a.rng.row_offset + (uint64_t)c.row0;                 // global row of the slab's first row (Philox address)
         if (slab != (int)blockIdx.x) SM_SYNC();                        // (the previous slab's last readers are done)
         SM_STAMP();
-        // ---- x = train_set_x[indexes] (dbn.py:307): 4 rows into LDS (every thread resolves its own source row)
-        {
-            const int q4 = L.ldx >> 2, dq4 = (int)(ldv >> 2);
-            for (int e = tid; e < SM_ROWS * q4; e += SM_NT) {
-                const int r = e / q4, c4 = e - r * q4;
-                sf32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (c.row0 + r < B && c4 < dq4) {
-                    v = *reinterpret_cast<const sf32x4*>(a.data + sm_src_row(a, c.row0 + r) * a.ld_data + 4 * c4);
-                    if (TAPS && a.keep) *reinterpret_cast<sf32x4*>(a.V2 + (int64_t)(c.row0 + r) * ldv + 4 * c4) = v;
-                }
-                *(lds_f4*)(c.X0 + r * L.ldx + 4 * c4) = v;
+        // ---- x = train_set_x[indexes] (dbn.py:307): 4 rows into LDS (every thread resolves its own source rows; the first
+        //      slab's are already in registers)
+        if (slab != (int)blockIdx.x) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int r, c4;
+                xg[j] = sf32x4{0.f, 0.f, 0.f, 0.f};
+                if (gather_where(j, c.row0, r, c4))
+                    xg[j] = *reinterpret_cast<const sf32x4*>(a.data + sm_src_row(a, c.row0 + r) * a.ld_data + 4 * c4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int r, c4;
+            const bool live = gather_where(j, c.row0, r, c4);
+            if (tid + j * SM_NT < SM_ROWS * q4x) {
+                *(lds_f4*)(c.X0 + r * L.ldx + 4 * c4) = xg[j];
+                if (TAPS && a.keep && live) *reinterpret_cast<sf32x4*>(a.V2 + (int64_t)(c.row0 + r) * ldv + 4 * c4) = xg[j];
             }
         }
         SM_SYNC();
@@ -432,27 +487,28 @@ __global__ __launch_bounds__(SM_NT) void small_cd_kernel(SmallCdArgs a)
         SM_STAMP();
     }
 
-    // ---- this workgroup's partials: a lane holds 16-byte pieces of ONE row of S (64 tv + lane), stored as such; the column
-    //      sums; the cost
+    // ---- this workgroup's partials: the cost first (its block sum has barriers, and a __syncthreads() waits for every global
+    //      store issued before it); then a lane's 16-byte pieces of ONE row of S (64 tv + lane), stored as such; the column sums
+    {
+        const float tot = block_sum(cost, red);
+        if (tid == 0) a.cost_partials[blockIdx.x] = tot;
+    }
+    // (layout of a partial: the 16-byte pieces in the order the lanes hold them -- [hidden tile th][visible tile tv][piece u]
+    //  [lane] -- so that every store instruction writes 1 KB of consecutive memory; stored by row of S, 160 bytes apart per
+    //  lane, the 5 120 scattered pieces of a workgroup took 2.5 us (stamped).  small_finish_kernel decodes the position.)
     if (wave < L.tiles_dn * L.tiles_up) {
-        const int v = 64 * tv_w + lane;
-        if (v < V) {
-            sf32x4* Sp = reinterpret_cast<sf32x4*>(a.part_S + (int64_t)blockIdx.x * V * ldh + (int64_t)v * ldh + 64 * th_w);
-#define SM_PUT(U) if ((U) < nq) Sp[U] = accS[U];
-            SM_PUT(0) SM_PUT(1) SM_PUT(2) SM_PUT(3) SM_PUT(4) SM_PUT(5) SM_PUT(6) SM_PUT(7)
-            SM_PUT(8) SM_PUT(9) SM_PUT(10) SM_PUT(11) SM_PUT(12) SM_PUT(13) SM_PUT(14) SM_PUT(15)
+        sf32x4* Sp = reinterpret_cast<sf32x4*>(a.part_S) + (int64_t)blockIdx.x * small_part_quads(L, (int)ldh)
+                     + (int64_t)(16 * th_w * L.tiles_dn + nq * tv_w) * 64 + lane;
+#define SM_PUT(U) if ((U) < nq) Sp[(U) * 64] = accS[U];
+        SM_PUT(0) SM_PUT(1) SM_PUT(2) SM_PUT(3) SM_PUT(4) SM_PUT(5) SM_PUT(6) SM_PUT(7)
+        SM_PUT(8) SM_PUT(9) SM_PUT(10) SM_PUT(11) SM_PUT(12) SM_PUT(13) SM_PUT(14) SM_PUT(15)
 #undef SM_PUT
-        }
     }
     for (int j = tid; j < (int)ldh; j += SM_NT) {
         a.posP[(int64_t)blockIdx.x * ldh + j] = j < L.H64 ? c.csP[j] : 0.f;
         a.negP[(int64_t)blockIdx.x * ldh + j] = j < L.H64 ? c.csN[j] : 0.f;
     }
     for (int i = tid; i < (int)ldv; i += SM_NT) a.partV[(int64_t)blockIdx.x * ldv + i] = i < L.V64 ? c.csV[i] : 0.f;
-    {
-        const float tot = block_sum(cost, red);
-        if (tid == 0) a.cost_partials[blockIdx.x] = tot;
-    }
     SM_STAMP();
 #ifdef MDBN_STAMP
     if (a.stamps && blockIdx.x == 0 && tid == 0) { a.stamps[0] = (unsigned long long)n_stamp; a.stamps[63] = (unsigned long long)(clock64() - sclk0); }
@@ -516,21 +572,20 @@ hipError_t launch_small_cd(const SmallCdArgs& a, hipStream_t s)
 __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinArgs f)
 {
     const int G = f.lanes, ipb = 256 / G;
-    const int nbw = (int)((f.n4 + ipb - 1) / ipb);
+    const int nbw = (int)((f.n4p + ipb - 1) / ipb);
     if ((int)blockIdx.x < nbw) {
         const int sub = threadIdx.x & (G - 1);
-        const int64_t i = (int64_t)blockIdx.x * ipb + threadIdx.x / G;
-        const bool in = i < f.n4;
+        const int64_t p = (int64_t)blockIdx.x * ipb + threadIdx.x / G;      // position in a partial
+        const bool in = p < f.n4p;
         const int per = (f.nparts + G - 1) / G;
         const int pb = sub * per, pe = min(f.nparts, pb + per);
         const float4* P = reinterpret_cast<const float4*>(f.part);
-        const int64_t ps4 = f.part_stride >> 2;
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int p0 = pb; p0 < pe; p0 += 8) {
             float4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                v[u] = (in && p0 + u < pe) ? P[i + (int64_t)(p0 + u) * ps4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[u] = (in && p0 + u < pe) ? P[p + (int64_t)(p0 + u) * f.n4p] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int u = 0; u < 8; ++u) { s4.x += v[u].x; s4.y += v[u].y; s4.z += v[u].z; s4.w += v[u].w; }
         }
@@ -539,18 +594,27 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinArgs f)
             s4.z += __shfl_xor(s4.z, off, 64); s4.w += __shfl_xor(s4.w, off, 64);
         }
         if (!in || sub != 0) return;
+        // position -> (row of S, 4-column group): [th][tv][u][lane], nq(th) pieces per lane (small_cd_kernel)
+        const int q = (int)(p >> 6), lane = (int)(p & 63);
+        const int th = q / (16 * f.tiles_dn);
+        const int nq = min(16, f.q4 - 16 * th);
+        const int rem = q - 16 * th * f.tiles_dn;
+        const int tv = rem / nq, u = rem - tv * nq;
+        const int v = 64 * tv + lane;
+        if (v >= f.V) return;
+        const int64_t i = (int64_t)v * f.q4 + 16 * th + u;
         if (!f.do_upd) {
             reinterpret_cast<float4*>(f.S_out)[i] = s4;
             return;
         }
-        const UpdEpi& u = f.upd;
-        const float4 w = reinterpret_cast<const float4*>(u.W)[i], sp = reinterpret_cast<const float4*>(u.Ws)[i];
-        const float4 w0 = u.W0 ? reinterpret_cast<const float4*>(u.W0)[i] : w;
+        const UpdEpi& up = f.upd;
+        const float4 w = reinterpret_cast<const float4*>(up.W)[i], sp = reinterpret_cast<const float4*>(up.Ws)[i];
+        const float4 w0 = up.W0 ? reinterpret_cast<const float4*>(up.W0)[i] : w;
         float4 wn, sn;
-        update_rule4(w, sp, s4, w0, u.inv_bs, u.wc, upd_decay(u.lr, u.l2), u.l1, upd_two_lr_l1(u.lr, u.l1), u.mu, u.lr, wn, sn);
-        reinterpret_cast<float4*>(u.W)[i] = wn;
-        reinterpret_cast<float4*>(u.Ws)[i] = sn;
-        if (u.Wp) store_planes4(u.Wp, u.wp_stride, 4 * i, wn);
+        update_rule4(w, sp, s4, w0, up.inv_bs, up.wc, upd_decay(up.lr, up.l2), up.l1, upd_two_lr_l1(up.lr, up.l1), up.mu, up.lr, wn, sn);
+        reinterpret_cast<float4*>(up.W)[i] = wn;
+        reinterpret_cast<float4*>(up.Ws)[i] = sn;
+        if (up.Wp) store_planes4(up.Wp, up.wp_stride, 4 * i, wn);
     } else {
         const int unit = ((int)blockIdx.x - nbw) * 4 + (threadIdx.x >> 6);
         if (unit <= fin_units(f.fin)) finalize_unit(f.fin, unit, threadIdx.x & 63);
@@ -560,9 +624,9 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinArgs f)
 hipError_t launch_small_finish(const SmallFinArgs& f0, hipStream_t s)
 {
     SmallFinArgs f = f0;
-    f.lanes = f.nparts >= 32 ? 8 : f.nparts >= 12 ? 4 : f.nparts >= 4 ? 2 : 1;
+    f.lanes = f.nparts >= 64 ? 16 : f.nparts >= 24 ? 8 : f.nparts >= 12 ? 4 : f.nparts >= 4 ? 2 : 1;
     const int ipb = 256 / f.lanes;
-    const int nbw = (int)((f.n4 + ipb - 1) / ipb);
+    const int nbw = (int)((f.n4p + ipb - 1) / ipb);
     const int nbf = ((int)((f.fin.ldh + f.fin.ldv + 15) / 16) + 1 + 3) / 4;       // fin_units + the cost unit, four waves per block
     hipLaunchKernelGGL(small_finish_kernel, dim3(nbw + nbf), dim3(256), 0, s, f);
     return hipGetLastError();
