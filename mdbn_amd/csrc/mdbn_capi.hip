@@ -374,6 +374,7 @@ WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
     // fused epilogues write one partial per block: 128 x 64 tiles, or 32-column strips (skinny)
     s.cost = std::max<int64_t>(s.cost, ((B + 127) / 128) * ((std::max(ldv, ldh) + 63) / 64) + 64);
     s.cost = std::max<int64_t>(s.cost, ((B + 63) / 64) * ((std::max(ldv, ldh) + 31) / 32) + 64);
+    if (small_shape_ok(B, V, H, 0) || small_shape_ok(B, V, H, 1)) s.cost = std::max<int64_t>(s.cost, (int64_t)small_blocks(B) * SM_NW + 64);   // a cost partial per wave
     const int ng = row_groups(B);
     s.colP = 2 * (int64_t)ng * ldh;
     s.colV = (int64_t)ng * ldv;
@@ -1038,6 +1039,11 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
         g_opt_comm_cus = (int)value;
         return MDBN_OK;
     }
+    if (strcmp(name, "small_fin_lanes") == 0) {
+        REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16, "small_fin_lanes must be 0, 1, 2, 4, 8 or 16");
+        g_small_fin_lanes = (int)value;
+        return MDBN_OK;
+    }
     if (strcmp(name, "small_fused") == 0) {
         g_opt_small_fused = value != 0;
         return MDBN_OK;
@@ -1444,7 +1450,7 @@ static bool small_eligible(const mdbn_cd_args* a, const Workspace& ws)
     if (!a->gauss && a->vs == nullptr) return false;
     if (a->B > 65535 * 16 || !small_shape_ok(a->B, a->V, a->H, a->gauss) || !small_ld_ok(a->V, a->H, a->ldv, a->ldh)) return false;
     const int nb = small_blocks(a->B);
-    return (int64_t)nb * ((a->V + 63) & ~int64_t(63)) * a->ldh <= ws.slab_floats && nb <= ws.cost_floats && nb <= row_groups(a->B);
+    return (int64_t)nb * ((a->V + 63) & ~int64_t(63)) * a->ldh <= ws.slab_floats && (int64_t)nb * SM_NW <= ws.cost_floats && nb <= row_groups(a->B);
 }
 
 // mode 0: the whole step; 1: the chain + partials only (mdbn_cd_forward); 2: the finish launch (mdbn_cd_statistics).
@@ -1470,7 +1476,7 @@ static int cd_step_small(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, co
         HIP_OK(launch_small_cd(k, s));
     }
     if (mode == 1) {
-        ctx->pending_n_cost = nb; ctx->pending_stats = a->stats;
+        ctx->pending_n_cost = nb * SM_NW; ctx->pending_stats = a->stats;
         return MDBN_OK;
     }
     if (mode == 2) { ctx->pending_n_cost = -1; ctx->pending_stats = nullptr; }
@@ -1499,7 +1505,7 @@ static int cd_step_small(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, co
         bu.H = H; bu.V = V; bu.lr = upd->lr; bu.mu = upd->momentum; bu.inv_rows = 1.0f / upd->n_rows;
         bu.cost_scale = upd->cost_scale; bu.cost_out = upd->cost_out;
     }
-    f.fin = make_fin_args(ws.colPpos, ws.colPneg, ws.colV, nb, ldh, ldv, ws.cost_partials, nb, s_h, s_v, cost, fuse_upd ? &bu : nullptr);
+    f.fin = make_fin_args(ws.colPpos, ws.colPneg, ws.colV, nb, ldh, ldv, ws.cost_partials, nb * SM_NW, s_h, s_v, cost, fuse_upd ? &bu : nullptr);
     HIP_OK(launch_small_finish(f, s));
     if (upd && !fuse_upd) {
         mdbn_update_args u = *upd;

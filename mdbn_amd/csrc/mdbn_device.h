@@ -100,6 +100,26 @@ __device__ __forceinline__ void update_rule4(const float4& w, const float4& sp, 
 // ----------------------------------------------------------------------------------
 __device__ __forceinline__ int fin_units(const FinArgs& f) { return (int)((f.ldh + f.ldv + 15) / 16); }
 
+// column i of [s_h | s_v] is known: store it and apply the bias half of the update (rbm.py:356-365; same helpers as update_kernel)
+__device__ __forceinline__ void finalize_column(const FinArgs& f, int64_t i, float t)
+{
+    if (i < f.ldh) f.s_h[i] = t;
+    else if (i < f.ldh + f.ldv) f.s_v[i - f.ldh] = t;
+    if (f.do_bias) {
+        const BiasUpd& bu = f.bu;
+        if (i < bu.H) {
+            const float sp = bu.hbs[i];
+            bu.hbs[i] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
+            bu.hb[i] = upd_param(bu.hb[i], 1.0f, sp, bu.lr);
+        } else if (i >= f.ldh && i - f.ldh < bu.V) {
+            const int64_t j = i - f.ldh;
+            const float sp = bu.vbs[j];
+            bu.vbs[j] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
+            bu.vb[j] = upd_param(bu.vb[j], 1.0f, sp, bu.lr);
+        }
+    }
+}
+
 __device__ __forceinline__ void finalize_unit(const FinArgs& f, int unit, int lane)
 {
     const int n_units = fin_units(f);
@@ -121,26 +141,16 @@ __device__ __forceinline__ void finalize_unit(const FinArgs& f, int unit, int la
         const int l0 = lane & ~3;
         const float r0 = __shfl(a, l0, 64), r1 = __shfl(a, l0 + 1, 64), r2 = __shfl(a, l0 + 2, 64), r3 = __shfl(a, l0 + 3, 64);
         const float t = (r0 + r1) + (r2 + r3);
-        if (qd == 0) {
-            if (i < f.ldh) f.s_h[i] = t;
-            else if (i < f.ldh + f.ldv) f.s_v[i - f.ldh] = t;
-            if (f.do_bias) {    // bias half of the update (rbm.py:356-365; same helpers as update_kernel)
-                const BiasUpd& bu = f.bu;
-                if (i < bu.H) {
-                    const float sp = bu.hbs[i];
-                    bu.hbs[i] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
-                    bu.hb[i] = upd_param(bu.hb[i], 1.0f, sp, bu.lr);
-                } else if (i >= f.ldh && i - f.ldh < bu.V) {
-                    const int64_t j = i - f.ldh;
-                    const float sp = bu.vbs[j];
-                    bu.vbs[j] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
-                    bu.vb[j] = upd_param(bu.vb[j], 1.0f, sp, bu.lr);
-                }
-            }
-        }
+        if (qd == 0) finalize_column(f, i, t);
     } else if (unit == n_units && f.cost_partials) {
         float a = 0.f;
-        for (int k = lane; k < f.n_cost; k += 64) a += f.cost_partials[k];
+        for (int k0 = lane; k0 < f.n_cost; k0 += 64 * 8) {     // (same order of additions per lane; 8 loads in flight instead of one)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = k0 + 64 * u < f.n_cost ? f.cost_partials[k0 + 64 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
         if (lane == 0) {
@@ -170,7 +180,14 @@ __device__ __forceinline__ int64_t epi_target_row(const EpiArgs& e, int64_t row)
 
 __device__ __forceinline__ float sigmoidf_(float x)
 {
+#ifndef MDBN_SIGMOID_RCP
+#define MDBN_SIGMOID_RCP 1      // 1: v_rcp_f32 (1 ulp); 0: __frcp_rn, which HIP expands to the 12-instruction correctly-rounded division
+#endif
+#if MDBN_SIGMOID_RCP
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+#else
     return __frcp_rn(1.0f + __expf(-x));
+#endif
 }
 __device__ __forceinline__ float softplusf_(float x)
 {

@@ -8,7 +8,7 @@ namespace mdbn {
 
 constexpr int SM_ROWS = 4;                  // minibatch rows per slab = M of v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4 columns),
                                             // and the rows one Philox block serves
-constexpr int SM_NW = 8, SM_NT = 64 * SM_NW;
+constexpr int SM_NW = 8, SM_NT = 64 * SM_NW;    // the waves that run the passes (a ninth draws the random numbers: mdbn_small.hip)
 constexpr int SM_MAXQ = 16;                 // accumulators of the statistics per wave: one 64-row x 64-column tile of S
 constexpr int SM_MAX_LDS = 160 * 1024;
 constexpr int SM_MAX_BLOCKS = 128;          // workgroups (= partials the finish kernel sums); more slabs: a workgroup loops
@@ -22,7 +22,7 @@ struct SmallLayout {
                                 // (lane 4 b + i reads row i, column k0 + b) meets 32 different banks per half wave
     int tiles_up, tiles_dn;     // 64-column output tiles of propup (H) / propdown (V)
     int ks_up, per_up;          // propup: K chunks (its one or two output tiles alone would leave waves idle) of per_up k-steps
-    int oW, oX0, oXa, oXb, oHs, oM0, oMn, oPart, oCsP, oCsN, oCsV, oHb, oVb, oRed;   // offsets in floats
+    int oW, oX0, oXa, oXb, oHs, oM0, oMn, oPart, oCsP, oCsN, oCsV, oHb, oVb, oU;   // offsets in floats
     int bytes;
 };
 
@@ -61,7 +61,7 @@ __host__ __device__ inline SmallLayout small_layout(int V, int H, bool gauss)
     L.oPart = take(L.ks_up * L.H64 * 4);
     L.oCsP = take(L.H64); L.oCsN = take(L.H64); L.oCsV = take(L.V64);
     L.oHb = take(L.H64); L.oVb = take(L.V64);
-    L.oRed = take(16);
+    L.oU = take(4 * L.H64);
     L.bytes = o * 4;
     return L;
 }
@@ -78,7 +78,7 @@ struct SmallCdArgs {
     float* part_S;                                   // [blocks][small_part_quads] float4, in the lanes' order (mdbn_small.hip)
     float* posP; float* negP;                        // [blocks][ldh]: sum_rows ph, sum_rows -nh
     float* partV;                                    // [blocks][ldv]: sum_rows (v0 - nv)
-    float* cost_partials;                            // [blocks]
+    float* cost_partials;                            // [blocks][SM_NW]: one per wave
     // inspection copies (keep != 0) and chain taps (NULL = off), as mdbn_cd_args
     float* V2; float* P2; float* hs; float* vs;
     float* trace_h; float* trace_v;
@@ -99,6 +99,7 @@ struct SmallFinArgs {
     FinArgs fin;
 };
 
+extern int g_small_fin_lanes;
 int small_blocks(int64_t B);
 bool small_shape_ok(int64_t B, int64_t V, int64_t H, int gauss);
 bool small_ld_ok(int64_t V, int64_t H, int64_t ldv, int64_t ldh);       // leading dimensions the LDS images can take

@@ -33,6 +33,7 @@
 namespace mdbn {
 
 typedef float sf32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t su32x4 __attribute__((ext_vector_type(4)));
 // Every LDS pointer of this file carries its address space in its TYPE: held as plain `float*` (in arrays, across lambdas)
 // hipcc loses track of it and emits FLAT loads -- the vector-memory path with an aperture check, several times slower than
 // ds_read and counted on vmcnt (seen in the ISA: v_lshl_add_u64 pointer arithmetic and s_waitcnt vmcnt(0) in the MFMA loops).
@@ -46,7 +47,8 @@ typedef __attribute__((address_space(3))) sf32x4 lds_f4;      // 16-byte LDS acc
 
 namespace {
 
-#ifdef MDBN_STAMP       // diagnostic builds: shader-clock cycles workgroup 0 / wave 0 spends in the parts of a pass (slots 48..55)
+#ifdef MDBN_STAMP_CLK   // diagnostic builds (with -DMDBN_STAMP): shader-clock cycles workgroup 0 / wave 0 spends in the parts of a pass
+                        // (slots 48..55); each costs a memory round trip of thread 0: the phase stamps are then ~0.1 us per part too long
 __device__ unsigned long long* g_sm_clk = nullptr;
 #define SM_CLK_BEGIN() const long long clk_ = clock64()
 #define SM_CLK_ADD(SLOT) do { if (g_sm_clk && blockIdx.x == 0 && threadIdx.x == 0) g_sm_clk[SLOT] += (unsigned long long)(clock64() - clk_); } while (0)
@@ -62,6 +64,13 @@ __device__ __forceinline__ int64_t sm_src_row(const SmallCdArgs& a, int row)
     if (s < 0) s += a.n_data;
     return s < 0 ? 0 : (s >= a.n_data ? a.n_data - 1 : s);
 }
+
+#ifndef SM_RNG_WAVE
+#define SM_RNG_WAVE 0       // 1: a ninth wave draws the propup epilogues' Philox blocks under the other waves' reduction loops
+#endif
+#ifndef SM_SUM_UNROLLED
+#define SM_SUM_UNROLLED 1   // propup epilogue: all chunk partials requested at once (0: a rolled read-wait-add loop)
+#endif
 
 // 16 rank-1 updates of a 4 x 64 tile: A register `A_` (16 k-steps, one per block), B values B_(0) .. B_(15); two accumulator
 // chains (even / odd k) so that an MFMA never waits for the one before it.  (abid must be an immediate: spelled out.)
@@ -133,9 +142,14 @@ __device__ __forceinline__ void sm_up_loop(lds_cf* X, lds_cf* Wl, const SmallLay
     }
 }
 
-template <class Epi>
-__device__ __forceinline__ void sm_up(lds_cf* X, lds_cf* Wl, const SmallLayout& L, lds_f* part, int wave, int lane, Epi&& epi)
+// `rng` (the ninth wave's job, under the other waves' reduction loops): the Philox blocks the epilogue will need, one per
+// column, into `U` -- 10 rounds of quarter-rate multiplies are half of the epilogue's ~1 850 cycles, and they depend on
+// nothing the pass computes.
+template <class Rng, class Epi>
+__device__ __forceinline__ void sm_up(lds_cf* X, lds_cf* Wl, const SmallLayout& L, lds_f* part, int wave, int lane, Rng&& rng, Epi&& epi)
 {
+    if (SM_RNG_WAVE && wave == SM_NW) rng();
+    else
     switch (L.ldw) {
         case 20: sm_up_loop<20>(X, Wl, L, part, wave, lane); break;
         case 44: sm_up_loop<44>(X, Wl, L, part, wave, lane); break;
@@ -145,9 +159,26 @@ __device__ __forceinline__ void sm_up(lds_cf* X, lds_cf* Wl, const SmallLayout& 
     }
     { SM_CLK_BEGIN(); SM_SYNC(); SM_CLK_ADD(49); }
     SM_CLK_BEGIN();
-    for (int col = threadIdx.x; col < L.H64; col += SM_NT) {
+    for (int col = threadIdx.x; col < L.H64; col += SM_NT + 64 * SM_RNG_WAVE) {
+        // (four chunk partials requested at once, summed in chunk order: a rolled read-wait-add loop is an LDS round trip per
+        //  chunk; chunks past ks_up re-read the last one and add an exact zero)
+#if SM_SUM_UNROLLED
+        sf32x4 pc[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) pc[ch] = *(const lds_f4*)(part + 4 * (min(ch, L.ks_up - 1) * L.H64 + col));
+        sf32x4 x = pc[0];
+#pragma unroll
+        for (int ch = 1; ch < 4; ++ch) x += ch < L.ks_up ? pc[ch] : sf32x4{0.f, 0.f, 0.f, 0.f};
+        if (L.ks_up > 4) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) pc[ch] = *(const lds_f4*)(part + 4 * (min(4 + ch, L.ks_up - 1) * L.H64 + col));
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) x += 4 + ch < L.ks_up ? pc[ch] : sf32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#else
         sf32x4 x = *(const lds_f4*)(part + 4 * col);
         for (int ch = 1; ch < L.ks_up; ++ch) x += *(const lds_f4*)(part + 4 * (ch * L.H64 + col));
+#endif
         epi(x, col);
     }
     SM_CLK_ADD(50);
@@ -213,18 +244,24 @@ __device__ __forceinline__ void sm_stats(sf32x4 (&accS)[SM_MAXQ], lds_cf* X0, ld
         a[r] = M0[r * L.ldhs + 64 * th + lane]; b[r] = X0[r * L.ldx + 64 * tv + lane];
         a[4 + r] = Mn[r * L.ldhs + 64 * th + lane]; b[4 + r] = Xn[r * L.ldx + 64 * tv + lane];
     }
+    // (two accumulators per block of code: a lone chain of dependent 4x4x1 MFMAs issues every 13.7 cycles, two every 9.5)
 #define SM_STAT(U)                                                                                                     \
-    if ((U) < nq) {                                                                                                    \
+    if ((U) + 1 < nq) {                                                                                                \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                                                \
+            accS[U] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], b[r], accS[U], 4, U, 0);                                \
+            accS[(U) + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], b[r], accS[(U) + 1], 4, (U) + 1, 0);              \
+        }                                                                                                              \
+    } else if ((U) < nq) {                                                                                             \
         _Pragma("unroll") for (int r = 0; r < 8; ++r) accS[U] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], b[r], accS[U], 4, U, 0); \
     }
-    SM_STAT(0) SM_STAT(1) SM_STAT(2) SM_STAT(3) SM_STAT(4) SM_STAT(5) SM_STAT(6) SM_STAT(7)
-    SM_STAT(8) SM_STAT(9) SM_STAT(10) SM_STAT(11) SM_STAT(12) SM_STAT(13) SM_STAT(14) SM_STAT(15)
+    SM_STAT(0) SM_STAT(2) SM_STAT(4) SM_STAT(6) SM_STAT(8) SM_STAT(10) SM_STAT(12) SM_STAT(14)
 #undef SM_STAT
 }
 
 // what the passes of one slab share (plain pointers and sizes: copied into registers once)
 struct SmCtx {
     lds_f *Wl, *X0, *Xa, *Xb, *Hs, *M0, *Mn, *part, *csP, *csN, *csV, *hbl, *vbl;
+    __attribute__((address_space(3))) uint32_t* U;      // [H64][4] Philox words of the running propup's epilogue
     int row0; uint64_t grow0;
 };
 
@@ -301,14 +338,31 @@ __device__ __forceinline__ void sm_step_up(const SmallCdArgs& a, const SmCtx& c,
     const SmallLayout& L = a.L;
     const int H = a.H, B = a.B;
     const int64_t ldh = a.ldh;
+    typedef __attribute__((address_space(3))) su32x4 lds_u4;
     sm_up(X, c.Wl, L, c.part, wave, lane,
+          [&]() {
+              if (KIND != 2) {
+                  for (int col = lane; col < L.H64; col += 64) {
+                      uint32_t w[4];
+                      philox_rows4(a.rng, (uint32_t)(2 * t), c.grow0, (uint32_t)col, w);
+                      *(lds_u4*)(c.U + 4 * col) = su32x4{w[0], w[1], w[2], w[3]};
+                  }
+              }
+          },
           [&](const sf32x4& x, int col) {
               const bool live = col < H;
               const float bias = c.hbl[col];
               lds_f* cd = (KIND == 2 ? c.csN : c.csP) + col;
               const float cs0 = KIND != 1 ? *cd : 0.f;
-              uint32_t w[4] = {0u, 0u, 0u, 0u};
-              if (KIND != 2) philox_rows4(a.rng, (uint32_t)(2 * t), c.grow0, (uint32_t)col, w);
+              su32x4 w = {0u, 0u, 0u, 0u};
+              if (KIND != 2) {
+                  if (SM_RNG_WAVE) w = *(const lds_u4*)(c.U + 4 * col);
+                  else {
+                      uint32_t w4[4];
+                      philox_rows4(a.rng, (uint32_t)(2 * t), c.grow0, (uint32_t)col, w4);
+                      w = su32x4{w4[0], w4[1], w4[2], w4[3]};
+                  }
+              }
               float m[4], sv[4], cs = 0.f;
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -347,7 +401,7 @@ __device__ __forceinline__ void sm_step_up(const SmallCdArgs& a, const SmCtx& c,
 }  // namespace
 
 template <bool GAUSS, bool TAPS>
-__global__ __launch_bounds__(SM_NT) void small_cd_kernel(SmallCdArgs a)
+__global__ __launch_bounds__(SM_NT + 64 * SM_RNG_WAVE) void small_cd_kernel(SmallCdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const SmallLayout& L = a.L;
@@ -366,8 +420,9 @@ __global__ __launch_bounds__(SM_NT) void small_cd_kernel(SmallCdArgs a)
     c.csV = lds + L.oCsV;           // [V64] column sums of v0 - nv
     c.hbl = lds + L.oHb;
     c.vbl = lds + L.oVb;
-    float* const red = sm + L.oRed;
+    c.U = (__attribute__((address_space(3))) uint32_t*)(lds + L.oU);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool worker = wave < SM_NW;          // waves 0..7 run the passes; wave 8 draws the random numbers ahead of them (sm_up)
     const int V = a.V, H = a.H, B = a.B;
     const int64_t ldv = a.ldv, ldh = a.ldh;
     const int nslabs = (B + SM_ROWS - 1) / SM_ROWS;
@@ -376,7 +431,9 @@ __global__ __launch_bounds__(SM_NT) void small_cd_kernel(SmallCdArgs a)
     (void)n_stamp;
 #ifdef MDBN_STAMP       // diagnostic builds (scripts/experiments/small_stamps.py): wall-clock stamps of workgroup 0's phases
     const long long sclk0 = clock64();
+#ifdef MDBN_STAMP_CLK
     if (blockIdx.x == 0 && tid == 0) { g_sm_clk = a.stamps; if (a.stamps) for (int i = 48; i < 56; ++i) a.stamps[i] = 0; }
+#endif
 #define SM_STAMP() do { if (a.stamps && blockIdx.x == 0 && tid == 0 && n_stamp < 46) a.stamps[1 + n_stamp++] = wall_clock64(); } while (0)
 #else
 #define SM_STAMP() do { } while (0)
@@ -391,15 +448,15 @@ __global__ __launch_bounds__(SM_NT) void small_cd_kernel(SmallCdArgs a)
     auto gather_where = [&](int j, int row0, int& r, int& c4) -> bool {      // element j of this thread: (row r, 16-byte piece c4)
         const int e = tid + j * SM_NT;
         r = e / q4x; c4 = e - r * q4x;
-        return e < SM_ROWS * q4x && row0 + r < B && c4 < dq4;
+        return worker && e < SM_ROWS * q4x && row0 + r < B && c4 < dq4;
     };
     const int row0_first = (int)blockIdx.x * SM_ROWS;
     int64_t srow[2] = {0, 0};
 #pragma unroll
     for (int j = 0; j < 2; ++j) { int r, c4; if (gather_where(j, row0_first, r, c4)) srow[j] = sm_src_row(a, row0_first + r); }
     const float hb_r = tid < H ? a.hbias[tid] : 0.f, vb_r = tid < V ? a.vbias[tid] : 0.f;       // (H, V <= 512 = SM_NT)
-    sf32x4 xg[2];
-    {
+    sf32x4 xg[2] = {sf32x4{0.f, 0.f, 0.f, 0.f}, sf32x4{0.f, 0.f, 0.f, 0.f}};
+    if (worker) {
         // W image [Vp][ldw]: rows >= V and columns >= ldh zero (the pad columns of W below ldh are zero in memory).  Batches
         // of SM_WB loads per thread in flight, then their LDS stores.
         const int q4w = L.ldw >> 2, q4 = (int)(ldh >> 2);
@@ -461,7 +518,7 @@ __global__ __launch_bounds__(SM_NT) void small_cd_kernel(SmallCdArgs a)
         for (int j = 0; j < 2; ++j) {
             int r, c4;
             const bool live = gather_where(j, c.row0, r, c4);
-            if (tid + j * SM_NT < SM_ROWS * q4x) {
+            if (worker && tid + j * SM_NT < SM_ROWS * q4x) {
                 *(lds_f4*)(c.X0 + r * L.ldx + 4 * c4) = xg[j];
                 if (TAPS && a.keep && live) *reinterpret_cast<sf32x4*>(a.V2 + (int64_t)(c.row0 + r) * ldv + 4 * c4) = xg[j];
             }
@@ -487,28 +544,40 @@ __global__ __launch_bounds__(SM_NT) void small_cd_kernel(SmallCdArgs a)
         SM_STAMP();
     }
 
-    // ---- this workgroup's partials: the cost first (its block sum has barriers, and a __syncthreads() waits for every global
-    //      store issued before it); then a lane's 16-byte pieces of ONE row of S (64 tv + lane), stored as such; the column sums
+    // ---- this workgroup's partials: the cost (one per wave: no barrier), a lane's 16-byte pieces of S, the column sums
     {
-        const float tot = block_sum(cost, red);
-        if (tid == 0) a.cost_partials[blockIdx.x] = tot;
+        float tot = cost;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+        if (lane == 0 && worker) a.cost_partials[(int)blockIdx.x * SM_NW + wave] = tot;
     }
     // (layout of a partial: the 16-byte pieces in the order the lanes hold them -- [hidden tile th][visible tile tv][piece u]
     //  [lane] -- so that every store instruction writes 1 KB of consecutive memory; stored by row of S, 160 bytes apart per
     //  lane, the 5 120 scattered pieces of a workgroup took 2.5 us (stamped).  small_finish_kernel decodes the position.)
-    if (wave < L.tiles_dn * L.tiles_up) {
+    if (wave < L.tiles_dn * L.tiles_up && 64 * tv_w + lane < V) {       // (pad lanes: rows of S that do not exist -- not stored, not read)
         sf32x4* Sp = reinterpret_cast<sf32x4*>(a.part_S) + (int64_t)blockIdx.x * small_part_quads(L, (int)ldh)
                      + (int64_t)(16 * th_w * L.tiles_dn + nq * tv_w) * 64 + lane;
+#ifndef SM_PART_STORE
+#define SM_PART_STORE 1     // 1 = non-temporal stores of the S partial (nobody on this XCD reads them: 10.5 MB of dirty L2 lines at the
+                            // kernel's end cost 4.5 us at 512 -> 40, streamed 3.2: profiles/r04z_small_partial_store_ab.log); 0 = plain;
+                            // 2 = none (experiment: wrong results)
+#endif
+#if SM_PART_STORE == 1
+#define SM_PUT(U) if ((U) < nq) __builtin_nontemporal_store(accS[U], Sp + (U) * 64);
+#elif SM_PART_STORE == 2
+#define SM_PUT(U) if ((U) < nq && a.B < 0) Sp[(U) * 64] = accS[U];
+#else
 #define SM_PUT(U) if ((U) < nq) Sp[(U) * 64] = accS[U];
+#endif
         SM_PUT(0) SM_PUT(1) SM_PUT(2) SM_PUT(3) SM_PUT(4) SM_PUT(5) SM_PUT(6) SM_PUT(7)
         SM_PUT(8) SM_PUT(9) SM_PUT(10) SM_PUT(11) SM_PUT(12) SM_PUT(13) SM_PUT(14) SM_PUT(15)
 #undef SM_PUT
     }
-    for (int j = tid; j < (int)ldh; j += SM_NT) {
+    for (int j = tid; j < (int)ldh && worker; j += SM_NT) {
         a.posP[(int64_t)blockIdx.x * ldh + j] = j < L.H64 ? c.csP[j] : 0.f;
         a.negP[(int64_t)blockIdx.x * ldh + j] = j < L.H64 ? c.csN[j] : 0.f;
     }
-    for (int i = tid; i < (int)ldv; i += SM_NT) a.partV[(int64_t)blockIdx.x * ldv + i] = i < L.V64 ? c.csV[i] : 0.f;
+    for (int i = tid; i < (int)ldv && worker; i += SM_NT) a.partV[(int64_t)blockIdx.x * ldv + i] = i < L.V64 ? c.csV[i] : 0.f;
     SM_STAMP();
 #ifdef MDBN_STAMP
     if (a.stamps && blockIdx.x == 0 && tid == 0) { a.stamps[0] = (unsigned long long)n_stamp; a.stamps[63] = (unsigned long long)(clock64() - sclk0); }
@@ -550,7 +619,7 @@ hipError_t launch_small_cd(const SmallCdArgs& a, hipStream_t s)
         if (e != hipSuccess) return e;
         attr_set[variant] = true;
     }
-    const dim3 grid(small_blocks(a.B)), block(SM_NT);
+    const dim3 grid(small_blocks(a.B)), block(SM_NT + 64 * SM_RNG_WAVE);
     SmallCdArgs k = a;
     k.L = L;
     switch (variant) {
@@ -576,7 +645,14 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinArgs f)
     if ((int)blockIdx.x < nbw) {
         const int sub = threadIdx.x & (G - 1);
         const int64_t p = (int64_t)blockIdx.x * ipb + threadIdx.x / G;      // position in a partial
-        const bool in = p < f.n4p;
+        // position -> (row of S, 4-column group): [th][tv][u][lane], nq(th) pieces per lane (small_cd_kernel)
+        const int q = (int)(p >> 6), lane = (int)(p & 63);
+        const int th = q / (16 * f.tiles_dn);
+        const int nq = max(1, min(16, f.q4 - 16 * th));
+        const int rem = q - 16 * th * f.tiles_dn;
+        const int tv = rem / nq, u = rem - tv * nq;
+        const int v = 64 * tv + lane;
+        const bool in = p < f.n4p && v < f.V;
         const int per = (f.nparts + G - 1) / G;
         const int pb = sub * per, pe = min(f.nparts, pb + per);
         const float4* P = reinterpret_cast<const float4*>(f.part);
@@ -594,14 +670,6 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinArgs f)
             s4.z += __shfl_xor(s4.z, off, 64); s4.w += __shfl_xor(s4.w, off, 64);
         }
         if (!in || sub != 0) return;
-        // position -> (row of S, 4-column group): [th][tv][u][lane], nq(th) pieces per lane (small_cd_kernel)
-        const int q = (int)(p >> 6), lane = (int)(p & 63);
-        const int th = q / (16 * f.tiles_dn);
-        const int nq = min(16, f.q4 - 16 * th);
-        const int rem = q - 16 * th * f.tiles_dn;
-        const int tv = rem / nq, u = rem - tv * nq;
-        const int v = 64 * tv + lane;
-        if (v >= f.V) return;
         const int64_t i = (int64_t)v * f.q4 + 16 * th + u;
         if (!f.do_upd) {
             reinterpret_cast<float4*>(f.S_out)[i] = s4;
@@ -621,10 +689,13 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinArgs f)
     }
 }
 
+int g_small_fin_lanes = 0;       // mdbn_set_option("small_fin_lanes"): 0 = by the number of partials
+
 hipError_t launch_small_finish(const SmallFinArgs& f0, hipStream_t s)
 {
     SmallFinArgs f = f0;
     f.lanes = f.nparts >= 64 ? 16 : f.nparts >= 24 ? 8 : f.nparts >= 12 ? 4 : f.nparts >= 4 ? 2 : 1;
+    if (g_small_fin_lanes > 0) f.lanes = g_small_fin_lanes;
     const int ipb = 256 / f.lanes;
     const int nbw = (int)((f.n4p + ipb - 1) / ipb);
     const int nbf = ((int)((f.fin.ldh + f.fin.ldv + 15) / 16) + 1 + 3) / 4;       // fin_units + the cost unit, four waves per block

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Build the library with different -D flags on the GPU box and time the headline step with each.
+"""Build the library with different -D flags on the GPU box and time the step of one layer with each (default: the headline
+shape; MDBN_AB_SHAPE="V,H,B,k,gauss" selects another, as scripts/step_ab.py).
     python scripts/build_variants.py "-DX6_SCHED=0" "-DX6_SCHED=1" ..."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,11 +15,18 @@ import numpy as np, torch, mdbn_amd
 from mdbn_amd import _lib
 _lib.use_diagnostic_library(%r)
 eng = mdbn_amd.set_engine(mdbn_amd.HipEngine())
-V, H, B, N = 4096, 1024, 512, 32768
+import os
+V, H, B, K, GAUSS = [int(x) for x in os.environ.get("MDBN_AB_SHAPE", "4096,1024,512,1,1").split(",")]
+N = 32768
 g = torch.Generator(device="cpu").manual_seed(0)
-data = mdbn_amd.shared(torch.randn((N, V), generator=g).to(eng.device))
-rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123))
-_, up = rbm.get_cost_updates(lr=0.001, k=1, lambda_2=0.1, batch_size=B)
+if GAUSS:
+    data = mdbn_amd.shared(torch.randn((N, V), generator=g).to(eng.device))
+    rbm = mdbn_amd.GRBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123))
+    _, up = rbm.get_cost_updates(lr=0.001, k=K, lambda_2=0.1, batch_size=B)
+else:
+    data = mdbn_amd.shared((torch.rand((N, V), generator=g) < 0.3).float().to(eng.device))
+    rbm = mdbn_amd.RBM(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(123))
+    _, up = rbm.get_cost_updates(lr=0.05, k=K, weightcost=2e-4, batch_size=B)
 fn = mdbn_amd.function(up, data)
 perm = torch.from_numpy(np.random.RandomState(1).permutation(N)).to(eng.device)
 def run(n):

@@ -10,7 +10,7 @@ out = os.path.join(ROOT, "gpurun_out"); os.makedirs(out, exist_ok=True)
 so = os.path.join(out, "libmdbn_small_stamp.so")
 src = [os.path.join(ROOT, "mdbn_amd", "csrc", f) for f in ("mdbn_kernels.hip", "mdbn_planes.hip", "mdbn_small.hip", "mdbn_capi.hip")]
 if not os.path.exists(so) or os.environ.get("MDBN_STAMP_REBUILD"):
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DMDBN_STAMP"] + src + ["-o", so, "-ldl"])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DMDBN_STAMP"] + (["-DMDBN_STAMP_CLK"] if os.environ.get("MDBN_STAMP_CLK") else []) + src + ["-o", so, "-ldl"])
 import numpy as np, torch
 from mdbn_amd import _lib
 _lib.use_diagnostic_library(so)
