@@ -344,7 +344,7 @@ struct WsSizes {
     int64_t total_bytes() const { return 4 * (ru64(slab) + ru64(cost) + ru64(colP) + ru64(colV)); }
 };
 
-WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
+static WsSizes ws_sizes_dense(int64_t B, int64_t V, int64_t H)
 {
     const int64_t ldv = padded_ld(V), ldh = padded_ld(H);      // the largest ld the policy hands out
     WsSizes s;
@@ -378,6 +378,19 @@ WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
     const int ng = row_groups(B);
     s.colP = 2 * (int64_t)ng * ldh;
     s.colV = (int64_t)ng * ldv;
+    return s;
+}
+
+// (a ragged hidden width may ride on a leading dimension padded to a multiple of 128 -- plane_shape_ok -- : every buffer is
+// then as large as the dense layer of that width needs)
+WsSizes ws_sizes(int64_t B, int64_t V, int64_t H)
+{
+    WsSizes s = ws_sizes_dense(B, V, H);
+    if (H % 128 != 0) {
+        const WsSizes p = ws_sizes_dense(B, V, (H + 127) & ~int64_t(127));
+        s.slab = std::max(s.slab, p.slab); s.cost = std::max(s.cost, p.cost);
+        s.colP = std::max(s.colP, p.colP); s.colV = std::max(s.colV, p.colV);
+    }
     return s;
 }
 
@@ -556,10 +569,15 @@ bool plane_plan(const Plan& p, int64_t M, int64_t N, int64_t K)
 bool plane_shape_ok(int64_t B, int64_t V, int64_t H, int64_t ldv, int64_t ldh)
 {
     if (!g_opt_gemm_planes) return false;
-    if (B <= 0 || B % 128 || V % 128 || H % 128 || ldv != V || ldh != H || B > 65535) return false;
-    if (g_opt_planes_min_work > 0 && (B * V * H < g_opt_planes_min_work || V * H < ((int64_t)1 << 21))) return false;
-    return plane_plan(plan_forward(B, H, V, H), B, H, V) && plane_plan(plan_forward(B, V, H, V), B, V, H) &&
-           plane_plan(plan_stats(V, H, 2 * B, H), V, H, 2 * B);
+    // A ragged hidden width rides on a padded leading dimension: the GEMMs run on He = ldh columns (a multiple of 128; the
+    // pad columns of W, of the hidden activations and of the statistics hold exact zeros, which every kernel of the path
+    // keeps so), the activation epilogues treat the columns >= H as dead.  The visible side stays dense: its leading
+    // dimension is the training table's.
+    if (B <= 0 || B % 128 || V % 128 || ldh % 128 || ldv != V || H > ldh || ldh - H >= 128 || B > 65535) return false;
+    const int64_t He = ldh;
+    if (g_opt_planes_min_work > 0 && (B * V * He < g_opt_planes_min_work || V * He < ((int64_t)1 << 21))) return false;
+    return plane_plan(plan_forward(B, He, V, He), B, He, V) && plane_plan(plan_forward(B, V, He, V), B, V, He) &&
+           plane_plan(plan_stats(V, He, 2 * B, He), V, He, 2 * B);
 }
 
 bool planes_eligible(const mdbn_cd_args* a)
@@ -568,7 +586,7 @@ bool planes_eligible(const mdbn_cd_args* a)
     if (a->persistent || a->sample_stats || (a->gauss && a->add_noise)) return false;
     const int64_t B = a->B, V = a->V, H = a->H;
     if (!plane_shape_ok(B, V, H, a->ldv, a->ldh)) return false;
-    return a->planes_bytes >= 2 * planes_elems(B, V, H) && aligned16(a->planes) && aligned16(a->W_planes);
+    return a->planes_bytes >= 2 * planes_elems(B, a->ldv, a->ldh) && aligned16(a->planes) && aligned16(a->W_planes);
 }
 
 // Workgroups of a balanced launch over `units` stage units (0: launch one workgroup per tile job as usual).  Balanced
@@ -593,9 +611,10 @@ int bal_blocks(const mdbn_ctx* ctx, int comm_cus, int64_t tiles, int64_t stages)
 
 // One forward pass on planes: A planes [rows, K] (ROW), W planes as COL (dir 0: propup) or ROW (dir 1: propdown);
 // `e` arrives with outputs / bias / rng / colsum set, this fills in the slab side and the cost partials.
+// (H: the hidden width the GEMMs run on -- ldh, see plane_shape_ok; ncols: the live columns of the output)
 int run_affine_planes(mdbn_ctx* ctx, int comm_cus, const unsigned short* A, int64_t lda, int64_t pa, int ap, int dir,
-                      const unsigned short* Wp, int64_t V, int64_t H, int64_t rows, EpiArgs e, bool want_cost, const Workspace& ws,
-                      hipStream_t s, int* n_cost_out)
+                      const unsigned short* Wp, int64_t V, int64_t H, int64_t ncols, int64_t rows, EpiArgs e, bool want_cost,
+                      const Workspace& ws, hipStream_t s, int* n_cost_out)
 {
     const int64_t Kdim = dir == 0 ? V : H, Ndim = dir == 0 ? H : V;
     PlaneGemmArgs g{};
@@ -624,7 +643,7 @@ int run_affine_planes(mdbn_ctx* ctx, int comm_cus, const unsigned short* A, int6
     }
     const bool fuse = !bal && g_opt_fused_epilogue && g.splitk == 1;
     const int nb = fuse ? g.tiles_m * g.tiles_n : epilogue_blocks(rows, e.ld);
-    e.rows = (int)rows; e.cols = (int)Ndim;
+    e.rows = (int)rows; e.cols = (int)ncols;
     e.cost_partials = nullptr;
     if (want_cost) {
         if (nb > ws.cost_floats) return fail(MDBN_ENOSPC, "cost scratch exhausted");
@@ -670,7 +689,8 @@ int run_affine_planes(mdbn_ctx* ctx, int comm_cus, const unsigned short* A, int6
 int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const mdbn_update_args* upd, const Workspace& ws,
                    int mode = 0, const mdbn_update_args* defer = nullptr)
 {
-    const int64_t B = a->B, V = a->V, H = a->H, ldv = V, ldh = H;
+    const int64_t B = a->B, V = a->V, Hlive = a->H, ldv = V, ldh = a->ldh;
+    const int64_t H = ldh;          // the width the GEMMs run on (pad columns: exact zeros; plane_shape_ok)
     PlaneBufs pb;
     unsigned short* Xother = nullptr;        // the X2 buffer this step does NOT use (gather-ahead target)
     {
@@ -712,7 +732,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
         e.ld = ldh; e.bias = a->hbias; e.mean = keep ? ph : nullptr; e.sample = keep ? a->hs : nullptr; e.mean_scale = 1.0f; e.gauss = 0;
         e.colsum = ws.colPpos; e.colsum_kind = 0; e.rng = key(0);
         e.mean_planes = pb.Pp; e.plane_stride = pb.pp; e.sample_plane = pb.hsp;
-        CHECK(run_affine_planes(ctx, a->comm_cus, pb.Xp, ldv, pb.px, 3, 0, Wp, V, H, B, e, false, ws, s, nullptr));
+        CHECK(run_affine_planes(ctx, a->comm_cus, pb.Xp, ldv, pb.px, 3, 0, Wp, V, H, Hlive, B, e, false, ws, s, nullptr));
         if (a->trace_h) HIP_OK(hipMemcpyAsync(a->trace_h, a->hs, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
     }
     for (int t = 1; t <= a->k; ++t) {                                  // gibbs_hvh x k (rbm.py:318-336)
@@ -731,7 +751,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
                     e.target_idx = a->indexes; e.target_idx64 = a->index_is_64;       // NULL: rows 0..B-1 of the data
                 }
             }
-            CHECK(run_affine_planes(ctx, a->comm_cus, pb.hsp, ldh, B * ldh, 1, 1, Wp, V, H, B, e, last, ws, s, last ? &n_cost : nullptr));
+            CHECK(run_affine_planes(ctx, a->comm_cus, pb.hsp, ldh, B * ldh, 1, 1, Wp, V, H, V, B, e, last, ws, s, last ? &n_cost : nullptr));
             if (a->trace_v && !a->gauss)
                 HIP_OK(hipMemcpyAsync(a->trace_v + (int64_t)(t - 1) * B * ldv, a->vs, sizeof(float) * B * ldv,
                                       hipMemcpyDeviceToDevice, s));
@@ -744,8 +764,8 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
             e.mean_planes = pb.Pp + B * ldh; e.plane_stride = pb.pp;       // rows B..2B-1 of the P2 planes: -nh_mean
             e.sample_plane = need_sample ? pb.hsp : nullptr;
             if (last) { e.colsum = ws.colPneg; e.colsum_kind = 0; }
-            if (a->gauss) CHECK(run_affine_planes(ctx, a->comm_cus, pb.Xp + B * ldv, ldv, pb.px, 3, 0, Wp, V, H, B, e, false, ws, s, nullptr));
-            else CHECK(run_affine_planes(ctx, a->comm_cus, pb.vsp, ldv, B * ldv, 1, 0, Wp, V, H, B, e, false, ws, s, nullptr));
+            if (a->gauss) CHECK(run_affine_planes(ctx, a->comm_cus, pb.Xp + B * ldv, ldv, pb.px, 3, 0, Wp, V, H, Hlive, B, e, false, ws, s, nullptr));
+            else CHECK(run_affine_planes(ctx, a->comm_cus, pb.vsp, ldv, B * ldv, 1, 0, Wp, V, H, Hlive, B, e, false, ws, s, nullptr));
             if (a->trace_h && need_sample)
                 HIP_OK(hipMemcpyAsync(a->trace_h + (int64_t)t * B * ldh, a->hs, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
         }
@@ -793,7 +813,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     if (fuse_upd) {
         BiasUpd bu;
         bu.hb = upd->hbias; bu.hbs = upd->hbias_speed; bu.vb = upd->vbias; bu.vbs = upd->vbias_speed;
-        bu.H = H; bu.V = V; bu.lr = upd->lr; bu.mu = upd->momentum; bu.inv_rows = 1.0f / upd->n_rows;
+        bu.H = Hlive; bu.V = V; bu.lr = upd->lr; bu.mu = upd->momentum; bu.inv_rows = 1.0f / upd->n_rows;
         bu.cost_scale = upd->cost_scale; bu.cost_out = upd->cost_out;
         g.fused = 2;
         g.fin_enabled = 1;
@@ -843,7 +863,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
             g.upd.Sprev = defer->stats; g.upd.early = 2;
             const float* ps_h = defer->stats + V * ldh;
             g.db.on = 1; g.db.hb = defer->hbias; g.db.hbs = defer->hbias_speed; g.db.vb = defer->vbias; g.db.vbs = defer->vbias_speed;
-            g.db.s_h = ps_h; g.db.s_v = ps_h + ldh; g.db.cost_sum = ps_h + ldh + ldv; g.db.H = H; g.db.V = V;
+            g.db.s_h = ps_h; g.db.s_v = ps_h + ldh; g.db.cost_sum = ps_h + ldh + ldv; g.db.H = Hlive; g.db.V = V;
             g.db.lr = defer->lr; g.db.mu = defer->momentum; g.db.inv_rows = 1.0f / defer->n_rows;
             g.db.cost_scale = defer->cost_scale; g.db.cost_out = defer->cost_out;
             if (!bal) set_gather_ahead();

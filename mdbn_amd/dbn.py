@@ -20,7 +20,7 @@ from .engine import get_engine
 from .mlp import HiddenLayer
 from .rbm import GRBM, RBM, Scalar, function
 from .rng import RandomStreams
-from .shared import HostTable, SharedArray, shared
+from .shared import HostTable, SharedArray, shared, weight_ld
 from .utils import get_minibatches_idx
 
 
@@ -96,7 +96,7 @@ class DBN(object):
             b = numpy.zeros((n_out,), dtype=numpy.float32) if b_list is None else b_list[i]
 
             sigmoid_layer = HiddenLayer(rng=numpy_rng, input=layer_input, n_in=n_in, n_out=n_out,
-                                        W=shared(W, name='W', engine=self.engine),
+                                        W=shared(W, name='W', engine=self.engine, ld=weight_ld(self.engine, n_in, n_out)),
                                         b=shared(b, name='b', engine=self.engine),
                                         activation=mlp.sigmoid, engine=self.engine)
             self.sigmoid_layers.append(sigmoid_layer)

@@ -159,6 +159,7 @@ class HipEngine(object):
         _lib.check(self.lib.mdbn_ctx_create(C.byref(ctx), self.device.index or 0), "mdbn_ctx_create")
         self.ctx = ctx
         self._workspace = None
+        self._options_epoch = 0         # bumped by set_option: argument structs cached by step functions are then stale
         self._ws_need = {}              # (B, V, H) -> bytes the library asks for (options that change it clear this)
         self._stats = {}
         self._scratch = {}
@@ -293,6 +294,21 @@ class HipEngine(object):
     # B * V * H >= planes_min_work and V * H >= 2^21.  Mirrors mdbn_set_option("planes_min_work"); tests set 0.
     planes_min_work = 1 << 30
 
+    def weight_ld(self, V, H):
+        """Leading dimension of a [V, H] weight matrix.  A big layer whose hidden width is not a multiple of 128 (the
+        reference's 2048 -> 400 gene-expression layer, AMLsm2.py / MDBN.py presets) gets its rows padded to the next
+        multiple: the plane path (bf16 planes + LDS-DMA GEMMs, whole 128-column tiles) then serves it on the padded
+        width, the pad columns holding exact zeros -- 2048 -> 400 CD-5 at B = 512: 393 us on the exact-f32 tile kernels,
+        which is what a ragged width falls back to.  None: the default (padded_ld)."""
+        if V % 128 == 0 and H % 128 != 0 and H > 128:
+            He = (H + 127) // 128 * 128
+            if V * He >= self.weight_ld_min_elems:
+                return He
+        return None
+
+    import os as _os
+    weight_ld_min_elems = int(_os.environ.get("MDBN_WEIGHT_LD_MIN", 1 << 21))      # smallest V * padded H that is padded
+
     def plane_shape(self, B, V, H, ldv, ldh):
         """Shapes the plane path of the library takes under its CURRENT options: asked of the library itself
         (mdbn_planes_eligible), so the host's buffers and the library's choice of path cannot disagree."""
@@ -309,6 +325,7 @@ class HipEngine(object):
     def set_option(self, name, value):
         """Library tuning knob (mdbn_set_option), e.g. ``set_option('gemm_bk', 32)``; process-wide."""
         _lib.check(self.lib.mdbn_set_option(self.ctx, name.encode(), int(value)), "mdbn_set_option")
+        self._options_epoch += 1         # (cached argument structs of step functions: stale)
         self._scratch.clear()            # options decide which scratch a shape needs (planes, slabs)
         self._ws_need.clear()            # ... and how many split-K slabs its workspace holds
 
@@ -622,7 +639,7 @@ class HipEngine(object):
         step, lr / momentum and the cost slot.  Returns None when the cache does not apply (the caller takes the full path)."""
         a, u, a_ref, u_ref, key, sc, keep = cache[:7]
         if key != (data.data_ptr(), data.shape[0], idx.dtype, idx.numel(), self._workspace.data_ptr() if self._workspace is not None else 0,
-                   self.keep_f32, self.trace_chain):
+                   self.keep_f32, self.trace_chain, self._options_epoch):
             return None
         a.indexes = idx.data_ptr()
         a.rng.step = rng_step & 0xFFFFFFFF
@@ -657,7 +674,8 @@ class HipEngine(object):
             idx = _keep[1]
             if idx is not None and sc.planes is None and not a.W_planes and not self.trace_chain and not sample_stats:
                 dm = _keep[0]
-                key = (dm.data_ptr(), dm.shape[0], idx.dtype, idx.numel(), self._workspace.data_ptr(), self.keep_f32, self.trace_chain)
+                key = (dm.data_ptr(), dm.shape[0], idx.dtype, idx.numel(), self._workspace.data_ptr(), self.keep_f32, self.trace_chain,
+                       self._options_epoch)
                 cache_out.extend([a, u, C.byref(a), C.byref(u), key, sc, (dm, stats, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed)])
         return cost
 

@@ -7,7 +7,7 @@ import numpy
 import torch
 
 from .engine import get_engine
-from .shared import as_tensor, shared
+from .shared import as_tensor, shared, weight_ld
 
 
 class LayerOutput(object):
@@ -43,7 +43,7 @@ class HiddenLayer(object):
                                      dtype=numpy.float32)
             if activation is sigmoid:
                 W_values *= 4
-            W = shared(W_values, name='W', engine=self.engine)
+            W = shared(W_values, name='W', engine=self.engine, ld=weight_ld(self.engine, n_in, n_out))
         if b is None:
             b = shared(numpy.zeros((n_out,), dtype=numpy.float32), name='b', engine=self.engine)
         self.W = shared(W, name='W', engine=self.engine)

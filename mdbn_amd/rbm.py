@@ -20,7 +20,7 @@ import torch
 from . import dist as _dist
 from .engine import RngAddr, get_engine
 from .rng import RandomStreams
-from .shared import HostTable, SharedArray, as_tensor, shared
+from .shared import HostTable, SharedArray, as_tensor, shared, weight_ld
 from .utils import get_minibatches_idx
 
 
@@ -502,7 +502,7 @@ class RBM(object):
             initial_W = numpy.asarray(numpy_rng.uniform(low=-bound, high=bound,
                                                         size=(n_visible, n_hidden)),
                                       dtype=numpy.float32)
-            W = shared(initial_W, name='W', engine=self.engine)
+            W = shared(initial_W, name='W', engine=self.engine, ld=weight_ld(self.engine, n_visible, n_hidden))
         if hbias is None:
             hbias = shared(numpy.zeros(n_hidden, dtype=numpy.float32), name='hbias', engine=self.engine)
         if vbias is None:
@@ -521,7 +521,8 @@ class RBM(object):
         self.momentum = 0.0                    # rbm.py:151; supplied per step-function call
 
         z = numpy.zeros
-        self.W_speed = shared(z((n_visible, n_hidden), numpy.float32), name='W_speed', engine=self.engine)
+        self.W_speed = shared(z((n_visible, n_hidden), numpy.float32), name='W_speed', engine=self.engine,
+                              ld=self.W.tensor.stride(0))        # (same layout as W: the update walks both)
         self.hbias_speed = shared(z(n_hidden, numpy.float32), name='hbias_speed', engine=self.engine)
         self.vbias_speed = shared(z(n_visible, numpy.float32), name='vbias_speed', engine=self.engine)
         self.params_speed = [self.W_speed, self.hbias_speed, self.vbias_speed]

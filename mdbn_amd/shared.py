@@ -11,13 +11,17 @@ from .engine import get_engine
 
 
 class SharedArray(object):
-    def __init__(self, value, name=None, engine=None, _tensor=None):
+    def __init__(self, value, name=None, engine=None, _tensor=None, ld=None):
         self.engine = engine if engine is not None else get_engine()
         self.name = name
         self._sync_hook = None      # called before host reads (completes deferred device work)
         self.version = 0            # bumped by every set_value (caches of derived data key on it)
         if _tensor is not None:
             self.tensor = _tensor
+        elif ld is not None:        # a weight matrix on a wider leading dimension (Engine.weight_ld); pad columns zero
+            src = self.engine.to_device(getattr(value, "tensor", value))
+            self.tensor = self.engine.alloc_matrix(src.shape[0], src.shape[1], ld=ld)
+            self.tensor.copy_(src)
         else:
             self.tensor = self.engine.to_device(getattr(value, "tensor", value))
 
@@ -37,7 +41,7 @@ class SharedArray(object):
         if not isinstance(new, torch.Tensor):
             new = torch.from_numpy(numpy.ascontiguousarray(new, dtype=numpy.float32))
         if tuple(new.shape) != tuple(self.tensor.shape):
-            self.tensor = self.engine.to_device(new)
+            self.tensor = self.engine.to_device(new)        # (a new shape: the default leading dimension again)
         else:
             self.tensor.copy_(new.to(self.tensor.device))
 
@@ -165,7 +169,7 @@ def host_table_threshold():
     return int(os.environ.get("MDBN_HOST_TABLE_BYTES", 128 << 30))
 
 
-def shared(value, name=None, borrow=False, engine=None, resident="device"):
+def shared(value, name=None, borrow=False, engine=None, resident="device", ld=None):
     """``theano.shared(value, name=, borrow=)``.  ``resident``: "device" (default, as the reference), "host" (a
     ``HostTable``: pinned memory, rows gathered over PCIe one minibatch ahead), or "auto" (host above
     ``host_table_threshold()`` bytes)."""
@@ -178,7 +182,13 @@ def shared(value, name=None, borrow=False, engine=None, resident="device"):
         return HostTable(value, name=name, engine=engine)
     if resident != "device":
         raise ValueError("resident must be 'device', 'host' or 'auto'")
-    return SharedArray(value, name=name, engine=engine)
+    return SharedArray(value, name=name, engine=engine, ld=ld)
+
+
+def weight_ld(engine, n_in, n_out):
+    """Leading dimension for an [n_in, n_out] weight matrix on ``engine`` (None: the default policy)."""
+    fn = getattr(engine, "weight_ld", None)
+    return fn(n_in, n_out) if fn is not None else None
 
 
 def as_tensor(x, engine):
