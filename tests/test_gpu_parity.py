@@ -351,32 +351,39 @@ def test_large_n_forward_is_chunked_consistently(hip_engine):
     assert (np.abs(F - F_o) / np.maximum(np.abs(F_o), 1.0)).max() <= 1e-4
 
 
-def test_config4_two_layer_dbn_full_width(hip_engine):
+@pytest.mark.parametrize("V,H1,H2", [(4096, 1024, 256), (2048, 1000, 40)])
+def test_config4_two_layer_dbn_full_width(hip_engine, V, H1, H2, tmp_path):
     """BASELINE configs[3]: DBN 4096 -> 1024 -> 256, CD-1, layer-wise, B = 512: both layers'
     step functions (layer 1 consuming the cached sigmoid activations of layer 0) against the
-    oracle driven with the same Philox streams."""
+    oracle driven with the same Philox streams.  Second case: a RAGGED first layer, 2048 -> 1000: its weights (shared by the
+    HiddenLayer and the RBM) live on rows padded to 1024 (Engine.weight_ld) and the step runs on the plane path; the class
+    surface, the forward pass, the free energy and a checkpoint round trip see [2048, 1000]."""
     import mdbn_amd
     mdbn_amd.DBN.verbose = False
     N, B = 1024, 512
-    x = np.random.RandomState(0).normal(size=(N, 4096)).astype(np.float32)
-    dbn = mdbn_amd.DBN(numpy_rng=np.random.RandomState(123), n_ins=4096, hidden_layers_sizes=[1024], n_outs=256,
+    x = np.random.RandomState(0).normal(size=(N, V)).astype(np.float32)
+    dbn = mdbn_amd.DBN(numpy_rng=np.random.RandomState(123), n_ins=V, hidden_layers_sizes=[H1], n_outs=H2,
                        engine=hip_engine)
+    ld1 = (H1 + 127) // 128 * 128
+    assert dbn.rbm_layers[0].W.tensor.stride(0) == ld1 and dbn.sigmoid_layers[0].W is dbn.rbm_layers[0].W
+    assert dbn.params[0].get_value().shape == (V, H1)
     W0, W1 = dbn.params[0].get_value(), dbn.params[2].get_value()
     fns, fe_fns = dbn.training_functions(mdbn_amd.shared(x, engine=hip_engine), batch_size=B, k=1,
                                          lambda_1=0.0, lambda_2=0.1)
     r0, r1 = dbn.rbm_layers
-    s0 = rbm_np.RBMState(4096, 1024, W=W0, gauss=True)
-    s1 = rbm_np.RBMState(1024, 256, W=W1); s1.freeze_W0()
+    s0 = rbm_np.RBMState(V, H1, W=W0, gauss=True)
+    s1 = rbm_np.RBMState(H1, H2, W=W1); s1.freeze_W0()
     idx = [np.arange(B), np.arange(B) + B]
     for t in range(2):                                   # layer 0: GRBM, lr 0.001 (stable), momentum 0
         c = float(fns[0](indexes=idx[t], momentum=0.0, lr=0.001))
         # teacher forcing: the oracle's chain starts from the device's positive-phase sample, which must
         # equal the oracle's own wherever the uniform is not within fp32 rounding of the probability
-        hs_dev = hip_engine.cd_scratch(B, 4096, 1024, False, fns[0]._data().stride(0), r0.W.tensor.stride(0)).hs
-        hs_dev = hs_dev.cpu().numpy()[:, :1024].astype(np.float64)
+        hs_dev = hip_engine.cd_scratch(B, V, H1, False, fns[0]._data().stride(0), r0.W.tensor.stride(0)).hs
+        assert not hs_dev.cpu().numpy()[:, H1:].any()
+        hs_dev = hs_dev.cpu().numpy()[:, :H1].astype(np.float64)
         draws = PhiloxDraws(r0.theano_rng.seed, r0.stream_id, t)
         p_o = rbm_np.propup(s0, x[idx[t]].astype(np.float64))[1]
-        u = draws.u(0, B, 1024)
+        u = draws.u(0, B, H1)
         flips = hs_dev != (u < p_o)
         assert np.all(np.abs(u - p_o)[flips] < 1e-6) and flips.sum() <= 4, "sample differs away from a tie"
         c_o = rbm_np.cd_step(s0, x[idx[t]], draws, lr=0.001, k=1, lambda_2=0.1, batch_size=B, chain_start=hs_dev)
@@ -394,6 +401,15 @@ def test_config4_two_layer_dbn_full_width(hip_engine):
     assert np.abs(out - out_o).max() <= 1e-4
     ft, fv = fe_fns[0](x[:64], x[64:128])
     np.testing.assert_allclose(ft, rbm_np.free_energy(s0, x[:64].astype(np.float64)), rtol=1e-4, atol=1e-2)
+    # checkpoint round trip (AMLsm2.py:112-205 schema): logical shapes on disk, the padded rows again after loading
+    from mdbn_amd import checkpoint
+    path = str(tmp_path / "net.npz")
+    checkpoint.save_network(path, {"dbn": dbn})
+    back = checkpoint.load_network(path, engine=hip_engine)["dbn"]
+    assert back.rbm_layers[0].W.tensor.stride(0) == ld1
+    for p, q in zip(dbn.params, back.params):
+        assert np.array_equal(p.get_value(), q.get_value())
+    assert np.array_equal(back.get_output(x[:64]), out)
 
 
 def test_config5_three_modality_mdbn(hip_engine):
