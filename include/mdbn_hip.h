@@ -222,9 +222,10 @@ int  mdbn_padded_ld(int64_t cols, int64_t *ld);
 int  mdbn_planes_bytes(int64_t B, int64_t ldv, int64_t ldh, int64_t *bytes);
 /* bytes of the second X2-plane buffer of the gather-ahead (mdbn_cd_args.planes_alt) */
 int  mdbn_planes_alt_bytes(int64_t B, int64_t ldv, int64_t *bytes);
-/* Does the plane path of mdbn_cd_step / mdbn_cd_train_step serve this shape under the CURRENT options (whole 128-row /
- * 128-column tiles, ldv == V, ldh == H, "gemm_planes" on, B * V * H >= "planes_min_work")?  The one statement of the
- * rule: a host allocates mdbn_cd_args.planes / W_planes for exactly these shapes.  (Per call the step also needs CD
+/* Does the plane path of mdbn_cd_step / mdbn_cd_train_step serve this shape under the CURRENT options (B and V whole
+ * 128-row / 128-column tiles, ldv == V; the hidden side on a leading dimension of whole tiles, ldh % 128 == 0 and
+ * H <= ldh < H + 128 -- a ragged hidden width rides on zero pad columns --; "gemm_planes" on, B * V * ldh >=
+ * "planes_min_work")?  The one statement of the rule: a host allocates mdbn_cd_args.planes / W_planes for exactly these shapes.  (Per call the step also needs CD
  * without a persistent chain, no sample_stats and no GRBM noise.)  W planes handed to a step with W_planes_valid = 0
  * are re-split on entry whichever path the step takes, so they are valid after ANY step that received them. */
 int  mdbn_planes_eligible(int64_t B, int64_t V, int64_t H, int64_t ldv, int64_t ldh, int32_t *eligible);

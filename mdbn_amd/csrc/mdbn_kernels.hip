@@ -1372,16 +1372,21 @@ static void launch_act_epilogue_cw(const EpiArgs& e, hipStream_t s)
     const int64_t n = ((int64_t)(e.rows + 3) / 4) * (e.ld / CW);
     const int t = epilogue_threads(e.rows, e.ld);
     const dim3 grid((unsigned)((n + t - 1) / t)), block(t);
-    // the split counts of the headline path take the specialised bodies
+    // MODE-specialised bodies (the activation arithmetic as straight-line code: a third of the generic body's time) for the
+    // split counts the plans produce -- 8 / 2 (headline), 16 / 3 / 4 (ragged and mid-size layers: 2048 -> 400 splits propup 16
+    // ways and propdown 3; its eleven epilogue launches per CD-5 step ran the generic body at 17 us each, 48 % of the step's
+    // GPU time, profiles/r04zk_ge_2048_400_cd5_kernel_stats.csv) and for any other count (NS = 0: the rolled slab loop)
     const int mode = (e.gauss ? 2 : 0) | ((e.sample != nullptr || e.sample_plane != nullptr) ? 1 : 0);
-    if (!e.bal_P && (e.nsplit == 8 || e.nsplit == 2)) {
+    if (mode != 3 && (e.bal_P || (e.nsplit != 6 && e.nsplit != 7))) {     // (6 / 7: the unrolled bodies of the balanced launches below)
+        const int ns = e.bal_P ? 0 : (e.nsplit == 8 || e.nsplit == 2 || e.nsplit == 16 || e.nsplit == 3 || e.nsplit == 4) ? e.nsplit : 0;
 #define EPI_MODE_CASE(NSV, MV) \
-    if (e.nsplit == NSV && mode == MV) { hipLaunchKernelGGL((act_epilogue_kernel<NSV, CW, MV>), grid, block, 0, s, e); return; }
-        EPI_MODE_CASE(8, 0) EPI_MODE_CASE(8, 1) EPI_MODE_CASE(8, 2) EPI_MODE_CASE(8, 3)
-        EPI_MODE_CASE(2, 0) EPI_MODE_CASE(2, 1) EPI_MODE_CASE(2, 2) EPI_MODE_CASE(2, 3)
+    if (ns == NSV && mode == MV) { hipLaunchKernelGGL((act_epilogue_kernel<NSV, CW, MV>), grid, block, 0, s, e); return; }
+#define EPI_MODE_CASES(NSV) EPI_MODE_CASE(NSV, 0) EPI_MODE_CASE(NSV, 1) EPI_MODE_CASE(NSV, 2)
+        EPI_MODE_CASES(8) EPI_MODE_CASES(2) EPI_MODE_CASES(16) EPI_MODE_CASES(3) EPI_MODE_CASES(4) EPI_MODE_CASES(0)
+#undef EPI_MODE_CASES
 #undef EPI_MODE_CASE
     }
-    switch (e.bal_P ? 0 : e.nsplit) {
+    switch (e.bal_P ? 0 : e.nsplit) {       // (a Gaussian unit WITH a sample: the generic body)
         case 1: hipLaunchKernelGGL((act_epilogue_kernel<1, CW>), grid, block, 0, s, e); break;
         case 2: hipLaunchKernelGGL((act_epilogue_kernel<2, CW>), grid, block, 0, s, e); break;
         case 4: hipLaunchKernelGGL((act_epilogue_kernel<4, CW>), grid, block, 0, s, e); break;
