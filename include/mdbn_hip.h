@@ -191,7 +191,13 @@ int  mdbn_ctx_destroy(mdbn_ctx *ctx);
  * "bf16_inputs" (default 0): REPORTING mode, not a parity path: the plane GEMMs use only the leading bf16 piece of
  *   every operand (one product instead of six; probabilities off by ~4e-3).
  * "update_overlap": 1 = mdbn_cd_train_step overlaps part of the update with the statistics GEMM
- * on a side stream (default 0: measured slower, see csrc/mdbn_capi.hip). */
+ * on a side stream (default 0: measured slower, see csrc/mdbn_capi.hip).
+ * "small_fused" (default 1): a layer whose W fits one CU's LDS (V, H <= 512, W image + row buffers <= 160 KB: 512 -> 40,
+ *   400 -> 40, 200 -> 20, 100 -> 128, 100 -> 24 -> 3) runs the whole CD-k chain in ONE launch per step -- W staged once, each
+ *   workgroup the whole chain for 4-row slabs on v_mfma_f32_4x4x1 out of LDS, partial statistics per workgroup -- plus a
+ *   small finish launch (sum of the partials in a fixed order + update); same Philox addressing as every path.  0: the
+ *   multi-launch path.  "small_fin_lanes" (0 = by the number of partials | 1, 2, 4, 8, 16): threads of the finish launch
+ *   that share one sum. */
 /* Introspection of the balanced launches of the data-parallel mode (no GPU work): segment k of workgroup w when
  * `workgroups` workgroups share `tiles` x `stages` evenly.  out[6] = {tile, first stage, end stage, segments of this
  * workgroup, stages of this workgroup, slabs (= sharing workgroups) of that tile}; tile = -1 when k is out of range. */

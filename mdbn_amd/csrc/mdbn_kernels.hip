@@ -1207,23 +1207,33 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int j = 0; j < CW; ++j) acc[r][j] = 0.0;
+        // Every load of a batch is issued before the first addition: the addresses are clamped into the slabs (a dead row
+        // re-reads the last live one, a dead slab the last slab) and the dead values become an exact 0.0 by a select
+        // afterwards.  Predicated loads -- `if (row < rows) load` -- put each load into its own basic block, and with the
+        // float64 accumulation hipcc then converted and added right behind every single load: one memory round trip per
+        // slab and row (the generic body: 49 us for the 37 slabs of 19 937 -> 400 at batch 20, 12 us before the float64
+        // sums; 17 us per launch at 2048 -> 400), and four round trips instead of one in the unrolled bodies.
+        const int rlast = e.rows - 1 - r0;                   // last live row of this thread's four (>= 0)
         if (NS > 0) {
+            constexpr int RB = NS * CW >= 64 ? 1 : (NS * CW >= 32 ? 2 : 4);      // rows per batch: <= 64 floats in flight
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (r0 + r < e.rows) {
-                    float v[NS > 0 ? NS : 1][CW];
+            for (int rb = 0; rb < 4; rb += RB) {
+                float v[RB][NS > 0 ? NS : 1][CW];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
 #pragma unroll
                     for (int sidx = 0; sidx < NS; ++sidx)
-                        VecIO<CW>::load(base + (int64_t)r * e.ld + (int64_t)sidx * e.slab_stride, v[sidx]);
+                        VecIO<CW>::load(base + (int64_t)min(rb + r, rlast) * e.ld + (int64_t)sidx * e.slab_stride, v[r][sidx]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
 #pragma unroll
                     for (int sidx = 0; sidx < NS; ++sidx)
 #pragma unroll
-                        for (int j = 0; j < CW; ++j) acc[r][j] += (double)v[sidx][j];
-                }
+                        for (int j = 0; j < CW; ++j) acc[rb + r][j] += rb + r <= rlast ? (double)v[r][sidx][j] : 0.0;
             }
         } else {
-            // any split count: 16 / CW slabs x 4 rows of loads in flight per round (a load-add-load-add
-            // chain costs one memory latency per slab: 76 us at 36 slabs), summed in slab order
+            // any split count: 16 / CW slabs x 4 rows of loads in flight per round, summed in slab order
             constexpr int SB = 16 / CW;               // slabs per round: 64 loaded floats per thread in flight
             int nsplit = e.nsplit;
             if (e.bal_P) {      // slabs of a balanced GEMM: this 128x128 tile has one per workgroup that shared its stages
@@ -1236,18 +1246,15 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int u = 0; u < SB; ++u) {
-#pragma unroll
-                        for (int j = 0; j < CW; ++j) v[r][u][j] = 0.f;
-                        if (r0 + r < e.rows && s0 + u < nsplit)
-                            VecIO<CW>::load(base + (int64_t)r * e.ld + (int64_t)(s0 + u) * e.slab_stride, v[r][u]);
-                    }
+                    for (int u = 0; u < SB; ++u)
+                        VecIO<CW>::load(base + (int64_t)min(r, rlast) * e.ld + (int64_t)min(s0 + u, nsplit - 1) * e.slab_stride, v[r][u]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int u = 0; u < SB; ++u)
 #pragma unroll
-                        for (int j = 0; j < CW; ++j) acc[r][j] += (double)v[r][u][j];
+                        for (int j = 0; j < CW; ++j) acc[r][j] += (r <= rlast && s0 + u < nsplit) ? (double)v[r][u][j] : 0.0;
             }
         }
 #pragma unroll
@@ -1375,14 +1382,16 @@ static void launch_act_epilogue_cw(const EpiArgs& e, hipStream_t s)
     // MODE-specialised bodies (the activation arithmetic as straight-line code: a third of the generic body's time) for the
     // split counts the plans produce -- 8 / 2 (headline), 16 / 3 / 4 (ragged and mid-size layers: 2048 -> 400 splits propup 16
     // ways and propdown 3; its eleven epilogue launches per CD-5 step ran the generic body at 17 us each, 48 % of the step's
-    // GPU time, profiles/r04zk_ge_2048_400_cd5_kernel_stats.csv) and for any other count (NS = 0: the rolled slab loop)
+    // GPU time, profiles/r04zk_ge_2048_400_cd5_kernel_stats.csv)
     const int mode = (e.gauss ? 2 : 0) | ((e.sample != nullptr || e.sample_plane != nullptr) ? 1 : 0);
     if (mode != 3 && (e.bal_P || (e.nsplit != 6 && e.nsplit != 7))) {     // (6 / 7: the unrolled bodies of the balanced launches below)
         const int ns = e.bal_P ? 0 : (e.nsplit == 8 || e.nsplit == 2 || e.nsplit == 16 || e.nsplit == 3 || e.nsplit == 4) ? e.nsplit : 0;
 #define EPI_MODE_CASE(NSV, MV) \
     if (ns == NSV && mode == MV) { hipLaunchKernelGGL((act_epilogue_kernel<NSV, CW, MV>), grid, block, 0, s, e); return; }
 #define EPI_MODE_CASES(NSV) EPI_MODE_CASE(NSV, 0) EPI_MODE_CASE(NSV, 1) EPI_MODE_CASE(NSV, 2)
-        EPI_MODE_CASES(8) EPI_MODE_CASES(2) EPI_MODE_CASES(16) EPI_MODE_CASES(3) EPI_MODE_CASES(4) EPI_MODE_CASES(0)
+        EPI_MODE_CASES(8) EPI_MODE_CASES(2) EPI_MODE_CASES(16) EPI_MODE_CASES(3) EPI_MODE_CASES(4)
+        // (NOT the rolled loop of any other count, NS = 0: its specialised bodies came out FOUR times slower than the generic
+        //  one -- 49 instead of 12 us for the 37 slabs of 19 937 -> 400 at batch 20, profiles/r04zo_ge_19937_400_b20_kernel_stats.csv)
 #undef EPI_MODE_CASES
 #undef EPI_MODE_CASE
     }
