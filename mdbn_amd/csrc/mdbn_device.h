@@ -281,6 +281,16 @@ __device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, f
     const bool is_gauss = MODE < 0 ? e.gauss != 0 : (MODE & 2) != 0;
     const bool need_u = MODE < 0 ? (e.sample != nullptr || e.sample_plane != nullptr) : (MODE & 1) != 0;
     const bool need_z = need_u && is_gauss;
+    // the cost targets of the four rows (index -> row: two dependent loads each) requested first, under the Philox rounds --
+    // loaded row by row inside the loop below they were eight memory round trips in a row
+    float tg4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e.target && live) {
+        int64_t srow[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) srow[j] = epi_target_row(e, min(r0 + j, e.rows - 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tg4[j] = e.target[srow[j] * e.ld_target + col];
+    }
     uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
     if (need_u) {
         const uint64_t g0 = e.rng.row_offset + (uint64_t)r0;
@@ -307,7 +317,7 @@ __device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, f
             }
             float tg = 0.f;
             if (e.target && live) {
-                tg = e.target[epi_target_row(e, row) * e.ld_target + col];
+                tg = tg4[j];
                 if (is_gauss) { const float d = sigmoidf_(xj) - tg; cost += d * d; }
                 else cost += tg * softplusf_(-xj) + (1.0f - tg) * softplusf_(xj);
             }

@@ -1214,6 +1214,20 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
         // slab and row (the generic body: 49 us for the 37 slabs of 19 937 -> 400 at batch 20, 12 us before the float64
         // sums; 17 us per launch at 2048 -> 400), and four round trips instead of one in the unrolled bodies.
         const int rlast = e.rows - 1 - r0;                   // last live row of this thread's four (>= 0)
+        // the cost targets of the four rows (index -> row: two dependent loads each) requested up front, not row by row
+        // inside the activation loop (eight round trips in a row: most of this launch's time on the last visible pass)
+        float tgt4[4][CW];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < CW; ++j) tgt4[r][j] = 0.f;
+        if (e.target) {
+            int64_t srow[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) srow[r] = epi_target_row(e, r0 + min(r, rlast));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) VecIO<CW>::load(e.target + srow[r] * e.ld_target + c0, tgt4[r]);
+        }
         if (NS > 0) {
             constexpr int RB = NS * CW >= 64 ? 1 : (NS * CW >= 32 ? 2 : 4);      // rows per batch: <= 64 floats in flight
 #pragma unroll
@@ -1281,8 +1295,7 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
             const int64_t off = (int64_t)(r0 + r) * e.ld + c0;
             float mean[CW], samp[CW], tgt[CW];
 #pragma unroll
-            for (int j = 0; j < CW; ++j) tgt[j] = 0.f;
-            if (e.target) VecIO<CW>::load(e.target + epi_target_row(e, r0 + r) * e.ld_target + c0, tgt);
+            for (int j = 0; j < CW; ++j) tgt[j] = tgt4[r][j];
 #pragma unroll
             for (int j = 0; j < CW; ++j) {
                 const bool live = c0 + j < e.cols;
