@@ -101,12 +101,19 @@ def pmc_traffic(rows=None):
     just timed (kernel_breakdown); a profile that lacks one of their kernel families is refused (null + the reason)
     instead of being quoted stale; a profile of the same kernels from edited sources is quoted with a note."""
     best = None
+    try:
+        from mdbn_amd import build
+        want_hash = build.source_hash()
+    except Exception:
+        want_hash = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
         try:
             with open(path) as f:
                 d = json.load(f)
             if "step_bytes" in d:
-                best = (os.path.basename(path), d)
+                # the profile of THESE sources if there is one (whatever its tag sorts like), else the last by name
+                if best is None or best[1].get("source_hash") != want_hash or d.get("source_hash") == want_hash:
+                    best = (os.path.basename(path), d)
         except Exception:
             pass
     if not best:

@@ -178,6 +178,37 @@ __device__ __forceinline__ int64_t epi_target_row(const EpiArgs& e, int64_t row)
     return s < 0 ? 0 : (s >= e.target_rows ? e.target_rows - 1 : s);
 }
 
+// ... of the four rows r0 .. r0 + 3 (rows past the end: the last one).  The four index loads are issued TOGETHER, the
+// arithmetic on them afterwards: four calls of epi_target_row compile to four blocks (one per index width) with a
+// `s_waitcnt vmcnt(0)` each -- four memory round trips in a row at the head of every epilogue with a cost target (the
+// "operands arrived after 2.0 us" of the propdown launch's phase stamps).
+__device__ __forceinline__ void epi_target_rows4(const EpiArgs& e, int r0, int64_t (&srow)[4])
+{
+    int64_t raw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) raw[j] = r0 + j < e.rows ? r0 + j : e.rows - 1;
+    if (!e.target_idx) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) srow[j] = raw[j];
+        return;
+    }
+    if (e.target_idx64) {
+        const int64_t* ix = reinterpret_cast<const int64_t*>(e.target_idx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) raw[j] = ix[raw[j]];
+    } else {
+        const int32_t* ix = reinterpret_cast<const int32_t*>(e.target_idx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) raw[j] = (int64_t)ix[raw[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int64_t t = raw[j];
+        if (t < 0) t += e.target_rows;
+        srow[j] = t < 0 ? 0 : (t >= e.target_rows ? e.target_rows - 1 : t);
+    }
+}
+
 __device__ __forceinline__ float sigmoidf_(float x)
 {
 #ifndef MDBN_SIGMOID_RCP
@@ -286,8 +317,7 @@ __device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, f
     float tg4[4] = {0.f, 0.f, 0.f, 0.f};
     if (e.target && live) {
         int64_t srow[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) srow[j] = epi_target_row(e, min(r0 + j, e.rows - 1));
+        epi_target_rows4(e, r0, srow);
 #pragma unroll
         for (int j = 0; j < 4; ++j) tg4[j] = e.target[srow[j] * e.ld_target + col];
     }
@@ -387,8 +417,7 @@ __device__ __forceinline__ void fused_tile_epilogue_4x4_t(const EpiArgs& e, floa
         const bool want_tg = e.target != nullptr;
         if (want_tg) {
             int64_t srow[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) srow[j] = epi_target_row(e, r0 + j < e.rows ? r0 + j : e.rows - 1);
+            epi_target_rows4(e, r0, srow);
 #pragma unroll
             for (int j = 0; j < 4; ++j) tg[j] = *reinterpret_cast<const float4*>(e.target + srow[j] * e.ld_target + col0);
         }

@@ -1223,8 +1223,7 @@ __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
             for (int j = 0; j < CW; ++j) tgt4[r][j] = 0.f;
         if (e.target) {
             int64_t srow[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) srow[r] = epi_target_row(e, r0 + min(r, rlast));
+            epi_target_rows4(e, r0, srow);
 #pragma unroll
             for (int r = 0; r < 4; ++r) VecIO<CW>::load(e.target + srow[r] * e.ld_target + c0, tgt4[r]);
         }
