@@ -129,7 +129,17 @@ __device__ __forceinline__ void finalize_unit(const FinArgs& f, int unit, int la
         const int per = (f.ngroups + 3) / 4;
         const int gbeg = qd * per, gend = min(f.ngroups, gbeg + per);
         float a = 0.f;
-        // (unroll 32 -- all of a lane's 32 groups at B = 512 in one pass -- made the unit take 11 us instead of 3.4: measured)
+        // (hipcc predicates every load of the plain loop into its own block and waits for them in pairs -- `s_waitcnt
+        //  vmcnt(2) / (0)` between 2-load groups in the ISA; a 32-wide unroll had made the unit take 11 us instead of 3.4,
+        //  round 3.  The batched form -- loads of 8 groups issued together at clamped addresses, dead entries added as an
+        //  exact zero, the same sums -- is the A/B alternative.)
+#ifndef MDBN_FIN_BATCH
+#define MDBN_FIN_BATCH 0   // 1: batches of 8 groups with clamped addresses (below).  Same-box A/B, profiles/r04zu_fin_batch_ab.log:
+                           // c1 (784 -> 500, batch 20: 5 groups) 41.5 -> 40.7 us per step, but the headline step 141.0 -> 142.1
+                           // (128 groups: 16 more loads per lane in flight beside the first LDS-DMA stages of the statistics
+                           // GEMM, whose MFMA waves run these units) -- the plain loop stays
+#endif
+#if !MDBN_FIN_BATCH
         if (i < f.ldh) {
 #pragma unroll 16
             for (int g = gbeg; g < gend; ++g) a += f.posP[(int64_t)g * f.ldh + i] + f.negP[(int64_t)g * f.ldh + i];
@@ -138,6 +148,29 @@ __device__ __forceinline__ void finalize_unit(const FinArgs& f, int unit, int la
 #pragma unroll 16
             for (int g = gbeg; g < gend; ++g) a += f.partV[(int64_t)g * f.ldv + j];
         }
+#else
+        if (i < f.ldh) {
+            for (int g0 = gbeg; g0 < gend; g0 += 8) {
+                float p[8], q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t g = min(g0 + u, gend - 1);
+                    p[u] = f.posP[g * f.ldh + i]; q[u] = f.negP[g * f.ldh + i];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += g0 + u < gend ? p[u] + q[u] : 0.f;
+            }
+        } else if (i < f.ldh + f.ldv) {
+            const int64_t j = i - f.ldh;
+            for (int g0 = gbeg; g0 < gend; g0 += 8) {
+                float p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = f.partV[(int64_t)min(g0 + u, gend - 1) * f.ldv + j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += g0 + u < gend ? p[u] : 0.f;
+            }
+        }
+#endif
         const int l0 = lane & ~3;
         const float r0 = __shfl(a, l0, 64), r1 = __shfl(a, l0 + 1, 64), r2 = __shfl(a, l0 + 2, 64), r3 = __shfl(a, l0 + 3, 64);
         const float t = (r0 + r1) + (r2 + r3);
