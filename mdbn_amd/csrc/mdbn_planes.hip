@@ -160,6 +160,37 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
     PL_STAMP(1);
     PL_ISSUE(0);
     PL_STAMP(2);
+    // gather-ahead: the source rows of this workgroup's <= 4 rows of the NEXT minibatch, resolved HERE -- four index loads
+    // issued together under the wait for stage 0, which the loader sits out anyway.  (Resolved where the gather phase
+    // begins, one `epi`-style lookup per row, they were four memory round trips in a row in the middle of the main loop,
+    // each behind a `s_waitcnt vmcnt(0)` that also drained the LDS-DMA ring: found by scanning the ISA for loads waited
+    // for at once; same-box A/B 140.0 -> 139.0 us per step, profiles/r04zv_ga_idx_ab.log.)
+    int64_t ga_srow[4] = {0, 0, 0, 0};
+    if constexpr (EARLYW) {
+        if (g.upd.early && g.ga.idx) {
+            int rr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = (int)blockIdx.x * g.ga.rpw + (i < g.ga.rpw ? i : 0);
+                rr[i] = r < g.ga.B ? r : g.ga.B - 1;
+            }
+            if (g.ga.idx64) {
+                const int64_t* ix = reinterpret_cast<const int64_t*>(g.ga.idx);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ga_srow[i] = ix[rr[i]];
+            } else {
+                const int32_t* ix = reinterpret_cast<const int32_t*>(g.ga.idx);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ga_srow[i] = (int64_t)ix[rr[i]];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int64_t t = ga_srow[i];
+                if (t < 0) t += g.ga.n_rows;
+                ga_srow[i] = t < 0 ? 0 : (t >= g.ga.n_rows ? g.ga.n_rows - 1 : t);
+            }
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PL_STAMP(3);
     __builtin_amdgcn_s_barrier();                    // stage 0 landed
@@ -283,19 +314,9 @@ __device__ __forceinline__ void pl_loader(const PlaneGemmArgs& g, char* smem, in
             if (g.ga.idx) {
                 // gather-ahead: rows blockIdx * rpw .. of the next minibatch, <= 4 units (host); source rows resolved once
                 // (as gather_planes_kernel).  The loads are unconditional at clamped, valid addresses: only stores are predicated.
-                int64_t srow[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int r = (int)blockIdx.x * g.ga.rpw + (i < g.ga.rpw ? i : 0);
-                    r = r < g.ga.B ? r : g.ga.B - 1;
-                    int64_t sidx = g.ga.idx64 ? reinterpret_cast<const int64_t*>(g.ga.idx)[r]
-                                              : (int64_t)reinterpret_cast<const int32_t*>(g.ga.idx)[r];
-                    if (sidx < 0) sidx += g.ga.n_rows;
-                    srow[i] = sidx < 0 ? 0 : (sidx >= g.ga.n_rows ? g.ga.n_rows - 1 : sidx);
-                }
+                const int64_t (&srow)[4] = ga_srow;         // (resolved at the head of the loader, under the wait for stage 0)
                 const int64_t ld8 = g.ga.ld >> 3;
                 const int nunits = g.ga.rpw * g.ga.passes;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the index loads above are hipcc's: settle them before counting again)
                 pf32x4 ga[4], gb[4];
 #define GU_ADDR(U)                                                                            \
     const int i_r0 = (U) / g.ga.passes, pass_ = (U) - i_r0 * g.ga.passes, i_r = i_r0 < 4 ? i_r0 : 3;   \
