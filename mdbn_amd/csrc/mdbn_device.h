@@ -107,15 +107,17 @@ __device__ __forceinline__ void finalize_column(const FinArgs& f, int64_t i, flo
     else if (i < f.ldh + f.ldv) f.s_v[i - f.ldh] = t;
     if (f.do_bias) {
         const BiasUpd& bu = f.bu;
+        // (speed and parameter loaded TOGETHER: read one after the other -- load, wait, store, load, wait, store -- they were
+        //  two memory round trips at the tail of every unit)
         if (i < bu.H) {
-            const float sp = bu.hbs[i];
+            const float sp = bu.hbs[i], p0 = bu.hb[i];
             bu.hbs[i] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
-            bu.hb[i] = upd_param(bu.hb[i], 1.0f, sp, bu.lr);
+            bu.hb[i] = upd_param(p0, 1.0f, sp, bu.lr);
         } else if (i >= f.ldh && i - f.ldh < bu.V) {
             const int64_t j = i - f.ldh;
-            const float sp = bu.vbs[j];
+            const float sp = bu.vbs[j], p0 = bu.vb[j];
             bu.vbs[j] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
-            bu.vb[j] = upd_param(bu.vb[j], 1.0f, sp, bu.lr);
+            bu.vb[j] = upd_param(p0, 1.0f, sp, bu.lr);
         }
     }
 }
