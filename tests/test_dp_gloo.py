@@ -179,7 +179,10 @@ def worker(rank, world, port, outdir, gauss, overlap):
     torch.set_num_threads(1)
     from mdbn_amd import dist
     dist.init_from_env(backend="gloo")
-    if gauss == 3:
+    if gauss == 6:                     # the opt-in bfloat16 wire format (not a parity path)
+        os.environ["MDBN_WIRE_BF16"] = "1"
+        out = run_steps(1, overlap, True)
+    elif gauss == 3:
         out = run_pcd(True)
     elif gauss == 4:
         out = run_mdbn(True)
@@ -197,7 +200,7 @@ def dp_results():
     res = {}
     with tempfile.TemporaryDirectory() as d:
         # 2 = two step functions interleaved, 3 = PCD (synchronous only), 4 = MDBN stack (row-sharded), 5 = modality-parallel
-        for gauss in (1, 0, 2, 3, 4, 5):
+        for gauss in (1, 0, 2, 3, 4, 5, 6):
             for overlap in ((0,) if gauss in (3, 4, 5) else (0, 1)):
                 mp.spawn(worker, args=(2, free_port(), d, gauss, overlap), nprocs=2, join=True)
                 res[(gauss, overlap)] = [dict(np.load(os.path.join(d, "rank%d_%d_%d.npz" % (r, gauss, overlap))))
@@ -221,6 +224,21 @@ def test_overlap_is_bit_identical_to_sync(dp_results, gauss):
     sync, ovl = dp_results[(gauss, 0)][0], dp_results[(gauss, 1)][0]
     for k in sync:
         assert np.array_equal(sync[k], ovl[k]), k
+
+
+def test_bf16_wire_format_is_an_opt_in_reporting_mode(dp_results):
+    """MDBN_WIRE_BF16=1 (half the bytes per all-reduce): the statistics cross the wire as bfloat16 and come
+    back widened.  Not a parity path -- the replicas still agree bit for bit with each other, the overlapped order with the
+    synchronous one, and the run stays within bfloat16's 8 bits of the float wire's; it must NOT equal it."""
+    exact = dp_results[(1, 0)][0]
+    for overlap in (0, 1):
+        r0, r1 = dp_results[(6, overlap)]
+        for k in exact:
+            assert np.array_equal(r0[k], r1[k]), "replicas diverged: %s" % k
+            assert np.abs(r0[k] - exact[k]).max() <= 2e-2 * max(1e-3, np.abs(exact[k]).max()), k
+        assert not np.array_equal(r0["Ws"], exact["Ws"]), "the wire format was not used"
+    for k in exact:
+        assert np.array_equal(dp_results[(6, 0)][0][k], dp_results[(6, 1)][0][k]), k
 
 
 def test_two_step_functions_of_equal_shape_do_not_share_pending_statistics(dp_results):
