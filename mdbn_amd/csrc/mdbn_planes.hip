@@ -39,6 +39,9 @@ typedef short ps16x8 __attribute__((ext_vector_type(8)));
 typedef float pf32x16 __attribute__((ext_vector_type(16)));
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef PL_ARGS_EARLY
+#define PL_ARGS_EARLY 1
+#endif
 constexpr int PL_PLANE = 8192, PL_STAGE = 6 * PL_PLANE, PL_NSTAGE = 3, PL_LW = 4;
 
 __device__ __forceinline__ void pl_glds16(const void* g, unsigned lds_off, char* smem)
@@ -614,6 +617,13 @@ __global__ __launch_bounds__(64 * (4 + PL_LW)) void gemm_planes_kernel(PlaneGemm
 {
     static_assert(BN == 128 || (BN == 64 && MS == 16 && FUSED == 1 && LB == LAY_K), "64-column tiles: unsplit ROW-operand forward pass");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#if PL_ARGS_EARLY
+    // the kernel arguments every wave needs before its first global access, requested in ONE batch at the top: hipcc loads
+    // kernarg fields where they are first used, and the head of this kernel was three scalar-load round trips in a row
+    // (tile mapping, reduction extent, the operand pointers) before the first LDS-DMA could be issued
+    asm volatile("" :: "s"(g.A), "s"(g.lda), "s"(g.pa), "s"(g.B), "s"(g.ldb), "s"(g.pb), "s"(g.C), "s"(g.ldc), "s"(g.slab_stride),
+                 "s"(g.kchunk), "s"(g.tiles_m), "s"(g.tiles_n), "s"((int)gridDim.x));
+#endif
     // XCD-aware (split, tile) order, as the other GEMM kernels: placement only affects speed
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;

@@ -444,18 +444,23 @@ __global__ __launch_bounds__(SM_NT + 64 * SM_RNG_WAVE) void small_cd_kernel(Smal
     //      four dependent ones -- W, biases, index, rows -- were 3.6 us of a 17-us kernel): the first slab's source-row indices
     //      first, the biases and the first batch of W behind them, then the slab's rows as soon as the indices are back
     //      (vector-memory loads return in order: waiting for the oldest does not wait for the rest).
+    // the slab's rows: ONE 16-byte piece per thread (4 rows x ldv / 4 pieces <= 512: small_ld_ok); the pad columns of X0 are
+    // zeroed once, here -- nobody else writes them
     const int q4x = L.ldx >> 2, dq4 = (int)(ldv >> 2);
-    auto gather_where = [&](int j, int row0, int& r, int& c4) -> bool {      // element j of this thread: (row r, 16-byte piece c4)
-        const int e = tid + j * SM_NT;
-        r = e / q4x; c4 = e - r * q4x;
-        return worker && e < SM_ROWS * q4x && row0 + r < B && c4 < dq4;
-    };
+    const int g_r = tid / dq4, g_c4 = tid - g_r * dq4;                    // this thread's piece: (row of the slab, piece of the row)
+    const bool g_mine = worker && g_r < SM_ROWS;
+    {
+        const int npad = q4x - dq4;
+        if (worker && tid < SM_ROWS * npad) {
+            const int r = tid / npad, cp = dq4 + (tid - r * npad);
+            *(lds_f4*)(c.X0 + r * L.ldx + 4 * cp) = sf32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     const int row0_first = (int)blockIdx.x * SM_ROWS;
-    int64_t srow[2] = {0, 0};
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { int r, c4; if (gather_where(j, row0_first, r, c4)) srow[j] = sm_src_row(a, row0_first + r); }
+    int64_t srow0 = 0;
+    if (g_mine && row0_first + g_r < B) srow0 = sm_src_row(a, row0_first + g_r);
     const float hb_r = tid < H ? a.hbias[tid] : 0.f, vb_r = tid < V ? a.vbias[tid] : 0.f;       // (H, V <= 512 = SM_NT)
-    sf32x4 xg[2] = {sf32x4{0.f, 0.f, 0.f, 0.f}, sf32x4{0.f, 0.f, 0.f, 0.f}};
+    sf32x4 xg = {0.f, 0.f, 0.f, 0.f};
     if (worker) {
         // W image [Vp][ldw]: rows >= V and columns >= ldh zero (the pad columns of W below ldh are zero in memory).  Batches
         // of SM_WB loads per thread in flight, then their LDS stores.
@@ -475,12 +480,7 @@ __global__ __launch_bounds__(SM_NT + 64 * SM_RNG_WAVE) void small_cd_kernel(Smal
             }
             if (e0 == tid) {                                         // the first slab's rows ride behind the first batch
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    int rr, cc;
-                    xg[j] = sf32x4{0.f, 0.f, 0.f, 0.f};
-                    if (gather_where(j, row0_first, rr, cc)) xg[j] = *reinterpret_cast<const sf32x4*>(a.data + srow[j] * a.ld_data + 4 * cc);
-                }
+                if (g_mine && row0_first + g_r < B) xg = *reinterpret_cast<const sf32x4*>(a.data + srow0 * a.ld_data + 4 * g_c4);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -506,22 +506,13 @@ __global__ __launch_bounds__(SM_NT + 64 * SM_RNG_WAVE) void small_cd_kernel(Smal
         // ---- x = train_set_x[indexes] (dbn.py:307): 4 rows into LDS (every thread resolves its own source rows; the first
         //      slab's are already in registers)
         if (slab != (int)blockIdx.x) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                int r, c4;
-                xg[j] = sf32x4{0.f, 0.f, 0.f, 0.f};
-                if (gather_where(j, c.row0, r, c4))
-                    xg[j] = *reinterpret_cast<const sf32x4*>(a.data + sm_src_row(a, c.row0 + r) * a.ld_data + 4 * c4);
-            }
+            xg = sf32x4{0.f, 0.f, 0.f, 0.f};
+            if (g_mine && c.row0 + g_r < B)
+                xg = *reinterpret_cast<const sf32x4*>(a.data + sm_src_row(a, c.row0 + g_r) * a.ld_data + 4 * g_c4);
         }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int r, c4;
-            const bool live = gather_where(j, c.row0, r, c4);
-            if (worker && tid + j * SM_NT < SM_ROWS * q4x) {
-                *(lds_f4*)(c.X0 + r * L.ldx + 4 * c4) = xg[j];
-                if (TAPS && a.keep && live) *reinterpret_cast<sf32x4*>(a.V2 + (int64_t)(c.row0 + r) * ldv + 4 * c4) = xg[j];
-            }
+        if (g_mine) {
+            *(lds_f4*)(c.X0 + g_r * L.ldx + 4 * g_c4) = xg;
+            if (TAPS && a.keep && c.row0 + g_r < B) *reinterpret_cast<sf32x4*>(a.V2 + (int64_t)(c.row0 + g_r) * ldv + 4 * g_c4) = xg;
         }
         SM_SYNC();
         SM_STAMP();
@@ -602,7 +593,8 @@ bool small_shape_ok(int64_t B, int64_t V, int64_t H, int gauss)
 bool small_ld_ok(int64_t V, int64_t H, int64_t ldv, int64_t ldh)
 {
     const SmallLayout L = small_layout((int)V, (int)H, false);
-    return ldh % 4 == 0 && ldv % 4 == 0 && ldh >= H && ldv >= V && ldh <= L.ldw && ldh <= L.H64 && ldv <= L.ldx;
+    return ldh % 4 == 0 && ldv % 4 == 0 && ldh >= H && ldv >= V && ldh <= L.ldw && ldh <= L.H64 && ldv <= L.ldx &&
+           ldv <= SM_NT;      // (4 rows x ldv / 4 pieces of a slab: one per thread)
 }
 
 hipError_t launch_small_cd(const SmallCdArgs& a, hipStream_t s)
