@@ -1188,6 +1188,11 @@ template <int NS, int CW, int MODE = -1>
 __global__ __launch_bounds__(256) void act_epilogue_kernel(EpiArgs e)
 {
     __shared__ float red[4];
+    // the arguments needed before the slab loads, requested in ONE batch (hipcc loads kernarg fields where they are first used:
+    // three scalar-load round trips in a row at the head of a 6-us launch)
+    asm volatile("" :: "s"(e.slabs), "s"(e.slab_stride), "s"(e.nsplit), "s"(e.rows), "s"(e.cols), "s"(e.ld), "s"(e.bias),
+                 "s"(e.target), "s"(e.ld_target), "s"(e.target_idx), "s"(e.mean_planes), "s"(e.plane_stride), "s"(e.sample_plane),
+                 "s"(e.colsum), "s"(e.target_idx64), "s"((int)blockDim.x));
     const bool is_gauss = MODE < 0 ? e.gauss != 0 : (MODE & 2) != 0;
     const int ldc = (int)(e.ld / CW);                    // column groups per row
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -632,6 +632,9 @@ hipError_t launch_small_cd(const SmallCdArgs& a, hipStream_t s)
 // ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinArgs f)
 {
+    // (the arguments needed before the first load, requested in one batch: see gemm_planes_kernel)
+    asm volatile("" :: "s"(f.part), "s"(f.nparts), "s"(f.n4p), "s"(f.V), "s"(f.q4), "s"(f.tiles_dn), "s"(f.lanes), "s"(f.do_upd),
+                 "s"(f.upd.W), "s"(f.upd.Ws), "s"(f.upd.W0), "s"((int)gridDim.x));
     const int G = f.lanes, ipb = 256 / G;
     const int nbw = (int)((f.n4p + ipb - 1) / ipb);
     if ((int)blockIdx.x < nbw) {
