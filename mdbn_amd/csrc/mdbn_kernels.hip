@@ -338,9 +338,18 @@ __device__ __forceinline__ void gemm_consume(const GemmArgs& g, const float* __r
 // CW: consumer (MFMA) waves per SIMD.  1: four consumers with a 2x2 grid of (32*MI)x(32*NI) wave tiles.
 // 2: eight consumers, 2x4 grid of (32*MI)x(16*NI) wave tiles -- the two MFMA waves of a SIMD cover each
 // other's LDS-return stalls (needs NI == 2; unfused kernels only).
+// The kernel arguments a GEMM kernel needs before its first global access, requested in ONE batch at the top: hipcc loads
+// kernarg fields where they are first used, which put two to four scalar-load round trips in a row at the head of every
+// launch (plane GEMMs: same-box 143.3 -> 141.6 us per headline step, profiles/r04zy_args_early_ab.log).
+#define MDBN_GEMM_ARGS_EARLY(G)                                                                                         \
+    asm volatile("" :: "s"((G).A), "s"((G).B), "s"((G).C), "s"((G).lda), "s"((G).ldb), "s"((G).ldc), "s"((G).slab_stride),   \
+                 "s"((G).M), "s"((G).N), "s"((G).K), "s"((G).Nst), "s"((G).kchunk), "s"((G).splitk), "s"((G).tiles_m),       \
+                 "s"((G).tiles_n), "s"((int)gridDim.x))
+
 template <int LA, int LB, int MI, int NI, int KB, int FUSED, int CW>
 __global__ __launch_bounds__(64 * (4 * CW + 4)) void gemm_splitk_kernel(GemmArgs g)
 {
+    MDBN_GEMM_ARGS_EARLY(g);
     constexpr int BM = 64 * MI, BN = 64 * NI;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -658,6 +667,7 @@ __device__ __forceinline__ void x6_produce(const float* __restrict__ P, int64_t 
 template <int LA, int LB, int FUSED, int AP = 3, bool RAGGED = false, int PW = 2>
 __global__ __launch_bounds__(64 * (4 + 2 * PW)) void gemm_bf16x6_kernel(GemmArgs g)
 {
+    MDBN_GEMM_ARGS_EARLY(g);
     constexpr int BM = 128, BN = 128, KB = X6_KB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned char* const lds = reinterpret_cast<unsigned char*>(smem);
@@ -961,6 +971,7 @@ __device__ __forceinline__ float4 skinny_load_operand(const float* p, int64_t ld
 template <int LA, int LB, int MI, int FUSED>
 __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmArgs g)
 {
+    MDBN_GEMM_ARGS_EARLY(g);
     constexpr int NW = SKINNY_WAVES, U = SKINNY_U, LDT = SKINNY_LDT, BM = 32 * MI;
     extern __shared__ __attribute__((aligned(16))) float smem[];      // [NW][BM][LDT] (+ 8)
     // block -> (K range, row tile, 32-column strip), strips fastest
