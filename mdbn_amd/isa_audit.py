@@ -198,3 +198,37 @@ def audit_source(source_path, flags, hipcc="/opt/rocm/bin/hipcc", defines=()):
     report["source"] = os.path.basename(source_path)
     report["hipcc"] = hipcc_version(hipcc)
     return report
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Wait report: where a kernel sits on a memory round trip it need not sit on.  Not a correctness audit -- a reading aid
+# that found, in round 4, the serialised slab loads of the activation epilogues (a convert-and-add behind every predicated
+# load), the four index lookups in a row at the head of every epilogue with a cost target, the gather-ahead's index lookups
+# that drained the LDS-DMA ring mid-loop, and kernel arguments fetched in three or four batches at a kernel's head.
+# ----------------------------------------------------------------------------------------------------------------------
+def wait_report(text, window=3):
+    """Per kernel of an assembly file: ``loads`` (vector-memory loads, LDS-DMA excluded), ``waited_at_once`` (loads with an
+    ``s_waitcnt vmcnt(0)`` within ``window`` instructions behind them: each is a full round trip nothing overlaps) and
+    ``kernarg_batches`` (groups of ``s_load`` from the kernarg pointer ``s[0:1]`` separated by a ``lgkmcnt`` wait: every
+    batch after the first is a scalar round trip the kernel's head could have shared).  Returns {kernel: dict}."""
+    out = {}
+    for name, lines in kernels(text):
+        code = [t.strip().split(";")[0].strip() for t in lines]
+        code = [t for t in code if t and t[0] not in ".;" and not t.endswith(":")]
+        loads = at_once = 0
+        batches, open_batch = 0, False
+        for i, t in enumerate(code):
+            op = t.split()[0]
+            if (op.startswith("global_load") and not op.startswith("global_load_lds")) or op.startswith("buffer_load") or \
+                    op.startswith("flat_load"):
+                loads += 1
+                if any(c.startswith("s_waitcnt") and "vmcnt(0)" in c for c in code[i + 1:i + 1 + window]):
+                    at_once += 1
+            if op.startswith("s_load") and "s[0:1]" in t:
+                if not open_batch:
+                    batches, open_batch = batches + 1, True
+            elif op == "s_waitcnt" and "lgkmcnt" in t:
+                open_batch = False
+        out[name] = {"loads": loads, "waited_at_once": at_once, "kernarg_batches": batches}
+    return out
+

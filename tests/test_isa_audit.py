@@ -94,3 +94,12 @@ def test_the_build_records_its_verdict(built_lib):
     v = build.audit_verdicts()
     assert "mdbn_planes.hip" in v and v["mdbn_planes.hip"]["loads"] > 0 and v["mdbn_planes.hip"]["findings"] == []
     assert "clang" in v["mdbn_planes.hip"]["hipcc"].lower() or "hip" in v["mdbn_planes.hip"]["hipcc"].lower()
+
+
+def test_wait_report_counts_round_trips_nothing_overlaps():
+    body = ("\ts_load_dwordx4 s[4:7], s[0:1], 0x0\n\ts_waitcnt lgkmcnt(0)\n\ts_load_dword s8, s[0:1], 0x40\n\ts_waitcnt lgkmcnt(0)\n"
+            "\tglobal_load_dword v1, v[2:3], off\n\ts_waitcnt vmcnt(0)\n\tv_add_f32_e32 v4, v1, v1\n"
+            "\tglobal_load_dword v5, v[2:3], off\n\tglobal_load_dword v6, v[2:3], off offset:4\n\tglobal_load_lds_dwordx4 v[34:35], off\n"
+            "\tv_mov_b32_e32 v9, 0\n\tv_mov_b32_e32 v10, 0\n\tv_mov_b32_e32 v11, 0\n\ts_waitcnt vmcnt(0)\n\tv_add_f32_e32 v7, v5, v6\n")
+    r = isa_audit.wait_report(kernel(body))["k"]
+    assert r == {"loads": 3, "waited_at_once": 1, "kernarg_batches": 2}, r
