@@ -555,10 +555,13 @@ __device__ __forceinline__ void fused_tile_epilogue_4x4(const EpiArgs& e, float*
 // stride BN + 8): W and W_speed are read and written once, S never touches HBM.  The GEMM reads
 // only V2 / P2, so updating W in place under it is safe.  A thread owns one float4 column group and
 // walks rows; 4 rows of loads are in flight per round.
+#ifndef FUSED_UPD_RB
+#define FUSED_UPD_RB 4      // rows of W / W_speed (/ W0) loads in flight per thread and round
+#endif
 template <int BM, int BN, int NT = 512>
 __device__ __forceinline__ void fused_update_epilogue(const UpdEpi& u, const float* T, int m0, int n0)
 {
-    constexpr int LDT = BN + 8, C4 = BN / 4, RSTEP = NT / C4, RB = 4;
+    constexpr int LDT = BN + 8, C4 = BN / 4, RSTEP = NT / C4, RB = FUSED_UPD_RB;
     const int c4 = threadIdx.x % C4, rr = threadIdx.x / C4;
     const int col = n0 + 4 * c4;
     if (col >= (int)u.ld) return;
@@ -566,17 +569,19 @@ __device__ __forceinline__ void fused_update_epilogue(const UpdEpi& u, const flo
     const float decay = upd_decay(u.lr, u.l2);
 #pragma unroll 1
     for (int r = rr; r < BM; r += RSTEP * RB) {
+        // (loads unconditional at clamped rows, issued as one batch; only the stores are predicated: with `if (row < rows)
+        //  load`, every row's loads sat in their own block behind a wait)
         float4 w[RB], sp[RB], w0[RB];
+        const float* w0base = u.W0 ? u.W0 : u.W;
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
-            const int row = m0 + r + b * RSTEP;
-            if (r + b * RSTEP < BM && row < u.rows) {
-                const int64_t off = (int64_t)row * u.ld + col;
-                w[b] = *reinterpret_cast<const float4*>(u.W + off);
-                sp[b] = *reinterpret_cast<const float4*>(u.Ws + off);
-                w0[b] = u.W0 ? *reinterpret_cast<const float4*>(u.W0 + off) : w[b];
-            }
+            const int rowc = min(m0 + min(r + b * RSTEP, BM - 1), u.rows - 1);
+            const int64_t off = (int64_t)rowc * u.ld + col;
+            w[b] = *reinterpret_cast<const float4*>(u.W + off);
+            sp[b] = *reinterpret_cast<const float4*>(u.Ws + off);
+            w0[b] = *reinterpret_cast<const float4*>(w0base + off);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
             const int row = m0 + r + b * RSTEP;
