@@ -548,18 +548,9 @@ __global__ __launch_bounds__(SM_NT + 64 * SM_RNG_WAVE) void small_cd_kernel(Smal
     if (wave < L.tiles_dn * L.tiles_up && 64 * tv_w + lane < V) {       // (pad lanes: rows of S that do not exist -- not stored, not read)
         sf32x4* Sp = reinterpret_cast<sf32x4*>(a.part_S) + (int64_t)blockIdx.x * small_part_quads(L, (int)ldh)
                      + (int64_t)(16 * th_w * L.tiles_dn + nq * tv_w) * 64 + lane;
-#ifndef SM_PART_STORE
-#define SM_PART_STORE 1     // 1 = non-temporal stores of the S partial (nobody on this XCD reads them: 10.5 MB of dirty L2 lines at the
-                            // kernel's end cost 4.5 us at 512 -> 40, streamed 3.2: profiles/r04z_small_partial_store_ab.log); 0 = plain;
-                            // 2 = none (experiment: wrong results)
-#endif
-#if SM_PART_STORE == 1
+        // non-temporal stores: nobody on this XCD reads the partial, and 10.5 MB of dirty L2 lines at the kernel's end cost 4.5 us
+        // at 512 -> 40 (measured by not storing them), streamed 3.2 (profiles/r04z_small_partial_store_ab.log)
 #define SM_PUT(U) if ((U) < nq) __builtin_nontemporal_store(accS[U], Sp + (U) * 64);
-#elif SM_PART_STORE == 2
-#define SM_PUT(U) if ((U) < nq && a.B < 0) Sp[(U) * 64] = accS[U];
-#else
-#define SM_PUT(U) if ((U) < nq) Sp[(U) * 64] = accS[U];
-#endif
         SM_PUT(0) SM_PUT(1) SM_PUT(2) SM_PUT(3) SM_PUT(4) SM_PUT(5) SM_PUT(6) SM_PUT(7)
         SM_PUT(8) SM_PUT(9) SM_PUT(10) SM_PUT(11) SM_PUT(12) SM_PUT(13) SM_PUT(14) SM_PUT(15)
 #undef SM_PUT
