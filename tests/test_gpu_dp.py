@@ -113,6 +113,34 @@ def worker(rank, world, port, outdir, overlap, shape, comm_cus=0, fused=1):
     torch.distributed.destroy_process_group()
 
 
+def wire_worker(rank, world, port, outdir, overlap):
+    os.environ["MDBN_WIRE_BF16"] = "1"
+    worker(rank, world, port, outdir, overlap, "small")
+
+
+def test_bf16_wire_format_on_device(built_lib):
+    """MDBN_WIRE_BF16=1 (opt-in reporting mode, never a parity path): the statistics of the HIP engine cross the wire as
+    bfloat16.  Replicas agree bit for bit, overlapped == synchronous, the run stays within bfloat16's 8 bits of the
+    float-wire run and differs from it."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(worker, args=(2, free_port(), d, 0, "small"), nprocs=2, join=True)
+        exact = dict(np.load(os.path.join(d, "rank0_0.npz")))
+        res = {}
+        for overlap in (0, 1):
+            mp.spawn(wire_worker, args=(2, free_port(), d, overlap), nprocs=2, join=True)
+            res[overlap] = [dict(np.load(os.path.join(d, "rank%d_%d.npz" % (r, overlap)))) for r in range(2)]
+    for overlap in (0, 1):
+        r0, r1 = res[overlap]
+        for k in exact:
+            assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
+            assert np.abs(r0[k] - exact[k]).max() <= 2e-2 * max(1e-3, np.abs(exact[k]).max()), k
+    assert any(not np.array_equal(res[0][0][k], exact[k]) for k in exact), "the wire format was not used"
+    for k in exact:
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
+
+
 @pytest.mark.parametrize("shape", ["small", "c2"])
 def test_two_ranks_equal_one_process_on_device(built_lib, shape):
     if not torch.cuda.is_available():
