@@ -54,9 +54,11 @@ def _run_device(engine, case):
     return out
 
 
-# absolute tolerances, fp32 device vs f64 golden; S and the speeds scale with B
-TOL = dict(ph_mean=2e-6, nh_mean=5e-6, nv_mean=2e-5, s_h=2e-5, s_v=2e-4, W=2e-6, hbias=2e-6,
-           vbias=2e-6, W_speed=5e-6, hbias_speed=5e-6, vbias_speed=2e-5)
+# absolute tolerances relative to max(1, max|golden|), fp32 device vs f64 golden: SURVEY 8d's table as it stands --
+# probabilities and nv_mean 2e-6, the statistics (S, s_h, s_v) 1e-5 rel-to-max, W after the steps 1e-6 -> 2e-6 over three
+# steps; nh_mean 4e-6 (the one documented excess, DESIGN "tolerance table": it is formed from the device's own nv_mean)
+TOL = dict(ph_mean=2e-6, nh_mean=4e-6, nv_mean=2e-6, s_h=1e-5, s_v=1e-5, W=2e-6, hbias=2e-6,
+           vbias=2e-6, W_speed=5e-6, hbias_speed=5e-6, vbias_speed=1e-5)
 
 
 @pytest.mark.gpu
