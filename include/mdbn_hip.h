@@ -151,7 +151,10 @@ int  mdbn_source_hash(char *buf, size_t n);
 int  mdbn_ctx_create(mdbn_ctx **out, int device);
 int  mdbn_ctx_destroy(mdbn_ctx *ctx);
 
-/* Tuning knobs (process-wide; results never change beyond fp32 summation order).
+/* Tuning knobs, PER CONTEXT (round 5): mdbn_set_option(ctx, ...) changes what calls made on `ctx` launch and nothing
+ * else -- two contexts of one process (two engines, modality-parallel placement in-process) keep their own settings; the
+ * context-free sizing calls (mdbn_workspace_bytes, mdbn_planes_eligible) answer for a context with default options, their
+ * _ctx forms for the given one.  Results never change beyond fp32 summation order.
  * "gemm_bf16x6" (default 3): bit 0 = statistics GEMM, bit 1 = forward GEMMs run on the bf16 matrix pipe
  *   with exactly split f32 operands and f32 accumulation (f32-grade results) when the problem is made of
  *   whole 128x128 tiles; 0 = always the exact-f32 MFMA kernel.
@@ -192,6 +195,11 @@ int  mdbn_ctx_destroy(mdbn_ctx *ctx);
  *   every operand (one product instead of six; probabilities off by ~4e-3).
  * "update_overlap": 1 = mdbn_cd_train_step overlaps part of the update with the statistics GEMM
  * on a side stream (default 0: measured slower, see csrc/mdbn_capi.hip).
+ * "thin_fused" (default 1): minibatches of <= 32 rows (the reference's batch_size = 20, MDBN.py:46) on layers that are not
+ *   LDS-resident (ldh <= 512) run as a stream over W (csrc/mdbn_thin.hip): the positive phase and each gibbs_hvh read W
+ *   once (propdown and the following propup share one read: a workgroup owns whole rows of W), the rank-2B statistics are
+ *   formed in registers inside the update pass -- W is read 2 + k times and written once per CD-k step.  0: the
+ *   register-streaming GEMM path.
  * "small_fused" (default 1): a layer whose W fits one CU's LDS (V, H <= 512, W image + row buffers <= 160 KB: 512 -> 40,
  *   400 -> 40, 200 -> 20, 100 -> 128, 100 -> 24 -> 3) runs the whole CD-k chain in ONE launch per step -- W staged once, each
  *   workgroup the whole chain for 4-row slabs on v_mfma_f32_4x4x1 out of LDS, partial statistics per workgroup -- plus a
@@ -220,6 +228,8 @@ int  mdbn_kernel_timing_detail(mdbn_ctx *ctx, int64_t cap, double *ms, double *a
 
 /* bytes of split-K / reduction scratch the calls below need for shapes up to (B, V, H) */
 int  mdbn_workspace_bytes(int64_t B, int64_t V, int64_t H, int64_t *bytes);
+/* ... under the options of `ctx` (the plans, hence the scratch, depend on them) */
+int  mdbn_workspace_bytes_ctx(mdbn_ctx *ctx, int64_t B, int64_t V, int64_t H, int64_t *bytes);
 /* leading dimension this library recommends for a [., cols] matrix (currently round_up(cols, 4);
  * see the measurement note in csrc/mdbn_capi.hip).  Any ld % 4 == 0, ld >= cols is accepted. */
 int  mdbn_padded_ld(int64_t cols, int64_t *ld);
@@ -235,6 +245,7 @@ int  mdbn_planes_alt_bytes(int64_t B, int64_t ldv, int64_t *bytes);
  * without a persistent chain, no sample_stats and no GRBM noise.)  W planes handed to a step with W_planes_valid = 0
  * are re-split on entry whichever path the step takes, so they are valid after ANY step that received them. */
 int  mdbn_planes_eligible(int64_t B, int64_t V, int64_t H, int64_t ldv, int64_t ldh, int32_t *eligible);
+int  mdbn_planes_eligible_ctx(mdbn_ctx *ctx, int64_t B, int64_t V, int64_t H, int64_t ldv, int64_t ldh, int32_t *eligible);
 /* exact three-way bf16 split of an f32 matrix [rows, ld] into planes [3][rows][ld] (x = p1 + p2 + p3) */
 int  mdbn_split_planes(mdbn_ctx *ctx, void *stream, const float *x, int64_t rows, int64_t ld, void *planes);
 /* floats in the packed statistics buffer [S (V*ldh) | s_h (ldh) | s_v (ldv) | 4] */

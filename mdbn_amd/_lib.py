@@ -71,10 +71,12 @@ SIGNATURES = {
     "mdbn_kernel_timing_detail": [_vp, _i64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(_i64)],
     "mdbn_workspace_bytes": [_i64, _i64, _i64, C.POINTER(_i64)],
+    "mdbn_workspace_bytes_ctx": [_vp, _i64, _i64, _i64, C.POINTER(_i64)],
     "mdbn_padded_ld": [_i64, C.POINTER(_i64)],
     "mdbn_planes_bytes": [_i64, _i64, _i64, C.POINTER(_i64)],
     "mdbn_planes_alt_bytes": [_i64, _i64, C.POINTER(_i64)],
     "mdbn_planes_eligible": [_i64, _i64, _i64, _i64, _i64, C.POINTER(_i32)],
+    "mdbn_planes_eligible_ctx": [_vp, _i64, _i64, _i64, _i64, _i64, C.POINTER(_i32)],
     "mdbn_split_planes": [_vp, _vp, _vp, _i64, _i64, _vp],
     "mdbn_stats_floats": [_i64, _i64, _i64, C.POINTER(_i64)],
     "mdbn_gather_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _i64, _vp, _i64],

@@ -21,21 +21,42 @@
 #include <vector>
 #include "mdbn_kernels.h"
 #include "mdbn_small.h"
+#include "mdbn_thin.h"
 
 using namespace mdbn;
 
-struct mdbn_ctx {
-    int device;
-    int num_cu;
-    // mdbn_cd_forward -> mdbn_cd_statistics hand-over (host side only): the cost partials the chain's last visible pass left
-    int pending_n_cost = -1;
-    const void* pending_stats = nullptr;
-    void* comm = nullptr;      // ncclComm_t of mdbn_comm_init_rank (RCCL), or NULL
-    int comm_ranks = 0;
-    // side stream + events for mdbn_cd_train_step (memory-bound update work overlapped with the
-    // compute-bound statistics GEMM); created on first use
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+// Tuning knobs of ONE context (mdbn_set_option(ctx, ...) writes ctx->opt; a knob set on one context never changes what
+// another context of the process launches).  The option comments sit beside the g_opt_* names below, which read the
+// options of the context whose call is running on this thread (CtxScope).
+struct Options {
+    int gemm_bk = 0;
+    int x6_min_jobs = 48;
+    int x6_pw = 4;
+    int gemm_cw = 0;
+    int update_overlap = 0;
+    int fused_epilogue = 1;
+    int fused_update = 1;
+    int fused_finalize = 1;
+    int skinny_gemm = 1;
+    int skinny_fused_max_k = 1024;
+    int64_t skinny_max_macs = 32ll << 20;
+    int gemm_bf16x6 = 3;
+    int small_fused = 1;
+    int thin_fused = 1;
+    int gemm_planes = 1;
+    int planes_mfma = 16;
+    int early_w = 1;
+    int narrow_tiles = 1;
+    int feed_copy_streams = 1;
+    int gather_ahead = 1;
+    int bf16_inputs = 0;
+    int64_t planes_min_work = (int64_t)1 << 30;
+    int comm_cus = 0;
+    int bal_blocks = 0;
+    int min_splitk = 128;
+    int epilogue_cw = 0;
+    int epilogue_threads = 0;
+    int small_fin_lanes = 0;
 };
 
 // Optional HIP-event timing of the GEMM launches (the dominant kernel), used by bench.py to
@@ -48,7 +69,46 @@ struct GemmTiming {
     std::vector<Meta> meta;
     size_t used = 0;
 };
-static GemmTiming g_timing;
+
+struct mdbn_ctx {
+    int device;
+    int num_cu;
+    Options opt;
+    GemmTiming timing;                  // mdbn_kernel_timing: per context
+    // mdbn_cd_forward -> mdbn_cd_statistics hand-over (host side only): the cost partials the chain's last visible pass left
+    int pending_n_cost = -1;
+    const void* pending_stats = nullptr;
+    void* comm = nullptr;      // ncclComm_t of mdbn_comm_init_rank (RCCL), or NULL
+    int comm_ranks = 0;
+    // side stream + events for mdbn_cd_train_step (memory-bound update work overlapped with the
+    // compute-bound statistics GEMM); created on first use
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+
+
+// The options / timing records a library call reads are those of the context it was made on: every entry point that takes
+// a context opens a CtxScope; context-free entry points (mdbn_workspace_bytes, mdbn_planes_eligible, ...) see the defaults
+// of a fresh context.
+static const Options g_default_options;
+static GemmTiming g_no_timing;                          // calls outside any context record nothing
+static thread_local const Options* t_opt = &g_default_options;
+static thread_local GemmTiming* t_timing = &g_no_timing;
+#define g_timing (*t_timing)
+struct CtxScope {
+    const Options* prev_opt; GemmTiming* prev_timing;
+    explicit CtxScope(mdbn_ctx* c) : prev_opt(t_opt), prev_timing(t_timing)
+    {
+        if (c) {
+            t_opt = &c->opt; t_timing = &c->timing;
+            set_epilogue_cw(c->opt.epilogue_cw); set_epilogue_threads(c->opt.epilogue_threads);
+            g_small_fin_lanes = c->opt.small_fin_lanes;
+        }
+    }
+    ~CtxScope() { t_opt = prev_opt; t_timing = prev_timing; }
+    CtxScope(const CtxScope&) = delete;
+    CtxScope& operator=(const CtxScope&) = delete;
+};
 
 namespace {
 
@@ -78,25 +138,25 @@ int fail(int code, const char* fmt, ...)
         if (!(cond)) return fail(MDBN_EINVAL, __VA_ARGS__); \
     } while (0)
 
-static int g_opt_gemm_bk = 0;          // mdbn_set_option("gemm_bk"): 0 = auto, 32, 64
-static int g_opt_x6_min_jobs = 48;     // mdbn_set_option("x6_min_jobs"): fewer 128x128-tile jobs than this keep the exact kernel (192 -> 48: 1024->256 and 512^3 at B = 512 -6%)
-static int g_opt_x6_pw = 4;            // mdbn_set_option("x6_producer_waves"): bf16x6 producer waves per operand (2 | 4); 4: step 162.4 -> 158.3 us
-static int g_opt_gemm_cw = 0;          // mdbn_set_option("gemm_cw"): MFMA waves per SIMD of the tiled GEMM, 0 = auto, 1, 2
+#define g_opt_gemm_bk (t_opt->gemm_bk)          // mdbn_set_option("gemm_bk"): 0 = auto, 32, 64
+#define g_opt_x6_min_jobs (t_opt->x6_min_jobs)     // mdbn_set_option("x6_min_jobs"): fewer 128x128-tile jobs than this keep the exact kernel (192 -> 48: 1024->256 and 512^3 at B = 512 -6%)
+#define g_opt_x6_pw (t_opt->x6_pw)            // mdbn_set_option("x6_producer_waves"): bf16x6 producer waves per operand (2 | 4); 4: step 162.4 -> 158.3 us
+#define g_opt_gemm_cw (t_opt->gemm_cw)          // mdbn_set_option("gemm_cw"): MFMA waves per SIMD of the tiled GEMM, 0 = auto, 1, 2
 // mdbn_set_option("update_overlap"): run finalize + the parameter half of the update on a side
 // stream under the statistics GEMM.  Measured (profile r01j): the fork/join events cost more than
 // the ~12 us they hide (278.7 vs 259.6 us per step), so it is off by default.
-static int g_opt_update_overlap = 0;
+#define g_opt_update_overlap (t_opt->update_overlap)
 // mdbn_set_option("fused_epilogue"): apply the activation epilogue on the MFMA accumulators when a
 // GEMM needs no split-K (default on)
-static int g_opt_fused_epilogue = 1;
+#define g_opt_fused_epilogue (t_opt->fused_epilogue)
 // mdbn_set_option("fused_update"): mdbn_cd_train_step applies the update inside the statistics GEMM
 // when that GEMM is not split, and lets the update kernel sum the split-K slabs when it is
 // (default on); the S block of `stats` is then not materialised
-static int g_opt_fused_update = 1;
+#define g_opt_fused_update (t_opt->fused_update)
 // mdbn_set_option("fused_finalize"): ... and runs the bias statistics / cost / bias update inside that GEMM too
-static int g_opt_fused_finalize = 1;
+#define g_opt_fused_finalize (t_opt->fused_finalize)
 constexpr int kTargetJobs = 256;       // one 8-wave tile job per CU (MI355X: 256 CUs)
-static int kMinSplitK = 128;           // >= 4 slices of BK = 32 per split (mdbn_set_option "gemm_min_splitk")
+#define kMinSplitK (t_opt->min_splitk)     // >= 4 slices of BK = 32 per split (mdbn_set_option "gemm_min_splitk")
 
 inline int64_t ru4(int64_t x) { return (x + 3) & ~int64_t(3); }
 // Leading-dimension policy (mdbn_padded_ld).  Padding 1-KiB-multiple rows by 64 floats (to spread
@@ -156,16 +216,16 @@ Plan plan_gemm(int64_t M, int64_t N, int64_t K)
 
 // mdbn_set_option("skinny_gemm"): route GEMMs of <= 64 output rows, and small-layer GEMMs whose
 // operands are L2-resident, to the register-streaming skinny_gemm_kernel (default on)
-static int g_opt_skinny_gemm = 1;
+#define g_opt_skinny_gemm (t_opt->skinny_gemm)
 constexpr int kSkinnyTargetBlocks = 512;   // two 8-wave blocks per CU
 constexpr int kSkinnyMinK = 256;           // >= 4 octets per wave
-static int g_opt_skinny_fused_max_k = 1024;   // up to here one block streams the whole K range
+#define g_opt_skinny_fused_max_k (t_opt->skinny_fused_max_k)   // up to here one block streams the whole K range
 // Above 64 rows the streaming kernel only pays for problems so small that the chain of dependent
 // launches is the whole cost; every register batch exposes an L2 latency, so long per-wave K
 // streams (K > 512) get a third of the budget.  Measured at B = 512 (scripts/skinny_macs_ab.py):
 // 400->40 76 -> 52 us, 256->200 72 -> 48, 100->128 69 -> 41, 512->40 CD-5 164 -> 124; 1024->256
 // (134 M MACs per pass) 76 either way; 256x200 statistics over K = 1024 (52 M) 5 us slower.
-static int64_t g_opt_skinny_max_macs = 32ll << 20;
+#define g_opt_skinny_max_macs (t_opt->skinny_max_macs)
 
 // Skinny plan of out[M, N (ldo stored)] over K: (32*mi)-row tiles x 32-column strips x K ranges.
 Plan plan_skinny(int64_t M, int64_t K, int64_t ldo, bool allow_split)
@@ -205,43 +265,47 @@ bool prefer_skinny(int64_t M, int64_t N, int64_t K)
 // mdbn_set_option("gemm_bf16x6"): GEMMs of full 128x128 tiles run on the bf16 matrix pipe with three-way
 // split operands (f32 accuracy, see gemm_bf16x6_kernel); bit 0 = statistics GEMM, bit 1 = forward
 // passes; default 3
-static int g_opt_gemm_bf16x6 = 3;
+#define g_opt_gemm_bf16x6 (t_opt->gemm_bf16x6)
 // mdbn_set_option("gemm_planes"): the CD step runs on pre-split bf16 planes (mdbn_planes.hip) when the caller
 // supplies the plane buffers and the shape is made of whole 128-row / 128-column tiles (default on)
 // mdbn_set_option("small_fused"): layers whose W fits one CU's LDS run the whole CD-k chain in ONE launch + a small finish
 // launch (mdbn_small.hip); 0 = the multi-launch path (register-streaming GEMMs, fused epilogues)
-static int g_opt_small_fused = 1;
-static int g_opt_gemm_planes = 1;
+#define g_opt_small_fused (t_opt->small_fused)
+// mdbn_set_option("thin_fused"): minibatches of <= 32 rows (the reference's batch_size = 20) on layers that are not
+// LDS-resident run the stream-over-W step of mdbn_thin.hip (W read 2 + k times per CD-k step); 0 = the register-streaming
+// GEMM path
+#define g_opt_thin_fused (t_opt->thin_fused)
+#define g_opt_gemm_planes (t_opt->gemm_planes)
 // mdbn_set_option("planes_mfma"): MFMA shape of the plane GEMMs: 16 = v_mfma_f32_16x16x32_bf16 (default: the chip holds
 // a higher clock on it), 32 = v_mfma_f32_32x32x16_bf16 (the products and order of gemm_bf16x6_kernel: same bits as the
 // f32-operand path)
-static int g_opt_planes_mfma = 16;
+#define g_opt_planes_mfma (t_opt->planes_mfma)
 // mdbn_set_option("early_w"): the statistics GEMM's loader waves apply the parameter half of the fused update during the
 // main loop (W' needs only the old W and the old speed), the epilogue only forms the new speed (default on; same bits)
-static int g_opt_early_w = 1;
+#define g_opt_early_w (t_opt->early_w)
 // mdbn_set_option("narrow_tiles"): forward passes whose 128 x 128 plan would split K two ways run unsplit on 128 x 64 tiles
 // with the fused activation epilogue instead (default on)
-static int g_opt_narrow_tiles = 1;
+#define g_opt_narrow_tiles (t_opt->narrow_tiles)
 // mdbn_set_option("feed_copy_streams"): a row feeder created afterwards moves each minibatch as 1 or 2 copies on as many
 // streams (two SDMA engines side by side)
-static int g_opt_feed_copy_streams = 1;
+#define g_opt_feed_copy_streams (t_opt->feed_copy_streams)
 // mdbn_set_option("gather_ahead"): honour mdbn_cd_args.next_indexes (default on; same bits)
-static int g_opt_gather_ahead = 1;
+#define g_opt_gather_ahead (t_opt->gather_ahead)
 // mdbn_set_option("bf16_inputs"): REPORTING mode of BASELINE configs[1] ("bf16/fp32"): the plane GEMMs use only the
 // leading bf16 piece of every operand (inputs truncated to bf16, f32 accumulation, one product instead of six).
 // Probabilities then carry ~4e-3 of error: never used for a parity claim, off by default.
-static int g_opt_bf16_inputs = 0;
+#define g_opt_bf16_inputs (t_opt->bf16_inputs)
 // mdbn_set_option("planes_min_work"): the plane path serves a whole-tile shape only from B * V * H >= this on (and V * H
 // >= 2^21): below, the launches of a step are so short that writing every tensor twice (f32 + planes) costs more than the
 // cheaper GEMMs gain (c4's second layer 1024 -> 256 at B = 512: 69.2 us on the f32-operand kernels, 77.3 on planes;
 // 2048 -> 1024: 122.9 vs 118.9; c2: 158.7 vs 150).  0: every whole-tile shape (tests).
-static int64_t g_opt_planes_min_work = (int64_t)1 << 30;
+#define g_opt_planes_min_work (t_opt->planes_min_work)
 // mdbn_set_option("comm_cus"): CUs left to a collective that runs beside the step (data-parallel mode).  > 0: the plane
 // GEMMs of mdbn_cd_step are launched BALANCED on (CUs - comm_cus) workgroups (mdbn_planes.hip, "BALANCED launches"):
 // a collective's kernel takes whole CUs, and a one-workgroup-per-CU grid on fewer CUs needs a second round (measured:
 // 163 -> 219 us per step with 8 CUs taken, scripts/dp_contention_probe.py).  0 (default): one workgroup per CU.
-static int g_opt_comm_cus = 0;
-static int g_opt_bal_blocks = 0;       // "bal_blocks" (tests): the number of workgroups itself, whatever the device has
+#define g_opt_comm_cus (t_opt->comm_cus)
+#define g_opt_bal_blocks (t_opt->bal_blocks)       // "bal_blocks" (tests): the number of workgroups itself, whatever the device has
 constexpr int kMaxBalBlocks = 256;
 
 // Turn an LDS-tiled plan into a bf16x6 plan (128x128 tiles, 32-deep slices) when that leaves enough
@@ -369,12 +433,21 @@ static WsSizes ws_sizes_dense(int64_t B, int64_t V, int64_t H)
     }
     if (small_shape_ok(B, V, H, 0) || small_shape_ok(B, V, H, 1))       // one S partial per workgroup of the one-launch step
         s.slab = std::max<int64_t>(s.slab, (int64_t)small_blocks(B) * ((V + 63) & ~int64_t(63)) * ldh);   // (pad lanes included)
+    int64_t thin_cost = 0;
+    {       // thin-batch step (mdbn_thin.hip): one [Bq, ldh] partial and one cost partial per workgroup of a pass
+        ThinGeom tg;
+        if (thin_geom(B, V, H, ldv, ldh, kTargetJobs, tg)) {
+            s.slab = std::max<int64_t>(s.slab, (int64_t)tg.G * tg.Bq * ldh);
+            thin_cost = tg.G;
+        }
+    }
     s.slab = std::max<int64_t>(s.slab, 4 * std::max(ldv, ldh) * 8);
     s.cost = std::max<int64_t>(256, (((B + 3) / 4) * std::max(ldv, ldh) + 63) / 64) + 64;   // worst case: one column per thread, 64-thread blocks
     // fused epilogues write one partial per block: 128 x 64 tiles, or 32-column strips (skinny)
     s.cost = std::max<int64_t>(s.cost, ((B + 127) / 128) * ((std::max(ldv, ldh) + 63) / 64) + 64);
     s.cost = std::max<int64_t>(s.cost, ((B + 63) / 64) * ((std::max(ldv, ldh) + 31) / 32) + 64);
     if (small_shape_ok(B, V, H, 0) || small_shape_ok(B, V, H, 1)) s.cost = std::max<int64_t>(s.cost, (int64_t)small_blocks(B) * SM_NW + 64);   // a cost partial per wave
+    s.cost = std::max<int64_t>(s.cost, thin_cost + 64);
     const int ng = row_groups(B);
     s.colP = 2 * (int64_t)ng * ldh;
     s.colV = (int64_t)ng * ldv;
@@ -940,6 +1013,7 @@ int mdbn_comm_destroy(mdbn_ctx* ctx);
 
 int mdbn_ctx_destroy(mdbn_ctx* ctx)
 {
+    CtxScope ctx_scope(ctx);
     if (ctx) {
         if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
         if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -967,125 +1041,130 @@ int mdbn_bal_segment(int32_t tiles, int32_t stages, int32_t workgroups, int32_t 
 
 int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx != nullptr && name != nullptr, "NULL argument");
     if (strcmp(name, "gemm_bk") == 0) {
         REQUIRE(value == 0 || value == 32 || value == 64, "gemm_bk must be 0 (auto), 32 or 64");
-        g_opt_gemm_bk = (int)value;
+        ctx->opt.gemm_bk = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "epilogue_threads") == 0) {
         if (value != 0 && value != 64 && value != 128 && value != 256) return fail(MDBN_EINVAL, "epilogue_threads must be 0, 64, 128 or 256");
-        set_epilogue_threads((int)value);
+        ctx->opt.epilogue_threads = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "epilogue_cw") == 0) {
         REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "epilogue_cw must be 0 (auto), 1, 2 or 4");
-        set_epilogue_cw((int)value);
+        ctx->opt.epilogue_cw = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "skinny_gemm") == 0) {
-        g_opt_skinny_gemm = value != 0;
+        ctx->opt.skinny_gemm = value != 0;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "thin_fused") == 0) {
+        ctx->opt.thin_fused = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "skinny_fused_max_k") == 0) {
-        g_opt_skinny_fused_max_k = value;
+        ctx->opt.skinny_fused_max_k = value;
         return MDBN_OK;
     }
     if (strcmp(name, "x6_min_jobs") == 0) {
-        g_opt_x6_min_jobs = (int)value;
+        ctx->opt.x6_min_jobs = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "x6_producer_waves") == 0) {
         if (value != 2 && value != 4) return fail(MDBN_EINVAL, "x6_producer_waves must be 2 or 4");
-        g_opt_x6_pw = (int)value;
+        ctx->opt.x6_pw = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "gemm_min_splitk") == 0) {
         if (value < 32) return fail(MDBN_EINVAL, "gemm_min_splitk must be >= 32");
-        kMinSplitK = (int)value;
+        ctx->opt.min_splitk = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "gemm_cw") == 0) {
         if (value < 0 || value > 2) return fail(MDBN_EINVAL, "gemm_cw must be 0 (auto), 1 or 2");
-        g_opt_gemm_cw = (int)value;
+        ctx->opt.gemm_cw = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "skinny_max_macs") == 0) {
-        g_opt_skinny_max_macs = value;
+        ctx->opt.skinny_max_macs = value;
         return MDBN_OK;
     }
     if (strcmp(name, "gemm_bf16x6") == 0) {
-        g_opt_gemm_bf16x6 = (int)value & 3;
+        ctx->opt.gemm_bf16x6 = (int)value & 3;
         return MDBN_OK;
     }
     if (strcmp(name, "planes_min_work") == 0) {
         if (value < 0) return fail(MDBN_EINVAL, "planes_min_work must be >= 0");
-        g_opt_planes_min_work = value;
+        ctx->opt.planes_min_work = value;
         return MDBN_OK;
     }
     if (strcmp(name, "bf16_inputs") == 0) {
-        g_opt_bf16_inputs = value != 0;
+        ctx->opt.bf16_inputs = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "planes_mfma") == 0) {
         if (value != 16 && value != 32) return fail(MDBN_EINVAL, "planes_mfma must be 16 or 32");
-        g_opt_planes_mfma = (int)value;
+        ctx->opt.planes_mfma = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "narrow_tiles") == 0) {
-        g_opt_narrow_tiles = value != 0;
+        ctx->opt.narrow_tiles = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "feed_copy_streams") == 0) {
         REQUIRE(value == 1 || value == 2, "feed_copy_streams must be 1 or 2");
-        g_opt_feed_copy_streams = value;
+        ctx->opt.feed_copy_streams = value;
         return MDBN_OK;
     }
     if (strcmp(name, "gather_ahead") == 0) {
-        g_opt_gather_ahead = value != 0;
+        ctx->opt.gather_ahead = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "early_w") == 0) {
-        g_opt_early_w = value != 0;
+        ctx->opt.early_w = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "bal_blocks") == 0) {
         if (value < 0 || value > kMaxBalBlocks) return fail(MDBN_EINVAL, "bal_blocks must be in [0, %d]", kMaxBalBlocks);
-        g_opt_bal_blocks = (int)value;
+        ctx->opt.bal_blocks = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "comm_cus") == 0) {
         if (value < 0 || value > 192) return fail(MDBN_EINVAL, "comm_cus must be in [0, 192]");
-        g_opt_comm_cus = (int)value;
+        ctx->opt.comm_cus = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "small_fin_lanes") == 0) {
         REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16, "small_fin_lanes must be 0, 1, 2, 4, 8 or 16");
-        g_small_fin_lanes = (int)value;
+        ctx->opt.small_fin_lanes = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "small_fused") == 0) {
-        g_opt_small_fused = value != 0;
+        ctx->opt.small_fused = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "gemm_planes") == 0) {
-        g_opt_gemm_planes = value != 0;
+        ctx->opt.gemm_planes = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "fused_finalize") == 0) {
-        g_opt_fused_finalize = value != 0;
+        ctx->opt.fused_finalize = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "fused_update") == 0) {
-        g_opt_fused_update = value != 0;
+        ctx->opt.fused_update = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "fused_epilogue") == 0) {
-        g_opt_fused_epilogue = value != 0;
+        ctx->opt.fused_epilogue = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "update_overlap") == 0) {
-        g_opt_update_overlap = value != 0;
+        ctx->opt.update_overlap = value != 0;
         return MDBN_OK;
     }
     return fail(MDBN_EINVAL, "unknown option %s", name);
@@ -1093,6 +1172,7 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
 
 int mdbn_kernel_timing(mdbn_ctx* ctx, int enable)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx != nullptr, "ctx is NULL");
     g_timing.enabled = enable != 0;
     g_timing.used = 0;
@@ -1101,6 +1181,7 @@ int mdbn_kernel_timing(mdbn_ctx* ctx, int enable)
 
 int mdbn_kernel_timing_read(mdbn_ctx* ctx, int64_t* n_launches, double* total_ms)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx && n_launches && total_ms, "NULL argument");
     double tot = 0.0;
     for (size_t i = 0; i < g_timing.used; ++i) {
@@ -1117,6 +1198,7 @@ int mdbn_kernel_timing_read(mdbn_ctx* ctx, int64_t* n_launches, double* total_ms
 int mdbn_kernel_timing_detail(mdbn_ctx* ctx, int64_t cap, double* ms, double* alg_flop, double* pipe_flop,
                               int32_t* kind, int64_t* n_launches)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx && n_launches && (cap == 0 || (ms && alg_flop && pipe_flop && kind)), "NULL argument");
     const int64_t n = std::min<int64_t>(cap, (int64_t)g_timing.used);
     for (int64_t i = 0; i < n; ++i) {
@@ -1137,6 +1219,13 @@ int mdbn_workspace_bytes(int64_t B, int64_t V, int64_t H, int64_t* bytes)
     REQUIRE(bytes != nullptr && B > 0 && V > 0 && H > 0, "bad arguments");
     *bytes = ws_sizes(B, V, H).total_bytes();
     return MDBN_OK;
+}
+
+int mdbn_workspace_bytes_ctx(mdbn_ctx* ctx, int64_t B, int64_t V, int64_t H, int64_t* bytes)
+{
+    CtxScope ctx_scope(ctx);
+    REQUIRE(ctx != nullptr, "ctx is NULL");
+    return mdbn_workspace_bytes(B, V, H, bytes);
 }
 
 int mdbn_padded_ld(int64_t cols, int64_t* ld)
@@ -1160,6 +1249,13 @@ int mdbn_planes_eligible(int64_t B, int64_t V, int64_t H, int64_t ldv, int64_t l
     return MDBN_OK;
 }
 
+int mdbn_planes_eligible_ctx(mdbn_ctx* ctx, int64_t B, int64_t V, int64_t H, int64_t ldv, int64_t ldh, int32_t* eligible)
+{
+    CtxScope ctx_scope(ctx);
+    REQUIRE(ctx != nullptr, "ctx is NULL");
+    return mdbn_planes_eligible(B, V, H, ldv, ldh, eligible);
+}
+
 int mdbn_planes_alt_bytes(int64_t B, int64_t ldv, int64_t* bytes)
 {
     REQUIRE(bytes != nullptr && B > 0 && ldv > 0, "bad arguments");
@@ -1169,6 +1265,7 @@ int mdbn_planes_alt_bytes(int64_t B, int64_t ldv, int64_t* bytes)
 
 int mdbn_split_planes(mdbn_ctx* ctx, void* stream, const float* x, int64_t rows, int64_t ld, void* planes)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx && x && planes && rows > 0 && ld > 0 && ld % 4 == 0, "bad arguments");
     REQUIRE(aligned16(x) && aligned16(planes), "x and planes must be 16-byte aligned");
     HIP_OK(launch_split_planes(x, rows, ld, reinterpret_cast<unsigned short*>(planes), rows * ld, (hipStream_t)stream));
@@ -1186,6 +1283,7 @@ int mdbn_gather_rows(mdbn_ctx* ctx, void* stream, const float* src, int64_t n_ro
                      int64_t ld_src, const void* indexes, int index_is_64, int64_t n_idx, float* dst,
                      int64_t ld_dst)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx != nullptr, "ctx is NULL");
     CHECK(check_mat(src, ld_src, cols, "src"));
     CHECK(check_mat(dst, ld_dst, cols, "dst"));
@@ -1200,6 +1298,7 @@ int mdbn_gather_rows_host(mdbn_ctx* ctx, void* stream, const float* src, int64_t
                           const void* indexes, int index_is_64, int64_t n_idx, float* dst, int64_t ld_dst, int workgroups,
                           int threads)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx != nullptr, "ctx is NULL");
     CHECK(check_mat(src, ld_src, cols, "src"));
     CHECK(check_mat(dst, ld_dst, cols, "dst"));
@@ -1217,6 +1316,7 @@ int mdbn_propup_sample(mdbn_ctx* ctx, void* stream, const float* v, int64_t B, i
                        float mean_scale, float* sample, const mdbn_rng* rng, void* workspace,
                        int64_t workspace_bytes)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx != nullptr, "ctx is NULL");
     REQUIRE(B > 0 && V > 0 && H > 0, "bad shape");
     CHECK(check_mat(v, ldv, V, "v"));
@@ -1237,6 +1337,7 @@ int mdbn_propdown_sample(mdbn_ctx* ctx, void* stream, const float* h, int64_t B,
                          float* pre, float* mean, float* sample, const mdbn_rng* rng, const float* v0,
                          float* cost_sum, void* workspace, int64_t workspace_bytes)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx != nullptr, "ctx is NULL");
     REQUIRE(B > 0 && V > 0 && H > 0, "bad shape");
     CHECK(check_mat(h, ldh, H, "h"));
@@ -1313,6 +1414,7 @@ int mdbn_comm_unique_id(char* id128)
 
 int mdbn_comm_init_rank(mdbn_ctx* ctx, const char* id128, int nranks, int rank)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx != nullptr && id128 != nullptr && nranks >= 1 && rank >= 0 && rank < nranks, "bad arguments");
     REQUIRE(ctx->comm == nullptr, "this context already has a communicator");
     CHECK(rccl_load());
@@ -1327,6 +1429,7 @@ int mdbn_comm_init_rank(mdbn_ctx* ctx, const char* id128, int nranks, int rank)
 
 int mdbn_allreduce_stats(mdbn_ctx* ctx, void* stream, float* stats, int64_t n)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx != nullptr && ctx->comm != nullptr, "no communicator: call mdbn_comm_init_rank first");
     REQUIRE(stats != nullptr && n > 0, "bad arguments");
     // in place, float32 (ncclFloat32 = 7), sum (ncclSum = 0): the packed [S | s_h | s_v | cost] buffer of one CD step
@@ -1336,6 +1439,7 @@ int mdbn_allreduce_stats(mdbn_ctx* ctx, void* stream, float* stats, int64_t n)
 
 int mdbn_comm_destroy(mdbn_ctx* ctx)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx != nullptr, "ctx is NULL");
     if (ctx->comm) {
         RCCL_OK(g_rccl.CommDestroy(ctx->comm));
@@ -1350,6 +1454,7 @@ int mdbn_gibbs_chain(mdbn_ctx* ctx, void* stream, float* v, int64_t B, int64_t l
                      float* pre_h, float* h_mean, float* h_sample, float* pre_v, float* v_mean, const mdbn_rng* rng,
                      void* workspace, int64_t workspace_bytes)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx != nullptr && rng != nullptr, "NULL argument");
     REQUIRE(B > 0 && V > 0 && H > 0 && n_steps >= 1, "bad shape / step count");
     CHECK(check_mat(v, ldv, V, "v"));
@@ -1390,6 +1495,7 @@ int mdbn_gibbs_chain(mdbn_ctx* ctx, void* stream, float* v, int64_t B, int64_t l
 int mdbn_cd_stats(mdbn_ctx* ctx, void* stream, const float* V2, const float* P2, int64_t B, int64_t V,
                   int64_t H, int64_t ldv, int64_t ldh, float* stats, void* workspace, int64_t workspace_bytes)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx != nullptr, "ctx is NULL");
     REQUIRE(B > 0 && V > 0 && H > 0, "bad shape");
     CHECK(check_mat(V2, ldv, V, "V2"));
@@ -1434,6 +1540,7 @@ static int check_update_args(const mdbn_update_args* a);
 
 int mdbn_apply_update(mdbn_ctx* ctx, void* stream, const mdbn_update_args* a)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx != nullptr && a != nullptr, "NULL argument");
     CHECK(check_update_args(a));
     // phases that write W also rewrite its bf16 planes when the caller keeps some
@@ -1535,6 +1642,90 @@ static int cd_step_small(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, co
     return MDBN_OK;
 }
 
+// ---------------------------------------------------------------------------------- thin-batch step (B <= 32, mdbn_thin.hip)
+static bool thin_eligible(const mdbn_ctx* ctx, const mdbn_cd_args* a, const Workspace& ws, ThinGeom& tg)
+{
+    if (!g_opt_thin_fused || g_opt_bf16_inputs) return false;
+    if (a->persistent || a->sample_stats || (a->gauss && a->add_noise)) return false;
+    if (!a->gauss && a->vs == nullptr) return false;
+    if (!thin_geom(a->B, a->V, a->H, a->ldv, a->ldh, std::min(ctx->num_cu, kTargetJobs), tg)) return false;      // (the workspace is sized for <= 256 CUs)
+    return (int64_t)tg.G * tg.Bq * a->ldh <= ws.slab_floats && tg.G <= ws.cost_floats;
+}
+
+// mode 0: the whole step; 1: gather + positive phase + chain (mdbn_cd_forward); 2: statistics (+ update) (mdbn_cd_statistics).
+// upd: single-device step, the update kernel consumes each row of S as it forms it; else it stores [S | s_h | s_v | cost].
+static int cd_step_thin(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const mdbn_update_args* upd, const Workspace& ws,
+                        const ThinGeom& tg, int mode, const mdbn_update_args* defer)
+{
+    const int64_t B = a->B, V = a->V, H = a->H, ldv = a->ldv, ldh = a->ldh;
+    float* v0 = a->V2;
+    float* nv = a->V2 + B * ldv;
+    float* ph = a->P2;
+    float* nh = a->P2 + B * ldh;
+    int n_cost = tg.G;
+    if (mode != 2) {
+        ThinPassArgs p{};
+        p.B = (int)B; p.Bq = tg.Bq; p.V = (int)V; p.H = (int)H; p.ldv = ldv; p.ldh = ldh;
+        p.G = tg.G; p.rpw = tg.rpw; p.PW = tg.PW;
+        p.W = a->W; p.part = ws.slabs;
+        p.data = a->data; p.n_data = a->n_data; p.ld_data = ldv; p.idx = a->indexes; p.idx64 = a->index_is_64; p.v0_out = v0;
+        p.vbias = a->vbias; p.gauss = a->gauss;
+        // x = train_set_x[indexes] and the partials of x W                      (dbn.py:307, rbm.py:303)
+        HIP_OK(launch_thin_pass(0, p, tg, s));
+        ThinActArgs act{};
+        act.part = ws.slabs; act.G = tg.G; act.Bq = tg.Bq;
+        act.e.rows = (int)B; act.e.cols = (int)H; act.e.ld = ldh; act.e.bias = a->hbias;
+        act.e.mean = ph; act.e.mean_scale = 1.0f; act.e.sample = a->hs; act.e.rng = make_key(a->rng, 0u);
+        HIP_OK(launch_thin_act(act, s));
+        if (a->trace_h) HIP_OK(hipMemcpyAsync(a->trace_h, a->hs, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
+        for (int t = 1; t <= a->k; ++t) {                                  // gibbs_hvh x k (rbm.py:318-336)
+            const bool last = t == a->k;
+            p.chain = a->hs; p.nv = nv; p.vs = a->gauss ? nullptr : a->vs; p.last = last ? 1 : 0;
+            p.target = last ? v0 : nullptr; p.ld_target = ldv; p.cost_partials = last ? ws.cost_partials : nullptr;
+            p.rng = make_key(a->rng, (uint32_t)(2 * t - 1));
+            HIP_OK(launch_thin_pass(1, p, tg, s));
+            if (a->trace_v && !a->gauss)
+                HIP_OK(hipMemcpyAsync(a->trace_v + (int64_t)(t - 1) * B * ldv, a->vs, sizeof(float) * B * ldv, hipMemcpyDeviceToDevice, s));
+            act.e.mean = nh; act.e.mean_scale = -1.0f; act.e.sample = last ? nullptr : a->hs;
+            act.e.rng = make_key(a->rng, (uint32_t)(2 * t));
+            HIP_OK(launch_thin_act(act, s));
+            if (a->trace_h && !last)
+                HIP_OK(hipMemcpyAsync(a->trace_h + (int64_t)t * B * ldh, a->hs, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    if (mode == 1) {
+        ctx->pending_n_cost = n_cost; ctx->pending_stats = a->stats;
+        return MDBN_OK;
+    }
+    if (mode == 2) n_cost = ctx->pending_n_cost;
+    ctx->pending_n_cost = -1; ctx->pending_stats = nullptr;
+    // the previous step's deferred update (data-parallel order) is its own launch here, ahead of the statistics
+    if (defer) HIP_OK(launch_update(*defer, s, nullptr, 1, 0, reinterpret_cast<unsigned short*>(defer->W_planes)));
+    ThinUpdArgs u{};
+    u.B = (int)B; u.Bq = tg.Bq; u.V = (int)V; u.H = (int)H; u.ldv = ldv; u.ldh = ldh; u.G = tg.Gu; u.rpw = tg.rpu;
+    u.V2 = a->V2; u.P2 = a->P2;
+    u.S = a->stats; u.s_h = a->stats + V * ldh; u.s_v = u.s_h + ldh; u.cost = u.s_v + ldv;
+    u.cost_partials = ws.cost_partials; u.n_cost = n_cost;
+    const bool fuse_upd = upd && g_opt_fused_update;
+    u.do_upd = fuse_upd ? 1 : 0;
+    if (fuse_upd) {
+        u.upd.W = upd->W; u.upd.Ws = upd->W_speed; u.upd.W0 = upd->W0; u.upd.ld = ldh; u.upd.rows = (int)V;
+        u.upd.lr = upd->lr; u.upd.l1 = upd->lambda_1; u.upd.l2 = upd->lambda_2; u.upd.wc = upd->weightcost;
+        u.upd.mu = upd->momentum; u.upd.inv_bs = 1.0f / upd->batch_size;
+        u.upd.Wp = reinterpret_cast<unsigned short*>(upd->W_planes); u.upd.wp_stride = V * ldh;
+        u.bu.hb = upd->hbias; u.bu.hbs = upd->hbias_speed; u.bu.vb = upd->vbias; u.bu.vbs = upd->vbias_speed;
+        u.bu.H = H; u.bu.V = V; u.bu.lr = upd->lr; u.bu.mu = upd->momentum; u.bu.inv_rows = 1.0f / upd->n_rows;
+        u.bu.cost_scale = upd->cost_scale; u.bu.cost_out = upd->cost_out;
+    }
+    HIP_OK(launch_thin_update(u, tg, s));
+    if (upd && !fuse_upd) {
+        mdbn_update_args uu = *upd;
+        uu.phase = 0;
+        HIP_OK(launch_update(uu, s, nullptr, 1, 0, reinterpret_cast<unsigned short*>(uu.W_planes)));
+    }
+    return MDBN_OK;
+}
+
 static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, const mdbn_update_args* upd, int mode = 0,
                         const mdbn_update_args* defer = nullptr)
 {
@@ -1581,6 +1772,10 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
                 "deferred update does not match the step's parameters");
     }
     if (small_eligible(a, ws) && !(upd && g_opt_update_overlap)) return cd_step_small(ctx, s, a, upd, ws, mode, defer);
+    {
+        ThinGeom tg;
+        if (thin_eligible(ctx, a, ws, tg) && !(upd && g_opt_update_overlap)) return cd_step_thin(ctx, s, a, upd, ws, tg, mode, defer);
+    }
     if (planes_eligible(a) && !(upd && g_opt_update_overlap)) {
         const int rc = cd_step_planes(ctx, s, a, upd, ws, mode, defer);
         if (mode != 1) { ctx->pending_n_cost = -1; ctx->pending_stats = nullptr; }
@@ -1747,16 +1942,19 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
 
 int mdbn_cd_step(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a)
 {
+    CtxScope ctx_scope(ctx);
     return cd_step_impl(ctx, stream, a, nullptr);
 }
 
 int mdbn_cd_forward(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a)
 {
+    CtxScope ctx_scope(ctx);
     return cd_step_impl(ctx, stream, a, nullptr, 1, nullptr);
 }
 
 int mdbn_cd_statistics(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, const mdbn_update_args* deferred)
 {
+    CtxScope ctx_scope(ctx);
     if (deferred) {
         CHECK(check_update_args(deferred));
         REQUIRE(deferred->phase == 3 || deferred->phase == 0, "a deferred update is phase 3 (or the whole rule, phase 0)");
@@ -1766,6 +1964,7 @@ int mdbn_cd_statistics(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, const
 
 int mdbn_cd_train_step(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, const mdbn_update_args* upd)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(upd != nullptr, "update arguments are NULL");
     CHECK(check_update_args(upd));
     return cd_step_impl(ctx, stream, a, upd);
@@ -1775,6 +1974,7 @@ int mdbn_free_energy(mdbn_ctx* ctx, void* stream, const float* x, int64_t N, int
                      int64_t V, int64_t H, int64_t ldh, const float* hbias, const float* vbias, int gauss,
                      float* out, void* workspace, int64_t workspace_bytes)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx != nullptr, "ctx is NULL");
     REQUIRE(N > 0 && V > 0 && H > 0, "bad shape");
     CHECK(check_mat(x, ldv, V, "x"));
@@ -1809,6 +2009,7 @@ int mdbn_free_energy(mdbn_ctx* ctx, void* stream, const float* x, int64_t N, int
 int mdbn_round_flip(mdbn_ctx* ctx, void* stream, const float* x, int64_t rows, int64_t cols, int64_t ld, int64_t flip_col,
                     float* out)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx && x && out && rows >= 0 && cols > 0 && ld >= cols && flip_col < cols, "bad arguments");
     HIP_OK(launch_round_flip(x, out, rows, cols, ld, flip_col, (hipStream_t)stream));
     return MDBN_OK;
@@ -1817,6 +2018,7 @@ int mdbn_round_flip(mdbn_ctx* ctx, void* stream, const float* x, int64_t rows, i
 int mdbn_pl_cost(mdbn_ctx* ctx, void* stream, const float* fe, const float* fe_flip, int64_t rows, int64_t n_visible,
                  float* cost_out)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx && fe && fe_flip && cost_out && rows > 0 && n_visible > 0, "bad arguments");
     HIP_OK(launch_pl_cost(fe, fe_flip, rows, (float)n_visible, cost_out, (hipStream_t)stream));
     return MDBN_OK;
@@ -1825,6 +2027,7 @@ int mdbn_pl_cost(mdbn_ctx* ctx, void* stream, const float* fe, const float* fe_f
 int mdbn_recon_cost(mdbn_ctx* ctx, void* stream, const float* pre, int64_t ld_pre, const float* target, int64_t ld_target,
                     int64_t rows, int64_t cols, int gauss, float* cost_out, void* workspace, int64_t workspace_bytes)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx && pre && target && cost_out && rows > 0 && cols > 0 && ld_pre >= cols && ld_target >= cols, "bad arguments");
     REQUIRE(workspace != nullptr && workspace_bytes >= 4096, "workspace of >= 4096 bytes needed");
     const int nb = (int)std::min<int64_t>(std::min<int64_t>(1024, workspace_bytes / 4), (rows * cols + 255) / 256);
@@ -1837,6 +2040,7 @@ int mdbn_recon_cost(mdbn_ctx* ctx, void* stream, const float* pre, int64_t ld_pr
 
 int mdbn_tanh(mdbn_ctx* ctx, void* stream, float* x, int64_t rows, int64_t cols, int64_t ld)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx && x && rows >= 0 && cols > 0 && ld >= cols, "bad arguments");
     HIP_OK(launch_tanh(x, rows, cols, ld, (hipStream_t)stream));
     return MDBN_OK;
@@ -1844,6 +2048,7 @@ int mdbn_tanh(mdbn_ctx* ctx, void* stream, float* x, int64_t rows, int64_t cols,
 
 int mdbn_count_nonfinite(mdbn_ctx* ctx, void* stream, const float* x, int64_t n, int32_t* count)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx && x && count && n >= 0, "bad arguments");
     HIP_OK(launch_count_nonfinite(x, n, count, (hipStream_t)stream));
     return MDBN_OK;
@@ -1852,6 +2057,7 @@ int mdbn_count_nonfinite(mdbn_ctx* ctx, void* stream, const float* x, int64_t n,
 int mdbn_rng_uniform(mdbn_ctx* ctx, void* stream, float* out, int64_t rows, int64_t cols, int64_t ld,
                      const mdbn_rng* rng)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx && out && rng && rows >= 0 && cols >= 0 && ld >= cols, "bad arguments");
     HIP_OK(launch_rng_fill(out, rows, cols, ld, make_key(*rng, rng->draw), 0, (hipStream_t)stream));
     return MDBN_OK;
@@ -1860,6 +2066,7 @@ int mdbn_rng_uniform(mdbn_ctx* ctx, void* stream, float* out, int64_t rows, int6
 int mdbn_rng_normal(mdbn_ctx* ctx, void* stream, float* out, int64_t rows, int64_t cols, int64_t ld,
                     const mdbn_rng* rng)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx && out && rng && rows >= 0 && cols >= 0 && ld >= cols, "bad arguments");
     HIP_OK(launch_rng_fill(out, rows, cols, ld, make_key(*rng, rng->draw), 1, (hipStream_t)stream));
     return MDBN_OK;
@@ -2013,6 +2220,7 @@ int mdbn_host_gather_rows(const float* table, int64_t n_rows, int64_t cols, int6
 int mdbn_feeder_create(mdbn_ctx* ctx, const float* table, int64_t n_rows, int64_t cols, int64_t ld, int64_t max_rows,
                        int slots, float* const* device_slots, int64_t ld_device, int threads, mdbn_feeder** out)
 {
+    CtxScope ctx_scope(ctx);
     REQUIRE(ctx != nullptr && out != nullptr, "ctx / out is NULL");
     REQUIRE(table && n_rows > 0 && cols > 0 && ld >= cols && max_rows > 0, "bad table");
     REQUIRE(slots >= 2 && slots <= 16 && device_slots != nullptr, "slots must be in [2, 16]");

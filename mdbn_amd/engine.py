@@ -249,7 +249,7 @@ class HipEngine(object):
         need = self._ws_need.get((B, V, H))
         if need is None:
             n = C.c_int64()
-            _lib.check(self.lib.mdbn_workspace_bytes(B, V, H, C.byref(n)), "mdbn_workspace_bytes")
+            _lib.check(self.lib.mdbn_workspace_bytes_ctx(self.ctx, B, V, H, C.byref(n)), "mdbn_workspace_bytes_ctx")
             need = self._ws_need[(B, V, H)] = max(n.value, 8 << 20)
         if self._workspace is None or self._workspace.numel() * 4 < need + 256:
             self._workspace = torch.empty(need // 4 + 64, dtype=torch.float32, device=self.device)
@@ -310,20 +310,20 @@ class HipEngine(object):
     weight_ld_min_elems = int(_os.environ.get("MDBN_WEIGHT_LD_MIN", 1 << 21))      # smallest V * padded H that is padded
 
     def plane_shape(self, B, V, H, ldv, ldh):
-        """Shapes the plane path of the library takes under its CURRENT options: asked of the library itself
-        (mdbn_planes_eligible), so the host's buffers and the library's choice of path cannot disagree."""
+        """Shapes the plane path of the library takes under THIS engine's options: asked of the library itself
+        (mdbn_planes_eligible_ctx), so the host's buffers and the library's choice of path cannot disagree."""
         ok = C.c_int32()
-        _lib.check(self.lib.mdbn_planes_eligible(B, V, H, ldv, ldh, C.byref(ok)), "mdbn_planes_eligible")
+        _lib.check(self.lib.mdbn_planes_eligible_ctx(self.ctx, B, V, H, ldv, ldh, C.byref(ok)), "mdbn_planes_eligible_ctx")
         return bool(ok.value)
 
     def set_planes_min_work(self, work):
-        """Smallest B * V * H the plane path serves (0: every whole-tile shape).  Library options are process-wide:
-        this changes the rule for every engine of the process."""
+        """Smallest B * V * H the plane path serves (0: every whole-tile shape).  Library options belong to the context:
+        this changes the rule for this engine only."""
         self.planes_min_work = int(work)
         self.set_option("planes_min_work", int(work))
 
     def set_option(self, name, value):
-        """Library tuning knob (mdbn_set_option), e.g. ``set_option('gemm_bk', 32)``; process-wide."""
+        """Library tuning knob (mdbn_set_option), e.g. ``set_option('gemm_bk', 32)``; of this engine's context only."""
         _lib.check(self.lib.mdbn_set_option(self.ctx, name.encode(), int(value)), "mdbn_set_option")
         self._options_epoch += 1         # (cached argument structs of step functions: stale)
         self._scratch.clear()            # options decide which scratch a shape needs (planes, slabs)
