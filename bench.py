@@ -171,36 +171,6 @@ def rccl_summary(path):
     return out
 
 
-def capi_collective_alive(group, eng, td, deadline_s=20.0):
-    """One small all-reduce through the library's own RCCL communicator (mdbn_comm_init_rank / mdbn_allreduce_stats), on
-    its side stream, polled against a deadline -- so that a communicator that cannot be built or never completes keeps
-    the C-ABI collective out of the sweep instead of hanging the benchmark.  All ranks take the same decision."""
-    import torch
-    ok = 1
-    try:
-        group.native = True
-        buf = torch.ones(1024, dtype=torch.float32, device=eng.device)
-        work = group.all_reduce_sum_async(buf, eng)
-        ev = getattr(work, "event", None)
-        t0 = time.perf_counter()
-        while ev is not None and not ev.query():
-            if time.perf_counter() - t0 > deadline_s:
-                ok = 0
-                break
-            time.sleep(0.01)
-        if ok:
-            work.wait()
-            torch.cuda.synchronize(eng.device)
-            ok = int(abs(float(buf[0]) - group.world_size) < 0.5)
-    except Exception:
-        ok = 0
-    finally:
-        group.native = False
-    flag = torch.tensor([ok], dtype=torch.int32, device=eng.device)
-    td.all_reduce(flag, op=td.ReduceOp.MIN)              # through torch's own communicator
-    return bool(int(flag.item()))
-
-
 def capped_process_group(td, eng, max_ctas, world, deadline_s=60.0):
     """A second RCCL communicator over all ranks whose kernels use at most `max_ctas` workgroups (ncclConfig_t.maxCTAs
     through torch's ProcessGroupNCCL.Options): one channel = one workgroup = one CU taken from the step, so this is the other
@@ -348,8 +318,12 @@ def kernel_breakdown(detail):
 class Watchdog(object):
     """N > 1: the first contact with real hardware must not lose its number.  Once the DEFAULT setting has been timed, its
     complete JSON line is parked here; if anything after that (a sweep point, a second communicator, a collective of the
-    reporting tail) has not finished by the deadline, rank 0 prints the parked line and every rank leaves with exit code 0.
+    reporting tail) has not finished by the deadline, rank 0 prints the parked line -- marked `provisional`, with the phase
+    that stalled in `watchdog_phase` -- and every rank leaves with exit code WATCHDOG_RC (3): a stall is never reported as a
+    clean run (launch_ranks relays the code; under the driver's own torchrun every rank fails with it).
     Exactly ONE line is ever printed: `finish` and the watchdog exclude each other."""
+
+    WATCHDOG_RC = 3
 
     def __init__(self, rank):
         import threading
@@ -385,11 +359,15 @@ class Watchdog(object):
                 self.done = True
                 if self.rank == 0 and self.line is not None:
                     self.line["provisional"] = True
+                    self.line["watchdog_phase"] = self.why
                     self.line["provisional_reason"] = "watchdog: '%s' did not finish in time; this is the DEFAULT setting, " \
-                                                      "timed before any sweep" % self.why
+                                                      "timed before any sweep; the process exits with code %d" % (self.why, self.WATCHDOG_RC)
                     print(json.dumps(self.line))
                     sys.stdout.flush()
-            os._exit(0)
+                sys.stderr.write("bench.py watchdog (rank %d): phase '%s' stalled; exiting with code %d\n"
+                                 % (self.rank, self.why, self.WATCHDOG_RC))
+                sys.stderr.flush()
+            os._exit(self.WATCHDOG_RC)
 
 
 def main():
@@ -497,7 +475,8 @@ def main():
 
     def setting_of(fn):
         return {"overlap": bool(getattr(fn, "overlap", False)), "comm_cus": int(getattr(fn, "comm_cus", 0)),
-                "collective": "capi" if (getattr(fn, "group", None) is not None and fn.group.native) else "torch",
+                "collective": "capi" if (getattr(fn, "group", None) is not None and fn.group._comm_engine is not None
+                                         and fn.group.native is not False) else "torch",
                 "update_inside_statistics_gemm": int(getattr(fn, "fuse_deferred", 0)), "rccl_max_ctas": None}
 
     def line_for(wins, cost, detail, n_timed_steps, dist_block, extras=None):
@@ -582,6 +561,9 @@ def main():
         dist_block.update(setting_of(step_fn))
         dist_block["update_inside_statistics_gemm"] = int(getattr(step_fn, "fuse_deferred", 0)) >= (2 if getattr(step_fn, "comm_cus", 0) else 1)
         dist_block["collective"] = step_fn.group.collective if getattr(step_fn, "group", None) is not None else None
+        # MDBN_DP_COLLECTIVE=auto (default): the C-ABI RCCL collective once it has proven alive on every rank, else torch's
+        dist_block["collective_mode"] = os.environ.get("MDBN_DP_COLLECTIVE", "auto")
+        dist_block["capi_collective_fallback_reason"] = getattr(step_fn.group, "native_error", None) if getattr(step_fn, "group", None) is not None else None
         dist_block["default_setting_ms_per_step"] = 1e3 * float(np.median(wins)) / args.steps
         dog = Watchdog(rank)
         dog.park(line_for(wins, cost, detail, n_timed_steps, dict(dist_block, note="default setting; nothing after it finished")))
@@ -651,12 +633,15 @@ def main():
         # setting itself was timed above and is the first record
         sweep.append(dict(default, ms_per_step=dist_block["default_setting_ms_per_step"], windows=len(wins), error=None,
                           note="the default setting (timed first, full windows)"))
-        natives = (False, True) if (args.sweep_capi or os.environ.get("MDBN_BENCH_SWEEP_CAPI") == "1") else (False,)
-        settings = [dict(overlap=ov, comm_cus=cus if ov else 0, collective="capi" if nat else "torch",
-                         update_inside_statistics_gemm=fu, rccl_max_ctas=None)
-                    for nat in natives
-                    for ov, cus, fu in ((True, 0, 1), (True, 0, 0), (True, 8, 0), (True, 16, 0), (True, 32, 0), (True, 32, 2),
-                                        (True, 64, 0), (False, 0, 0))]
+        # every point on the DEFAULT collective; the other collective at the main point (comm_cus 0, update inside the
+        # statistics GEMM), so that the line always reports both; --sweep-capi: every point on both
+        other = "torch" if default["collective"] == "capi" else "capi"
+        shapes = ((True, 0, 1), (True, 0, 0), (True, 8, 0), (True, 16, 0), (True, 32, 0), (True, 32, 2), (True, 64, 0), (False, 0, 0))
+        settings = [dict(overlap=ov, comm_cus=cus if ov else 0, collective=default["collective"],
+                         update_inside_statistics_gemm=fu, rccl_max_ctas=None) for ov, cus, fu in shapes]
+        both = args.sweep_capi or os.environ.get("MDBN_BENCH_SWEEP_CAPI") == "1"
+        settings[1:1] = [dict(overlap=ov, comm_cus=cus if ov else 0, collective=other, update_inside_statistics_gemm=fu,
+                              rccl_max_ctas=None) for ov, cus, fu in (shapes if both else shapes[:1])]
         settings = [st for st in settings if st != default]
         capi_ok = None
         for st in settings:
@@ -667,10 +652,9 @@ def main():
                 if backend_name != "nccl":
                     continue                                  # the C-ABI communicator is RCCL: needs one GPU per rank
                 if capi_ok is None:
-                    capi_ok = capi_collective_alive(step_fn.group, eng, td)
+                    capi_ok = step_fn.group.probe_native(eng, deadline_s=30.0)     # (a no-op when the default already runs on it)
                     if not capi_ok:
-                        sweep.append({"collective": "capi", "error": "mdbn_allreduce_stats did not complete a small all-reduce "
-                                                                       "within 20 s on every rank: C-ABI collective not swept"})
+                        sweep.append({"collective": "capi", "error": "C-ABI collective not swept: %s" % step_fn.group.native_error})
                 if not capi_ok:
                     continue
             rec, nxt0 = point(st, default_pg, nxt0)
@@ -759,6 +743,37 @@ def main():
             dist_block["exposed_comm_error"] = repr(exc)[:200]
         finally:
             step_fn.group.stub_collective = False
+        # ONE place for what the one-GPU proxy predicted and what this run measured (the step alone 146 us,
+        # beside a CU-holding stand-in 197-213 us => 5.2-6.1x at 8 GPUs; the >= 6x of the north star is NOT a measured claim
+        # until this table comes from an 8-GPU node)
+        step_ms_now = 1e3 * float(np.median(wins)) / args.steps
+        single_gpu_ms = None
+        try:
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))
+            for path in reversed(cands):
+                with open(path) as fh:
+                    rec = json.loads(fh.read().strip().splitlines()[-1])
+                if rec.get("n_gpus") == 1 and rec.get("ms_per_step"):
+                    single_gpu_ms = float(rec["ms_per_step"])
+                    break
+        except Exception:
+            single_gpu_ms = None
+        dist_block["predicted_vs_measured"] = {
+            "ranks": world,
+            "single_gpu_ms_per_step (newest profiles/r*_bench.json)": single_gpu_ms,
+            "predicted_ms_per_step_one_gpu_proxy": [0.197, 0.213],
+            "predicted_weak_scaling_at_8": [5.2, 6.1],
+            "measured_ms_per_step": step_ms_now,
+            "measured_weak_scaling": (world * single_gpu_ms / step_ms_now) if single_gpu_ms else None,
+            "step_without_collective_ms": dist_block.get("step_without_collective_ms"),
+            "exposed_comm_us": dist_block.get("exposed_comm_us"),
+            "cover_us": dist_block.get("cover_us"),
+            "allreduce_alone_us": dist_block.get("allreduce_alone_us"),
+            "comm_cus": dist_block.get("comm_cus"),
+            "collective": dist_block.get("collective"),
+            "note": "comm_cus and the collective of `value` are the fastest point of `sweep` (installed and re-timed like the "
+                    "default); weak scaling = ranks x single-GPU step time / this step time",
+        }
 
     # the same steps with the GEMMs forced onto the exact-f32 MFMA (v_mfma_f32_32x32x2_f32): by default
     # they run on the bf16 matrix pipe with three-way split operands and f32 accumulation (f32 accuracy,

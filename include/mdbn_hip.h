@@ -398,6 +398,12 @@ int  mdbn_tanh(mdbn_ctx *ctx, void *stream, float *x, int64_t rows, int64_t cols
  * src/dbn.py:311); the caller zeroes count */
 int  mdbn_count_nonfinite(mdbn_ctx *ctx, void *stream, const float *x, int64_t n, int32_t *count);
 
+/* bfloat16 wire format of the data-parallel statistics (opt-in reporting mode MDBN_WIRE_BF16=1, never a
+ * parity path): dst[i] = bfloat16(src[i]) with round-to-nearest-even, and the exact widening back.  n elements; both
+ * buffers 16-byte aligned. */
+int  mdbn_f32_to_bf16(mdbn_ctx *ctx, void *stream, const float *src, void *dst, int64_t n);
+int  mdbn_bf16_to_f32(mdbn_ctx *ctx, void *stream, const void *src, float *dst, int64_t n);
+
 /* the random matrices themselves (tests, and sampling utilities) */
 int  mdbn_rng_uniform(mdbn_ctx *ctx, void *stream, float *out, int64_t rows, int64_t cols,
                       int64_t ld, const mdbn_rng *rng);

@@ -112,6 +112,8 @@ SIGNATURES = {
     "mdbn_recon_cost": [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _i64],
     "mdbn_tanh": [_vp, _vp, _vp, _i64, _i64, _i64],
     "mdbn_count_nonfinite": [_vp, _vp, _vp, _i64, _vp],
+    "mdbn_f32_to_bf16": [_vp, _vp, _vp, _vp, _i64],
+    "mdbn_bf16_to_f32": [_vp, _vp, _vp, _vp, _i64],
     "mdbn_rng_uniform": [_vp, _vp, _vp, _i64, _i64, _i64, _rngp],
     "mdbn_rng_normal": [_vp, _vp, _vp, _i64, _i64, _i64, _rngp],
     "mdbn_philox_host": [_vp, _i64, _i64, _i64, _rngp],

@@ -1606,7 +1606,7 @@ static int cd_step_small(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, co
         ctx->pending_n_cost = nb * SM_NW; ctx->pending_stats = a->stats;
         return MDBN_OK;
     }
-    if (mode == 2) { ctx->pending_n_cost = -1; ctx->pending_stats = nullptr; }
+    if (mode != 1) { ctx->pending_n_cost = -1; ctx->pending_stats = nullptr; }      // (any step that is not a forward half ends a pending hand-over: the workspace partials are gone)
     // the previous step's deferred update (data-parallel order) is its own launch here, ahead of the finish launch
     if (defer) HIP_OK(launch_update(*defer, s, nullptr, 1, 0, reinterpret_cast<unsigned short*>(defer->W_planes)));
     float* s_h = a->stats + V * ldh;
@@ -1766,6 +1766,9 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
     }
     if (mode == 2)
         REQUIRE(ctx->pending_stats == a->stats && ctx->pending_n_cost >= 0, "mdbn_cd_statistics must follow mdbn_cd_forward of the same step");
+    // a whole step between a forward half and its statistics half overwrites the partials that half left in the workspace
+    // (shared by all shapes): it ends the hand-over, whichever path serves it
+    if (mode == 0) { ctx->pending_n_cost = -1; ctx->pending_stats = nullptr; }
     if (defer) {
         REQUIRE(upd == nullptr && mode != 1, "a deferred update goes with the statistics half of a step without its own update");
         REQUIRE(defer->W == a->W && defer->ldh == ldh && defer->ldv == ldv && defer->V == V && defer->H == H,
@@ -2051,6 +2054,24 @@ int mdbn_count_nonfinite(mdbn_ctx* ctx, void* stream, const float* x, int64_t n,
     CtxScope ctx_scope(ctx);
     REQUIRE(ctx && x && count && n >= 0, "bad arguments");
     HIP_OK(launch_count_nonfinite(x, n, count, (hipStream_t)stream));
+    return MDBN_OK;
+}
+
+int mdbn_f32_to_bf16(mdbn_ctx* ctx, void* stream, const float* src, void* dst, int64_t n)
+{
+    CtxScope ctx_scope(ctx);
+    REQUIRE(ctx && src && dst && n >= 0, "bad arguments");
+    REQUIRE(aligned16(src) && aligned16(dst), "buffers must be 16-byte aligned");
+    HIP_OK(launch_narrow_bf16(src, reinterpret_cast<unsigned short*>(dst), n, (hipStream_t)stream));
+    return MDBN_OK;
+}
+
+int mdbn_bf16_to_f32(mdbn_ctx* ctx, void* stream, const void* src, float* dst, int64_t n)
+{
+    CtxScope ctx_scope(ctx);
+    REQUIRE(ctx && src && dst && n >= 0, "bad arguments");
+    REQUIRE(aligned16(src) && aligned16(dst), "buffers must be 16-byte aligned");
+    HIP_OK(launch_widen_bf16(reinterpret_cast<const unsigned short*>(src), dst, n, (hipStream_t)stream));
     return MDBN_OK;
 }
 

@@ -217,6 +217,8 @@ hipError_t launch_recon_cost(const float* pre, int64_t ldp, const float* tgt, in
                              float scale, float* partials, int n_partials, float* out, hipStream_t s);
 hipError_t launch_tanh(float* x, int64_t rows, int64_t cols, int64_t ld, hipStream_t s);
 hipError_t launch_count_nonfinite(const float* x, int64_t n, int* count, hipStream_t s);
+hipError_t launch_narrow_bf16(const float* x, unsigned short* y, int64_t n, hipStream_t s);
+hipError_t launch_widen_bf16(const unsigned short* y, float* x, int64_t n, hipStream_t s);
 hipError_t launch_rng_fill(float* out, int64_t rows, int64_t cols, int64_t ld, const PhiloxKey& k,
                            int normal, hipStream_t s);
 

@@ -1919,6 +1919,59 @@ hipError_t launch_tanh(float* x, int64_t rows, int64_t cols, int64_t ld, hipStre
     return hipGetLastError();
 }
 
+// bfloat16 wire format of the data-parallel statistics (opt-in reporting mode, mdbn_amd/dist.py): float32 -> bfloat16 with
+// round-to-nearest-even (a plain cast: v_cvt_pk_bf16_f32, NaN stays NaN) and back (exact).  16 bytes per thread and access.
+__global__ __launch_bounds__(256) void narrow_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t n)
+{
+    const int64_t i8 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i8 + 8 <= n) {
+        const float4 a = *reinterpret_cast<const float4*>(x + i8), b = *reinterpret_cast<const float4*>(x + i8 + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
+            w[e] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+        }
+        *reinterpret_cast<uint4*>(y + i8) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        for (int64_t i = i8; i < n; ++i) { const __bf16 t = (__bf16)x[i]; y[i] = __builtin_bit_cast(unsigned short, t); }
+    }
+}
+
+__global__ __launch_bounds__(256) void widen_bf16_kernel(const unsigned short* __restrict__ y, float* __restrict__ x, int64_t n)
+{
+    const int64_t i8 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i8 + 8 <= n) {
+        const uint4 w = *reinterpret_cast<const uint4*>(y + i8);
+        const unsigned u[4] = {w.x, w.y, w.z, w.w};
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = __builtin_bit_cast(float, u[e] << 16);
+            v[2 * e + 1] = __builtin_bit_cast(float, u[e] & 0xffff0000u);
+        }
+        *reinterpret_cast<float4*>(x + i8) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(x + i8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        for (int64_t i = i8; i < n; ++i) x[i] = __builtin_bit_cast(float, (unsigned)y[i] << 16);
+    }
+}
+
+hipError_t launch_narrow_bf16(const float* x, unsigned short* y, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(narrow_bf16_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s, x, y, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_widen_bf16(const unsigned short* y, float* x, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(widen_bf16_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s, y, x, n);
+    return hipGetLastError();
+}
+
 // count[0] += number of NaN / Inf entries of x[0..n)
 __global__ __launch_bounds__(256) void count_nonfinite_kernel(const float* __restrict__ x, int64_t n, int* __restrict__ count)
 {

@@ -462,15 +462,7 @@ __device__ __forceinline__ void pl_offsets16(int lane, int wm, int wn, int (&off
 // zero (smallest products first), and the stage's sum is added to the tile's accumulator with one v_add_f32 per element.
 // A tile's accumulator then takes ONE rounding at its own (large) magnitude per stage instead of six (three): the chained
 // roundings happen at the magnitude of a 32-term partial sum.  At K = 4096 the probabilities' worst error against float64
-// drops from 2.2e-6 to ~1e-6 (SURVEY 8d asks 2e-6); measured cost: see DESIGN.md "Stage-local accumulators".
-#ifndef PL_STAGE_ACC
-#define PL_STAGE_ACC 1
-#endif
-// PL_STAGE_ACC = 1 (default): the products of one 32-deep stage are chained into a STAGE-LOCAL accumulator that starts at
-// zero (smallest products first), and the stage's sum is added to the tile's accumulator with one v_add_f32 per element.
-// A tile's accumulator then takes ONE rounding at its own (large) magnitude per stage instead of six (three): the chained
-// roundings happen at the magnitude of a 32-term partial sum.  At K = 4096 the probabilities' worst error against float64
-// drops from 2.2e-6 to ~1e-6 (SURVEY 8d asks 2e-6); measured cost: see DESIGN.md "Stage-local accumulators".
+// drops from 2.2e-6 to ~1e-6 (SURVEY 8d asks 2e-6); measured cost: see docs/LABNOTES.md "Stage-local accumulators".
 #ifndef PL_STAGE_ACC
 #define PL_STAGE_ACC 1
 #endif

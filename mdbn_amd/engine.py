@@ -154,9 +154,14 @@ class HipEngine(object):
             raise _lib.MdbnError("no HIP device visible: mdbn_amd has no CPU fallback")
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        self.device = torch.device(device)
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _lib.MdbnError("HipEngine needs a HIP device, got %r" % (device,))
+        # 'cuda' without an index means the current device: fixed ONCE here (the raw-stream lookup and mdbn_ctx_create both
+        # take the index; an engine must not follow later torch.cuda.set_device calls)
+        self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
         ctx = C.c_void_p()
-        _lib.check(self.lib.mdbn_ctx_create(C.byref(ctx), self.device.index or 0), "mdbn_ctx_create")
+        _lib.check(self.lib.mdbn_ctx_create(C.byref(ctx), self.device.index), "mdbn_ctx_create")
         self.ctx = ctx
         self._workspace = None
         self._options_epoch = 0         # bumped by set_option: argument structs cached by step functions are then stale
@@ -638,8 +643,15 @@ class HipEngine(object):
         32 us per call, more than the GPU's time.  Only what changes from call to call is set: the index list, the Philox
         step, lr / momentum and the cost slot.  Returns None when the cache does not apply (the caller takes the full path)."""
         a, u, a_ref, u_ref, key, sc, keep = cache[:7]
-        if key != (data.data_ptr(), data.shape[0], idx.dtype, idx.numel(), self._workspace.data_ptr() if self._workspace is not None else 0,
-                   self.keep_f32, self.trace_chain, self._options_epoch):
+        W, W_speed, W0 = keep[2], keep[3], keep[4]
+        # the structs were captured for a W WITHOUT bf16 planes: if another consumer of the same W has created some since
+        # (another batch size of the same RBM, planes_min_work = 0), these steps must not go on updating W behind them
+        if getattr(W, "_mdbn_planes", None) is not None:
+            return None
+        if key != (data.data_ptr(), data.shape[0], data.stride(0), idx.dtype, idx.numel(),
+                   self._workspace.data_ptr() if self._workspace is not None else 0, self.keep_f32, self.trace_chain,
+                   self._options_epoch, a.rng.seed, a.rng.stream_id, torch._C._cuda_getCurrentRawStream(self.device.index),
+                   W.data_ptr(), W_speed.data_ptr(), W0.data_ptr() if W0 is not None else 0):
             return None
         a.indexes = idx.data_ptr()
         a.rng.step = rng_step & 0xFFFFFFFF
@@ -674,8 +686,10 @@ class HipEngine(object):
             idx = _keep[1]
             if idx is not None and sc.planes is None and not a.W_planes and not self.trace_chain and not sample_stats:
                 dm = _keep[0]
-                key = (dm.data_ptr(), dm.shape[0], idx.dtype, idx.numel(), self._workspace.data_ptr(), self.keep_f32, self.trace_chain,
-                       self._options_epoch)
+                key = (dm.data_ptr(), dm.shape[0], dm.stride(0), idx.dtype, idx.numel(), self._workspace.data_ptr(), self.keep_f32,
+                       self.trace_chain, self._options_epoch, a.rng.seed, a.rng.stream_id,
+                       torch._C._cuda_getCurrentRawStream(self.device.index), W.data_ptr(), W_speed.data_ptr(),
+                       W0.data_ptr() if W0 is not None else 0)
                 cache_out.extend([a, u, C.byref(a), C.byref(u), key, sc, (dm, stats, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed)])
         return cost
 
@@ -764,6 +778,35 @@ class HipEngine(object):
                    "mdbn_kernel_timing_detail")
         m = min(cap, n.value)
         return [(ms[i], alg[i], pipe[i], kind[i]) for i in range(m)]
+
+    # ------------------------------------------------------------------ bfloat16 wire format (data-parallel reporting mode)
+    def narrow_bf16(self, src, out=None):
+        """bfloat16 copy of a float32 buffer (round to nearest even; mdbn_f32_to_bf16): the wire form of the packed statistics
+        under MDBN_WIRE_BF16=1.  ``out``: a bfloat16 tensor of the same size to fill (kept by the caller across steps)."""
+        if out is None or out.numel() != src.numel():
+            out = torch.empty(src.numel(), dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.mdbn_f32_to_bf16(self.ctx, self._stream(), self._p(src), C.c_void_p(out.data_ptr()), src.numel()),
+                   "mdbn_f32_to_bf16")
+        return out
+
+    def widen_bf16(self, wire, dst):
+        """dst (float32) = wire (bfloat16), exactly (mdbn_bf16_to_f32)."""
+        _lib.check(self.lib.mdbn_bf16_to_f32(self.ctx, self._stream(), C.c_void_p(wire.data_ptr()), self._p(dst), dst.numel()),
+                   "mdbn_bf16_to_f32")
+        return dst
+
+    def cost_values(self, costs):
+        """Python floats of a list of 0-d step costs: ONE device-to-host copy per 1024-cost ring block (costs are views into
+        such blocks, `_next_cost_slot`; a block is never reused), no device arithmetic.  Synchronises."""
+        out, blocks = [0.0] * len(costs), {}
+        for i, c in enumerate(costs):
+            base = c._base if getattr(c, "_base", None) is not None else c
+            blocks.setdefault(id(base), (base, []))[1].append((i, c.storage_offset() - base.storage_offset()))
+        for base, items in blocks.values():
+            host = base.detach().reshape(-1).cpu().numpy()
+            for i, off in items:
+                out[i] = float(host[off])
+        return out
 
     def synchronize(self):
         torch.cuda.synchronize(self.device)

@@ -729,21 +729,18 @@ class RBM(object):
                 momentum = final_momentum
             _, minibatches = get_minibatches_idx(n_train_data, batch_size, shuffle=True, rng=shuffle_rng)
             dev_idx = self.engine.index_tensor(numpy.concatenate(minibatches))
-            # costs are 0-d device scalars: fold them into a running sum every 256 steps, without synchronising
-            costs, total = [], 0.0
+            # costs are 0-d device scalars (views into the engine's cost blocks): kept unread for the whole epoch -- no
+            # synchronisation inside it -- and read back with one copy per block at its end; the mean is formed on the host
+            # in float64, as the reference's numpy.mean over its per-minibatch floats (rbm.py:587-592)
+            costs = []
             views = list(torch.split(dev_idx, [len(b) for b in minibatches]))
             train_rbm.announce(views, host_indexes=minibatches)      # the epoch's order (a host-resident table starts feeding)
             for b_i in range(len(minibatches)):
                 # the next minibatch of the epoch as a hint (gathered inside this step's statistics kernel)
                 nxt = views[b_i + 1] if b_i + 1 < len(minibatches) else None
                 costs.append(train_rbm(views[b_i], momentum, next_indexes=nxt))
-                if len(costs) >= 256:
-                    total = total + torch.stack([c.reshape(()) for c in costs]).sum()
-                    costs = []
             train_rbm.flush()
-            if costs:
-                total = total + torch.stack([c.reshape(()) for c in costs]).sum()
-            mean_cost = float(total) / len(minibatches)
+            mean_cost = float(numpy.sum(numpy.asarray(self.engine.cost_values(costs), dtype=numpy.float64))) / len(minibatches)
             feg = None
             if n_val:
                 # rbm.py:597: gap between the first n_val training rows and the validation set

@@ -199,5 +199,15 @@ class OracleEngine(object):
         f = normal if normal_ else uniform
         return torch.from_numpy(f(rows, cols, rng.seed, rng.stream_id, rng.step, rng.draw, rng.row_offset))
 
+    def narrow_bf16(self, src, out=None):
+        return src.to(torch.bfloat16)
+
+    def widen_bf16(self, wire, dst):
+        dst.copy_(wire)
+        return dst
+
+    def cost_values(self, costs):
+        return [float(c) for c in costs]
+
     def synchronize(self):
         pass

@@ -299,3 +299,102 @@ def test_shard_bounds():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Which collective a group uses (VERDICT r4 #5a): the C-ABI RCCL collective by default ONCE IT HAS PROVEN
+# ALIVE on every rank, torch.distributed's otherwise; the bfloat16 wire flag must agree between the ranks.
+# ---------------------------------------------------------------------------------------------------------------------
+class _FakeLib(object):
+    """Stands in for libmdbn_hip.so's communicator entry points (no GPU here)."""
+
+    def __init__(self):
+        self.destroyed = 0
+
+    def mdbn_comm_unique_id(self, buf):
+        return 0
+
+    def mdbn_comm_destroy(self, ctx):
+        self.destroyed += 1
+        return 0
+
+
+class _FakeEngine(object):
+    def __init__(self):
+        self.ctx, self.lib, self.device = object(), _FakeLib(), torch.device("cpu")
+
+
+def _collective_worker(rank, world, port, outdir, case):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.pop("MDBN_DP_COLLECTIVE", None)
+    torch.set_num_threads(1)
+    from mdbn_amd import dist
+    dist.init_from_env(backend="gloo")
+    out = {}
+    if case == "fallback":
+        class G(dist.Group):                         # a group that believes the C-ABI collective is possible here ...
+            def _native_possible(self, engine):
+                return engine is not None
+
+            def _build_native(self, engine, ident):  # ... whose smoke all-reduce fails on rank 1 only
+                if self.rank == 1:
+                    raise RuntimeError("stubbed: the small all-reduce did not complete")
+                return "side-stream-of-rank-0"
+        g, eng = G(), _FakeEngine()
+        assert g.native is None                      # auto
+        x = torch.full((8,), float(rank + 1), dtype=torch.float64)
+        g.all_reduce_sum(x, eng)                     # probes once, agrees to fall back, reduces through torch.distributed
+        y = torch.full((8,), 1.0, dtype=torch.float64)
+        g.all_reduce_sum_async(y, eng).wait()
+        out = dict(sum=x.numpy(), sum2=y.numpy(), torch_collective=np.array("torch.distributed" in g.collective),
+                   has_error=np.array(g.native_error is not None), destroyed=np.array(eng.lib.destroyed),
+                   installed=np.array(g._comm_engine is not None), auto_off=np.array(g._auto_off))
+    elif case == "alive":
+        class G(dist.Group):
+            def _native_possible(self, engine):
+                return engine is not None
+
+            def _build_native(self, engine, ident):
+                return "side"
+        g, eng = G(), _FakeEngine()
+        ok = g.probe_native(eng)
+        out = dict(ok=np.array(ok), capi=np.array("C-ABI" in g.collective), err=np.array(g.native_error is None))
+    elif case == "wire_mismatch":
+        if rank == 0:
+            os.environ["MDBN_WIRE_BF16"] = "1"
+        else:
+            os.environ.pop("MDBN_WIRE_BF16", None)
+        try:
+            dist.Group()
+            out = dict(raised=np.array(False))
+        except RuntimeError as exc:
+            out = dict(raised=np.array("differs between the ranks" in str(exc)))
+    elif case == "wire_with_capi":
+        os.environ["MDBN_WIRE_BF16"] = "1"
+        try:
+            dist.Group(native=True)
+            out = dict(raised=np.array(False))
+        except RuntimeError as exc:
+            out = dict(raised=np.array("cannot be combined" in str(exc)))
+    np.savez(os.path.join(outdir, "coll_%s_%d.npz" % (case, rank)), **out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["fallback", "alive", "wire_mismatch", "wire_with_capi"])
+def test_collective_choice(case):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_collective_worker, args=(2, free_port(), d, case), nprocs=2, join=True)
+        r = [dict(np.load(os.path.join(d, "coll_%s_%d.npz" % (case, k)))) for k in range(2)]
+    if case == "fallback":
+        for k in range(2):
+            np.testing.assert_array_equal(r[k]["sum"], np.full(8, 3.0))          # 1 + 2 through the fallback collective
+            np.testing.assert_array_equal(r[k]["sum2"], np.full(8, 2.0))
+            assert r[k]["torch_collective"] and r[k]["has_error"] and r[k]["auto_off"] and not r[k]["installed"]
+        assert int(r[0]["destroyed"]) == 1 and int(r[1]["destroyed"]) == 0       # the rank that had come up tore its communicator down
+    elif case == "alive":
+        assert all(bool(x["ok"]) and bool(x["capi"]) and bool(x["err"]) for x in r)
+    else:
+        assert all(bool(x["raised"]) for x in r)
