@@ -44,3 +44,24 @@ def test_two_contexts_keep_their_own_options(built_lib):
         assert a.kernel_timing_detail() == []
     finally:
         a.kernel_timing(False)
+
+
+@pytest.mark.parametrize("shape", [(100, 24, 512), (784, 500, 20), (300, 130, 100)], ids=["one_launch", "thin", "streaming"])
+def test_a_whole_step_between_forward_and_statistics_ends_the_hand_over(hip_engine, shape):
+    """mdbn_cd_forward leaves partials in the workspace all shapes share; a whole step in between overwrites them, so the
+    statistics half must then be refused (MDBN_EINVAL) on every path instead of summing foreign partials."""
+    from mdbn_amd import RngAddr, _lib
+    eng = hip_engine
+    V, H, B = shape
+    rs = np.random.RandomState(1)
+    W = rs.uniform(-0.1, 0.1, size=(V, H)).astype(np.float32)
+    data = (rs.uniform(size=(B, V)) < 0.3).astype(np.float32)
+    dW, dhb, dvb, dx = [eng.to_device(a) for a in (W, np.zeros(H, np.float32), np.zeros(V, np.float32), data)]
+    token = eng.cd_forward(dx, None, dW, dhb, dvb, False, 1, RngAddr(1, 0, 0, 0, 0))
+    eng.cd_step(dx, None, dW, dhb, dvb, False, 1, RngAddr(1, 0, 1, 0, 0), stats_slot=1)        # a whole step in between
+    with pytest.raises(_lib.MdbnError, match="must follow mdbn_cd_forward"):
+        eng.cd_statistics(token)
+    # the regular order still works afterwards
+    token = eng.cd_forward(dx, None, dW, dhb, dvb, False, 1, RngAddr(1, 0, 2, 0, 0))
+    eng.cd_statistics(token)
+    eng.synchronize()
