@@ -32,7 +32,7 @@ def test_two_contexts_keep_their_own_options(built_lib):
     # knob 2: the plane path for a small whole-tile shape on `b` only (the default rule keeps it off planes)
     b.set_planes_min_work(0)
     ka, kb = _kinds(a, 1024, 512, 256, gauss=True), _kinds(b, 1024, 512, 256, gauss=True)
-    assert ka and all(k < 2000 for k in ka), ka                    # a: f32-operand kernels
+    assert ka and all(k < 2000 for k in ka), ka                    # a: f32-operand kernels (families 0 / 1)
     assert kb and all(k >= 2000 for k in kb), kb                   # b: bf16 plane kernels (family 2)
     # ... and the sizing calls answer per context
     assert b.plane_shape(256, 1024, 512, 1024, 512) and not a.plane_shape(256, 1024, 512, 1024, 512)
