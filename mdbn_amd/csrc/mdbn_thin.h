@@ -58,7 +58,10 @@ __host__ __device__ inline bool thin_geom(int64_t B, int64_t V, int64_t H, int64
     t.nt2 = (ldh + 31) / 32 <= 8 ? 1 : 2;
     t.lds_pass = thin_pass_lds(t.rpw, t.Bq, (int)ldh);
     t.lds_up = 3 * t.Bq * (((t.rpw + 15) & ~15) + 8) * 2;
-    int64_t rpu = (V + 2 * cus - 1) / (2 * cus);
+#ifndef TH_UPD_WGS
+#define TH_UPD_WGS 2        // update workgroups (256 threads) per CU: their phases overlap (A/B: profiles/r05i_thin_update_variants.log)
+#endif
+    int64_t rpu = (V + TH_UPD_WGS * cus - 1) / (TH_UPD_WGS * cus);
     if (rpu < 8) rpu = 8;
     while (rpu * 2 * t.Bq * 4 > 48 * 1024) rpu = (rpu + 1) / 2;
     t.rpu = (int)rpu;

@@ -220,19 +220,7 @@ __global__ __launch_bounds__(TH_NT) void thin_pass_kernel(ThinPassArgs a)
         }
         __syncthreads();
     } else {
-        // ---- MODE 0: x = train_set_x[indexes][:, r0 .. r1) -> v0 (float32 copy) and the three bf16 planes xP
-        for (int e = tid; e < Bq * R16; e += TH_NT) {
-            const int b = e / R16, i = e - b * R16;
-            float xv = 0.f;
-            if (b < a.B && i < nrows) {
-                xv = a.data[thin_src_row(a.idx, a.idx64, b, a.n_data) * a.ld_data + r0 + i];
-                a.v0_out[(int64_t)b * a.ldv + r0 + i] = xv;
-            }
-            unsigned short q1, q2, q3;
-            split3(xv, q1, q2, q3);
-            xP[b * PXb + i] = q1; xP[xp_plane + b * PXb + i] = q2; xP[2 * xp_plane + b * PXb + i] = q3;
-        }
-        __syncthreads();
+        // ---- MODE 0: (the gather of x and the first steps of W are requested together: below)
     }
 
     // ---- phase 2: partial[b][j] = sum_i x[b][i] W[r0 + i][j]; 32-column tiles wave, wave + 8; 16 rows of W per step
@@ -266,9 +254,11 @@ __global__ __launch_bounds__(TH_NT) void thin_pass_kernel(ThinPassArgs a)
                 }
             }
         } else {
-            // two steps of global loads in flight: one buffer is consumed while the other travels.  (Two NAMED buffers and a
-            // loop unrolled by two: indexing one array with the step's parity made hipcc wait for every single load.)
-            float fA[NT2][8], fB[NT2][8];
+            // THREE steps of global loads in flight in three NAMED buffers, the loop unrolled by three (indexing one array
+            // with the step's residue made hipcc wait for every single load).  Order of requests: the minibatch's row
+            // indices, the first three steps of W, then -- the indices are back by now -- the rows of x themselves: the
+            // gather's two dependent round trips pass beside W's first one instead of in front of it.
+            float fA[NT2][8], fB[NT2][8], fC[NT2][8];
             auto issue = [&](int s, float (&f)[NT2][8]) {
 #pragma unroll
                 for (int t = 0; t < NT2; ++t)
@@ -294,14 +284,62 @@ __global__ __launch_bounds__(TH_NT) void thin_pass_kernel(ThinPassArgs a)
                     }
                 }
             };
-            issue(0, fA);
-            for (int s = 0; s < nst2; s += 2) {
-                if (s + 1 < nst2) issue(s + 1, fB);
+            constexpr int GN = 4;               // items of the [Bq][R16] tile of x per thread and round: 32 * 256 / 512 / 4 rounds at most
+            const int items = Bq * R16;
+            for (int e0 = 0; e0 < items; e0 += TH_NT * GN) {
+                int64_t srow[GN];
+#pragma unroll
+                for (int u = 0; u < GN; ++u) {
+                    const int e = e0 + tid + TH_NT * u;
+                    const int b = min(e / R16, a.B - 1);
+                    srow[u] = thin_src_row(a.idx, a.idx64, b, a.n_data);
+                }
+                if (e0 == 0) { issue(0, fA); if (nst2 > 1) issue(1, fB); if (nst2 > 2) issue(2, fC); }
+                float xv[GN];
+#pragma unroll
+                for (int u = 0; u < GN; ++u) {
+                    const int e = e0 + tid + TH_NT * u;
+                    const int b = e / R16, i = e - b * R16;
+                    xv[u] = (e < items && b < a.B && i < nrows) ? a.data[srow[u] * a.ld_data + r0 + i] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < GN; ++u) {
+                    const int e = e0 + tid + TH_NT * u;
+                    const int b = e / R16, i = e - b * R16;
+                    if (e < items) {
+                        if (b < a.B && i < nrows) a.v0_out[(int64_t)b * a.ldv + r0 + i] = xv[u];
+                        unsigned short q1, q2, q3;
+                        split3(xv[u], q1, q2, q3);
+                        xP[b * PXb + i] = q1; xP[xp_plane + b * PXb + i] = q2; xP[2 * xp_plane + b * PXb + i] = q3;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int s = 0; s < nst2; s += 3) {
                 consume(s, fA);
-                if (s + 2 < nst2) issue(s + 2, fA);
+                if (s + 3 < nst2) issue(s + 3, fA);
                 if (s + 1 < nst2) consume(s + 1, fB);
+                if (s + 4 < nst2) issue(s + 4, fB);
+                if (s + 2 < nst2) consume(s + 2, fC);
+                if (s + 5 < nst2) issue(s + 5, fC);
             }
         }
+    }
+    else if (MODE == 0) {
+        // (waves without a tile of the upward product still take part in the gather of x and in its barrier)
+        const int items = Bq * R16;
+        for (int e = tid; e < items; e += TH_NT) {
+            const int b = e / R16, i = e - b * R16;
+            float xv = 0.f;
+            if (b < a.B && i < nrows) {
+                xv = a.data[thin_src_row(a.idx, a.idx64, b, a.n_data) * a.ld_data + r0 + i];
+                a.v0_out[(int64_t)b * a.ldv + r0 + i] = xv;
+            }
+            unsigned short q1, q2, q3;
+            split3(xv, q1, q2, q3);
+            xP[b * PXb + i] = q1; xP[xp_plane + b * PXb + i] = q2; xP[2 * xp_plane + b * PXb + i] = q3;
+        }
+        __syncthreads();
     }
 
     // the workgroup's partial of the upward product: rows 0 .. Bq - 1 (rows >= B are exact zeros)
@@ -448,12 +486,40 @@ template <> struct ThinVec<2> {
     static __device__ __forceinline__ T make(const float (&x)[2]) { return make_float2(x[0], x[1]); }
 };
 
+#ifndef TH_UPD_NT
+#define TH_UPD_NT 0         // 1: W / W_speed streamed with non-temporal loads and stores (A/B: profiles/r05i_thin_update_variants.log)
+#endif
+template <typename VT>
+__device__ __forceinline__ VT th_stream_load(const float* p)
+{
+#if TH_UPD_NT
+    typedef float nvec __attribute__((ext_vector_type(sizeof(VT) / 4)));
+    const nvec t = __builtin_nontemporal_load(reinterpret_cast<const nvec*>(p));
+    return __builtin_bit_cast(VT, t);
+#else
+    return *reinterpret_cast<const VT*>(p);
+#endif
+}
+template <typename VT>
+__device__ __forceinline__ void th_stream_store(float* p, const VT& v)
+{
+#if TH_UPD_NT
+    typedef float nvec __attribute__((ext_vector_type(sizeof(VT) / 4)));
+    __builtin_nontemporal_store(__builtin_bit_cast(nvec, v), reinterpret_cast<nvec*>(p));
+#else
+    *reinterpret_cast<VT*>(p) = v;
+#endif
+}
+
 template <int NB, int CW, bool WC>
 __global__ __launch_bounds__(TH_UNT) void thin_update_kernel(ThinUpdArgs a)
 {
     constexpr int Bq = 4 * NB, R2 = 2 * Bq;
     constexpr int NW = TH_UNT / 64;
-    constexpr int PD = CW == 4 ? 4 : 8;                        // rows whose W / W_speed loads are in flight together per wave
+#ifndef TH_UPD_PD
+#define TH_UPD_PD 8
+#endif
+    constexpr int PD = CW == 4 ? 4 : TH_UPD_PD;                // rows whose W / W_speed loads are in flight together per wave
     typedef typename ThinVec<CW>::T VT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x;
@@ -503,8 +569,8 @@ __global__ __launch_bounds__(TH_UNT) void thin_update_kernel(ThinUpdArgs a)
                 for (int q = 0; q < PD; ++q) {
                     const int ic = min(i + q * nrl, nrows - 1);
                     const int64_t off = (int64_t)(r0 + ic) * a.ldh + j;
-                    w[q] = *reinterpret_cast<const VT*>(u.W + off);
-                    sp[q] = *reinterpret_cast<const VT*>(u.Ws + off);
+                    w[q] = th_stream_load<VT>(u.W + off);
+                    sp[q] = th_stream_load<VT>(u.Ws + off);
                     if (WC) w0[q] = *reinterpret_cast<const VT*>(w0base + off);
                 }
             }
@@ -544,8 +610,8 @@ __global__ __launch_bounds__(TH_UNT) void thin_update_kernel(ThinUpdArgs a)
                         sn[c] = upd_speed(gr, sv[c], u.mu);
                         wn[c] = upd_param(wv[c], m, sv[c], u.lr);
                     }
-                    *reinterpret_cast<VT*>(u.W + off) = ThinVec<CW>::make(wn);
-                    *reinterpret_cast<VT*>(u.Ws + off) = ThinVec<CW>::make(sn);
+                    th_stream_store<VT>(u.W + off, ThinVec<CW>::make(wn));
+                    th_stream_store<VT>(u.Ws + off, ThinVec<CW>::make(sn));
                     if (u.Wp) {
 #pragma unroll
                         for (int c = 0; c < CW; ++c) {
