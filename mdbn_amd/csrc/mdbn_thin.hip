@@ -16,9 +16,13 @@
 //                         half of the update ride along.
 //
 // W is read 2 + k times per CD-k step (propup, k Gibbs steps, update) and written once, against ~7 streams on the
-// register-streaming GEMM path this replaces at B <= 32.  All arithmetic is float32: the products run on
-// v_mfma_f32_32x32x2_f32 (exact f32 FMA chains; the minibatch is one 32-row M tile), the rank-2B statistics on the VALU.
-// Same Philox addressing, same activation arithmetic (act_quad) as every other path.
+// register-streaming GEMM path this replaces at B <= 32 (PMC, 19 937 -> 400 at batch 20: 245 MB per step,
+// profiles/r05k_thin_pmc_traffic.json).  The products run on the bf16 matrix pipe at float32 accuracy
+// (v_mfma_f32_32x32x16_bf16; the minibatch is one 32-row M tile): every float32 fragment -- read from the float32 LDS image of
+// the workgroup's block of W, or straight from global memory in the positive phase -- is split EXACTLY into its three bf16
+// pieces in registers on the way into the MFMA (mdbn_bf16x3.h: the six / three piece products and order of
+// gemm_bf16x6_kernel); a first version on v_mfma_f32_32x32x2_f32 was bound by that pipe (1/16 of the bf16 rate).  The
+// rank-2B statistics run on the VALU.  Same Philox addressing and activation arithmetic (act_quad) as every other path.
 #include <hip/hip_runtime.h>
 #include "mdbn_thin.h"
 #include "mdbn_device.h"
@@ -399,28 +403,31 @@ hipError_t launch_thin_pass(int mode, const ThinPassArgs& a, const ThinGeom& t, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Sum of the G partials + bias + activation + sampling.  Workgroup = (4-row group, 64 columns); its 16 waves take
-// the partials p = wave, wave + 16, ... (loads of 8 partials x 4 rows in flight), sums in float64 and rounds ONCE, as
-// act_epilogue_kernel does with split-K slabs; wave 0 then adds the 16 wave sums in wave order (deterministic).
+// Sum of the G partials + bias + activation + sampling.  Workgroup = (4-row group, LW columns); its 1024 / LW lane groups
+// take the partials p = group, group + 1024 / LW, ... in batches of eight partials x four rows of loads, sum in float64 and
+// round ONCE, as act_epilogue_kernel does with split-K slabs; group 0 then adds the group sums in order (deterministic).
+// LW = 32 (half-waves) for many partials: at G = 256 every lane has ONE batch of 32 loads -- one round trip to the partials
+// for the whole launch (19 937 -> 400: 6.5 -> 5.6 us); LW = 64 for few (784 -> 500, G = 49: 5.0 us against 5.8 with LW = 32).
 // ------------------------------------------------------------------------------------------------------------------
-template <int MODE>       // act_quad's: bit 0 = a sample is wanted (hidden units are Bernoulli: bit 1, gauss, is never set here)
+template <int MODE, int LW>       // MODE: act_quad's bit 0 = a sample is wanted (hidden units are Bernoulli: bit 1, gauss, is never set here)
 __global__ __launch_bounds__(TH_ACT_NT) void thin_act_kernel(ThinActArgs a)
 {
-    __shared__ double redd[16][4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NG = TH_ACT_NT / LW;
+    __shared__ double redd[NG][4][LW];
+    const int l32 = threadIdx.x % LW, hw = threadIdx.x / LW;
     const EpiArgs& e = a.e;
-    const int ncc = (int)((e.ld + 63) >> 6);
+    const int ncc = (int)((e.ld + LW - 1) / LW);
     const int rg = blockIdx.x / ncc, cc = blockIdx.x - rg * ncc;
-    const int col = 64 * cc + lane, r0 = 4 * rg;
+    const int col = LW * cc + l32, r0 = 4 * rg;
     const int colc = min(col, (int)e.ld - 1);
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const int64_t pstride = (int64_t)a.Bq * e.ld;
     const float* base = a.part + (int64_t)r0 * e.ld + colc;
-    for (int p0 = wave; p0 < a.G; p0 += 16 * 8) {
+    for (int p0 = hw; p0 < a.G; p0 += NG * 8) {
         float v[8][4];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int p = min(p0 + 16 * u, a.G - 1);
+            const int p = min(p0 + NG * u, a.G - 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[u][r] = base[(int64_t)p * pstride + (int64_t)r * e.ld];
         }
@@ -428,17 +435,17 @@ __global__ __launch_bounds__(TH_ACT_NT) void thin_act_kernel(ThinActArgs a)
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] += p0 + 16 * u < a.G ? (double)v[u][r] : 0.0;
+            for (int r = 0; r < 4; ++r) acc[r] += p0 + NG * u < a.G ? (double)v[u][r] : 0.0;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) redd[wave][r][lane] = acc[r];
+    for (int r = 0; r < 4; ++r) redd[hw][r][l32] = acc[r];
     __syncthreads();
-    if (wave == 0 && col < (int)e.ld) {
+    if (hw == 0 && col < (int)e.ld) {
         double t[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4                      // (all 64 reads at once would not fit the 128 registers of a 16-wave workgroup)
-        for (int w = 0; w < 16; ++w)
+#pragma unroll 4                      // (all reads at once would not fit the 128 registers of a 16-wave workgroup)
+        for (int w = 0; w < NG; ++w)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] += redd[w][r][lane];
+            for (int r = 0; r < 4; ++r) t[r] += redd[w][r][l32];
         // hidden units: sigmoid + Bernoulli (rbm.py:198-213); act_quad's arithmetic and Philox words, without its cost /
         // plane / column-sum cases (with those compiled in, the kernel spilled at the 128 registers 16 waves leave a thread)
         const bool live = col < e.cols;
@@ -460,12 +467,18 @@ __global__ __launch_bounds__(TH_ACT_NT) void thin_act_kernel(ThinActArgs a)
 
 hipError_t launch_thin_act(const ThinActArgs& a, hipStream_t s)
 {
-    const int ncc = (int)((a.e.ld + 63) >> 6);
     if (a.e.gauss) return hipErrorInvalidValue;
-    if (a.e.sample != nullptr || a.e.sample_plane != nullptr)
-        hipLaunchKernelGGL(thin_act_kernel<1>, dim3((a.Bq >> 2) * ncc), dim3(TH_ACT_NT), 0, s, a);
-    else
-        hipLaunchKernelGGL(thin_act_kernel<0>, dim3((a.Bq >> 2) * ncc), dim3(TH_ACT_NT), 0, s, a);
+    const bool sample = a.e.sample != nullptr || a.e.sample_plane != nullptr;
+    const int lw = a.G >= 128 ? 32 : 64;
+    const int ncc = (int)((a.e.ld + lw - 1) / lw);
+    const dim3 grid((a.Bq >> 2) * ncc), block(TH_ACT_NT);
+    if (lw == 32) {
+        if (sample) hipLaunchKernelGGL((thin_act_kernel<1, 32>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((thin_act_kernel<0, 32>), grid, block, 0, s, a);
+    } else {
+        if (sample) hipLaunchKernelGGL((thin_act_kernel<1, 64>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((thin_act_kernel<0, 64>), grid, block, 0, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -536,6 +549,10 @@ __global__ __launch_bounds__(TH_UNT) void thin_update_kernel(ThinUpdArgs a)
     const int j = 64 * CW * cc + CW * lane;
     const bool jok = j < (int)a.ldh && rl < nrl;
     const int jc = j < (int)a.ldh ? j : 0;
+    const float two_lr_l1 = upd_two_lr_l1(u.lr, u.l1);
+    const float decay = upd_decay(u.lr, u.l2);
+    const float* w0base = u.W0 ? u.W0 : u.W;
+
     float p2[R2][CW];
 #pragma unroll
     for (int r = 0; r < R2; ++r) {
@@ -557,12 +574,9 @@ __global__ __launch_bounds__(TH_UNT) void thin_update_kernel(ThinUpdArgs a)
     __syncthreads();
     (void)npass;
 
-    const float two_lr_l1 = upd_two_lr_l1(u.lr, u.l1);
-    const float decay = upd_decay(u.lr, u.l2);
-    const float* w0base = u.W0 ? u.W0 : u.W;
-
     if (jok) {
         for (int i = rl; i < nrows; i += PD * nrl) {
+            // (requesting the first rows before the prologue above was measured: no gain, profiles/r05n)
             VT w[PD], sp[PD], w0[PD];
             if (a.do_upd) {
 #pragma unroll
