@@ -21,6 +21,9 @@ SHAPES = [  # V, H, B, k, gauss, through an index list
     (2000, 512, 7, 1, False, True),       # ragged batch (two Philox blocks, the second one partial), widest hidden layer
     (300, 130, 20, 2, False, False),      # fewer workgroups than CUs, hidden width not a multiple of 32
     (4099, 72, 25, 1, True, True),        # prime number of visible units: ragged last sub-block and last workgroup
+    (17, 5, 3, 2, False, True),           # tiny everything: one workgroup, one Philox block, H < one tile
+    (700, 512, 32, 1, True, False),       # the widest hidden layer at the largest batch: the LDS budget cuts the row blocks
+    (5000, 8, 1, 1, False, True),         # a single row
 ]
 
 
