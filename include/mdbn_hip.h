@@ -200,6 +200,11 @@ int  mdbn_ctx_destroy(mdbn_ctx *ctx);
  *   once (propdown and the following propup share one read: a workgroup owns whole rows of W), the rank-2B statistics are
  *   formed in registers inside the update pass -- W is read 2 + k times and written once per CD-k step.  0: the
  *   register-streaming GEMM path.
+ * "gchain" (default 0, opt-in): mid-size layers at B > 32 whose W fits the LDS of a group of 2-16 CUs (256 -> 200, 1024 -> 256)
+ *   run gather + positive phase + the whole Gibbs chain in ONE launch (csrc/mdbn_gchain.hip): 32-row slabs, each member of a
+ *   group holds a block of W's rows in LDS, one in-launch exchange of the upward partials per pass (agent-scope write-through
+ *   stores, a flag per member, bounded polls).  Same outputs as the multi-launch path, bit-reproducible; measured slower
+ *   than it (an exchange costs what a kernel boundary costs), hence off.
  * "small_fused" (default 1): a layer whose W fits one CU's LDS (V, H <= 512, W image + row buffers <= 160 KB: 512 -> 40,
  *   400 -> 40, 200 -> 20, 100 -> 128, 100 -> 24 -> 3) runs the whole CD-k chain in ONE launch per step -- W staged once, each
  *   workgroup the whole chain for 4-row slabs on v_mfma_f32_4x4x1 out of LDS, partial statistics per workgroup -- plus a

@@ -22,6 +22,7 @@
 #include "mdbn_kernels.h"
 #include "mdbn_small.h"
 #include "mdbn_thin.h"
+#include "mdbn_gchain.h"
 
 using namespace mdbn;
 
@@ -43,6 +44,7 @@ struct Options {
     int gemm_bf16x6 = 3;
     int small_fused = 1;
     int thin_fused = 1;
+    int gchain = 0;
     int gemm_planes = 1;
     int planes_mfma = 16;
     int early_w = 1;
@@ -84,6 +86,10 @@ struct mdbn_ctx {
     // compute-bound statistics GEMM); created on first use
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // group-chain step (mdbn_gchain.hip): the flag words of its in-launch exchange ([GC_MAX_FLAGS] + one error word; made
+    // and zeroed on first use, written by that protocol only) and the sequence number of the next launch's first exchange
+    unsigned* gc_flags = nullptr;
+    unsigned gc_seq = 1;
 };
 
 
@@ -275,6 +281,11 @@ bool prefer_skinny(int64_t M, int64_t N, int64_t K)
 // LDS-resident run the stream-over-W step of mdbn_thin.hip (W read 2 + k times per CD-k step); 0 = the register-streaming
 // GEMM path
 #define g_opt_thin_fused (t_opt->thin_fused)
+// mdbn_set_option("gchain") (default 0): mid-size layers at B > 32 whose W fits the LDS of a GROUP of 2-16 CUs (256 -> 200,
+// 1024 -> 256) run the positive phase and the whole Gibbs chain in ONE launch (mdbn_gchain.hip).  Parity-green and
+// deterministic, but NOT faster than one launch per pass (profiles/r05q_gchain_ab.log: 119.8 vs 104.9 us at 256 -> 200
+// CD-5, 68.6 vs 65.8 at 1024 -> 256): an in-launch exchange + the epilogues behind it cost what a kernel boundary costs.
+#define g_opt_gchain (t_opt->gchain)
 #define g_opt_gemm_planes (t_opt->gemm_planes)
 // mdbn_set_option("planes_mfma"): MFMA shape of the plane GEMMs: 16 = v_mfma_f32_16x16x32_bf16 (default: the chip holds
 // a higher clock on it), 32 = v_mfma_f32_32x32x16_bf16 (the products and order of gemm_bf16x6_kernel: same bits as the
@@ -441,6 +452,15 @@ static WsSizes ws_sizes_dense(int64_t B, int64_t V, int64_t H)
             thin_cost = tg.G;
         }
     }
+    int64_t gc_cost = 0;
+    {       // group-chain step (mdbn_gchain.hip): the exchange payload lives in the slab region (the statistics GEMM's slabs
+            // come after the chain), one cost partial per (slab, member)
+        GChainGeom gg;
+        if (gchain_geom(B, V, H, ldv, ldh, 0, kTargetJobs, gg)) {
+            s.slab = std::max<int64_t>(s.slab, gg.xbuf_floats);
+            gc_cost = (int64_t)gg.nslab * gg.g;
+        }
+    }
     s.slab = std::max<int64_t>(s.slab, 4 * std::max(ldv, ldh) * 8);
     s.cost = std::max<int64_t>(256, (((B + 3) / 4) * std::max(ldv, ldh) + 63) / 64) + 64;   // worst case: one column per thread, 64-thread blocks
     // fused epilogues write one partial per block: 128 x 64 tiles, or 32-column strips (skinny)
@@ -448,6 +468,7 @@ static WsSizes ws_sizes_dense(int64_t B, int64_t V, int64_t H)
     s.cost = std::max<int64_t>(s.cost, ((B + 63) / 64) * ((std::max(ldv, ldh) + 31) / 32) + 64);
     if (small_shape_ok(B, V, H, 0) || small_shape_ok(B, V, H, 1)) s.cost = std::max<int64_t>(s.cost, (int64_t)small_blocks(B) * SM_NW + 64);   // a cost partial per wave
     s.cost = std::max<int64_t>(s.cost, thin_cost + 64);
+    s.cost = std::max<int64_t>(s.cost, gc_cost + 64);
     const int ng = row_groups(B);
     s.colP = 2 * (int64_t)ng * ldh;
     s.colV = (int64_t)ng * ldv;
@@ -1019,6 +1040,7 @@ int mdbn_ctx_destroy(mdbn_ctx* ctx)
         if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
         if (ctx->side) (void)hipStreamDestroy(ctx->side);
         if (ctx->comm) (void)mdbn_comm_destroy(ctx);
+        if (ctx->gc_flags) (void)hipFree(ctx->gc_flags);
     }
     delete ctx;
     return MDBN_OK;
@@ -1064,6 +1086,10 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     }
     if (strcmp(name, "thin_fused") == 0) {
         ctx->opt.thin_fused = value != 0;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "gchain") == 0) {
+        ctx->opt.gchain = value != 0;
         return MDBN_OK;
     }
     if (strcmp(name, "skinny_fused_max_k") == 0) {
@@ -1790,7 +1816,35 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
     float* ph = a->P2;
     float* nh = a->P2 + B * ldh;
     int n_cost = 0;
-    if (mode != 2) {
+    // Mid-size layers: gather + positive phase + the whole Gibbs chain in ONE launch on groups of workgroups that hold W in
+    // their LDS between them (mdbn_gchain.hip); it leaves V2 / P2 / the column and cost partials exactly as the launches
+    // below would, so the statistics half of the step is unchanged
+    GChainGeom gg;
+    const bool use_gchain = mode != 2 && g_opt_gchain && !g_opt_bf16_inputs && !a->persistent && !a->sample_stats &&
+                            !(a->gauss && a->add_noise) && (a->gauss || a->vs != nullptr) &&
+                            gchain_geom(B, V, H, ldv, ldh, a->gauss, std::min(ctx->num_cu, kTargetJobs), gg) &&
+                            gg.xbuf_floats <= ws.slab_floats && (int64_t)gg.nslab * gg.g <= ws.cost_floats;
+    if (use_gchain) {
+        if (!ctx->gc_flags) {
+            HIP_OK(hipMalloc(reinterpret_cast<void**>(&ctx->gc_flags), sizeof(unsigned) * (GC_MAX_FLAGS + 4)));
+            HIP_OK(hipMemsetAsync(ctx->gc_flags, 0, sizeof(unsigned) * (GC_MAX_FLAGS + 4), s));
+        }
+        GChainArgs c{};
+        c.B = (int)B; c.V = (int)V; c.H = (int)H; c.k = a->k; c.gauss = a->gauss; c.ldv = ldv; c.ldh = ldh;
+        c.g = gg.g; c.Vb = gg.Vb; c.nslab = gg.nslab; c.nsg = gg.nsg; c.PW = gg.PW; c.S1 = gg.S1;
+        c.W = a->W; c.hbias = a->hbias; c.vbias = a->vbias;
+        c.data = a->data; c.n_data = a->n_data; c.ld_data = ldv; c.idx = a->indexes; c.idx64 = a->index_is_64;
+        c.V2 = a->V2; c.P2 = a->P2; c.hs = a->hs; c.vs = a->gauss ? nullptr : a->vs;
+        c.trace_h = a->trace_h; c.trace_v = a->gauss ? nullptr : a->trace_v;
+        c.colPpos = ws.colPpos; c.colPneg = ws.colPneg; c.colV = ws.colV; c.cost_partials = ws.cost_partials;
+        c.xbuf = ws.slabs; c.flags = ctx->gc_flags; c.error = ctx->gc_flags + GC_MAX_FLAGS;
+        c.seq0 = ctx->gc_seq;
+        ctx->gc_seq += (unsigned)(((gg.nslab + gg.nsg - 1) / gg.nsg) * (a->k + 1)) + 1u;
+        c.rng = make_key(a->rng, 0u);
+        HIP_OK(launch_gchain(c, gg.lds, s));
+        n_cost = gg.nslab * gg.g;
+    }
+    if (mode != 2 && !use_gchain) {
 
     // x = train_set_x[indexes]                                        (dbn.py:307)
     HIP_OK(launch_gather(a->data, a->n_data, ldv, ldv, a->indexes, a->index_is_64, B, v0, ldv, s));

@@ -4,7 +4,7 @@ shape; MDBN_AB_SHAPE="V,H,B,k,gauss" selects another, as scripts/step_ab.py).
     python scripts/build_variants.py "-DX6_SCHED=0" "-DX6_SCHED=1" ..."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = [os.path.join(ROOT, "mdbn_amd", "csrc", f) for f in ("mdbn_kernels.hip", "mdbn_planes.hip", "mdbn_small.hip", "mdbn_thin.hip", "mdbn_capi.hip")]
+src = [os.path.join(ROOT, "mdbn_amd", "csrc", f) for f in ("mdbn_kernels.hip", "mdbn_planes.hip", "mdbn_small.hip", "mdbn_thin.hip", "mdbn_gchain.hip", "mdbn_capi.hip")]
 out = os.path.join(ROOT, "gpurun_out"); os.makedirs(out, exist_ok=True)
 for i, flags in enumerate(sys.argv[1:]):
     so = os.path.join(out, "libmdbn_var%d.so" % i)
