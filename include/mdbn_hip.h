@@ -108,9 +108,13 @@ typedef struct mdbn_cd_args {
      * buffer: the statistics kernel's loader waves then gather those rows into the other buffer beside the MFMA main loop,
      * and the next call starts without a gather launch (x_buffer flipped, v0_ready = 1).  Same planes as the gather kernel
      * writes: results are bit-identical with and without.  The library decides per call whether it does it (plane path,
-     * fused early update, keep_f32 = 0, <= 4 rows per workgroup) and reports through *ahead_done. */
+     * fused early update, keep_f32 = 0, <= 4 rows per workgroup) and reports through *ahead_done.
+     * Thin-batch path (B <= 32): the update kernel, which streams W once anyway, also gathers the next minibatch into rows
+     * 0..B-1 of V2 and leaves the partials of its positive phase x' W' in planes_alt (>= mdbn_ahead_bytes_ctx bytes): the
+     * next call (v0_ready = 1; same data, index list and parameters, nothing else run on these buffers in between)
+     * starts at its first activation kernel.  Same products in the same order: bit-identical with and without. */
     const void  *next_indexes;   /* [B] indices of the next minibatch (device, same type as indexes), or NULL         */
-    void        *planes_alt;     /* second [3][2B][ldv] bf16 X2-plane buffer (mdbn_planes_alt_bytes), or NULL          */
+    void        *planes_alt;     /* second [3][2B][ldv] bf16 X2-plane buffer (mdbn_ahead_bytes_ctx), or NULL            */
     int32_t      x_buffer;       /* X2 planes of THIS step: 0 = inside `planes`, 1 = `planes_alt`                      */
     int32_t      v0_ready;       /* 1: rows 0..B-1 of that buffer already hold this minibatch (gathered ahead)         */
     int32_t     *ahead_done;     /* host pointer (nullable): set to 1 when this call gathered next_indexes ahead, else 0 */
@@ -243,6 +247,9 @@ int  mdbn_padded_ld(int64_t cols, int64_t *ld);
 int  mdbn_planes_bytes(int64_t B, int64_t ldv, int64_t ldh, int64_t *bytes);
 /* bytes of the second X2-plane buffer of the gather-ahead (mdbn_cd_args.planes_alt) */
 int  mdbn_planes_alt_bytes(int64_t B, int64_t ldv, int64_t *bytes);
+/* bytes of mdbn_cd_args.planes_alt for this shape, whichever path serves it (plane path: the same as
+ * mdbn_planes_alt_bytes; thin-batch path: the partials of the next step's positive phase) */
+int  mdbn_ahead_bytes_ctx(mdbn_ctx *ctx, int64_t B, int64_t V, int64_t H, int64_t ldv, int64_t ldh, int64_t *bytes);
 /* Does the plane path of mdbn_cd_step / mdbn_cd_train_step serve this shape under the CURRENT options (B and V whole
  * 128-row / 128-column tiles, ldv == V; the hidden side on a leading dimension of whole tiles, ldh % 128 == 0 and
  * H <= ldh < H + 128 -- a ragged hidden width rides on zero pad columns --; "gemm_planes" on, B * V * ldh >=

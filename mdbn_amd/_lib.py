@@ -75,6 +75,7 @@ SIGNATURES = {
     "mdbn_padded_ld": [_i64, C.POINTER(_i64)],
     "mdbn_planes_bytes": [_i64, _i64, _i64, C.POINTER(_i64)],
     "mdbn_planes_alt_bytes": [_i64, _i64, C.POINTER(_i64)],
+    "mdbn_ahead_bytes_ctx": [_vp, _i64, _i64, _i64, _i64, _i64, C.POINTER(_i64)],
     "mdbn_planes_eligible": [_i64, _i64, _i64, _i64, _i64, C.POINTER(_i32)],
     "mdbn_planes_eligible_ctx": [_vp, _i64, _i64, _i64, _i64, _i64, C.POINTER(_i32)],
     "mdbn_split_planes": [_vp, _vp, _vp, _i64, _i64, _vp],

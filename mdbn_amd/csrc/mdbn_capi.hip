@@ -1289,6 +1289,18 @@ int mdbn_planes_alt_bytes(int64_t B, int64_t ldv, int64_t* bytes)
     return MDBN_OK;
 }
 
+int mdbn_ahead_bytes_ctx(mdbn_ctx* ctx, int64_t B, int64_t V, int64_t H, int64_t ldv, int64_t ldh, int64_t* bytes)
+{
+    CtxScope ctx_scope(ctx);
+    REQUIRE(ctx != nullptr && bytes != nullptr && B > 0 && V > 0 && H > 0 && ldv >= V && ldh >= H, "bad arguments");
+    int64_t n = 2 * 6 * B * ldv;                        // plane path: the second X2-plane buffer
+    ThinGeom tg;
+    if (thin_geom(B, V, H, ldv, ldh, std::min(ctx->num_cu, kTargetJobs), tg) && tg.lds_ahead > 0)
+        n = std::max<int64_t>(n, (int64_t)tg.G * tg.Bq * ldh * 4);     // thin path: the partials of the next positive phase
+    *bytes = n;
+    return MDBN_OK;
+}
+
 int mdbn_split_planes(mdbn_ctx* ctx, void* stream, const float* x, int64_t rows, int64_t ld, void* planes)
 {
     CtxScope ctx_scope(ctx);
@@ -1689,6 +1701,13 @@ static int cd_step_thin(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, con
     float* ph = a->P2;
     float* nh = a->P2 + B * ldh;
     int n_cost = tg.G;
+    // positive phase ahead (mdbn_cd_args.next_indexes on the thin path): the previous call's update kernel left v0 in V2 and
+    // the partials of x W in planes_alt; this call's update kernel may do the same for the next one
+    const bool keep = a->keep_f32 != 0 || a->trace_h != nullptr || a->trace_v != nullptr;
+    const bool ahead_ok = a->planes_alt != nullptr && !keep && tg.lds_ahead > 0 && a->indexes != nullptr;
+    const bool ahead_in = ahead_ok && a->v0_ready && mode != 2;
+    if (a->planes_alt) REQUIRE(aligned16(a->planes_alt), "planes_alt not 16-byte aligned");
+    float* part_ahead = reinterpret_cast<float*>(a->planes_alt);
     if (mode != 2) {
         ThinPassArgs p{};
         p.B = (int)B; p.Bq = tg.Bq; p.V = (int)V; p.H = (int)H; p.ldv = ldv; p.ldh = ldh;
@@ -1697,12 +1716,13 @@ static int cd_step_thin(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, con
         p.data = a->data; p.n_data = a->n_data; p.ld_data = ldv; p.idx = a->indexes; p.idx64 = a->index_is_64; p.v0_out = v0;
         p.vbias = a->vbias; p.gauss = a->gauss;
         // x = train_set_x[indexes] and the partials of x W                      (dbn.py:307, rbm.py:303)
-        HIP_OK(launch_thin_pass(0, p, tg, s));
+        if (!ahead_in) HIP_OK(launch_thin_pass(0, p, tg, s));
         ThinActArgs act{};
-        act.part = ws.slabs; act.G = tg.G; act.Bq = tg.Bq;
+        act.part = ahead_in ? part_ahead : ws.slabs; act.G = tg.G; act.Bq = tg.Bq;
         act.e.rows = (int)B; act.e.cols = (int)H; act.e.ld = ldh; act.e.bias = a->hbias;
         act.e.mean = ph; act.e.mean_scale = 1.0f; act.e.sample = a->hs; act.e.rng = make_key(a->rng, 0u);
         HIP_OK(launch_thin_act(act, s));
+        act.part = ws.slabs;
         if (a->trace_h) HIP_OK(hipMemcpyAsync(a->trace_h, a->hs, sizeof(float) * B * ldh, hipMemcpyDeviceToDevice, s));
         for (int t = 1; t <= a->k; ++t) {                                  // gibbs_hvh x k (rbm.py:318-336)
             const bool last = t == a->k;
@@ -1742,6 +1762,15 @@ static int cd_step_thin(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, con
         u.bu.hb = upd->hbias; u.bu.hbs = upd->hbias_speed; u.bu.vb = upd->vbias; u.bu.vbs = upd->vbias_speed;
         u.bu.H = H; u.bu.V = V; u.bu.lr = upd->lr; u.bu.mu = upd->momentum; u.bu.inv_rows = 1.0f / upd->n_rows;
         u.bu.cost_scale = upd->cost_scale; u.bu.cost_out = upd->cost_out;
+    }
+    if (fuse_upd && mode == 0 && ahead_ok && a->next_indexes && g_opt_gather_ahead) {
+        // update(t) + gather and positive-phase partials of step t + 1 in one pass over W
+        u.G = tg.G; u.rpw = tg.rpw; u.PW = tg.PW;
+        u.data = a->data; u.n_data = a->n_data; u.ld_data = ldv; u.next_idx = a->next_indexes; u.idx64 = a->index_is_64;
+        u.part_next = part_ahead; u.v0_next = a->V2;
+        HIP_OK(launch_thin_update_ahead(u, tg, s));
+        if (a->ahead_done) *a->ahead_done = 1;
+        return MDBN_OK;
     }
     HIP_OK(launch_thin_update(u, tg, s));
     if (upd && !fuse_upd) {

@@ -28,6 +28,7 @@ struct ThinGeom {
     int lds_pass, lds_up;                   // dynamic LDS of the down + up pass / of the up-only pass (bytes)
     int Gu, rpu;                            // workgroups / rows per workgroup of the update kernel
     int lds_upd;
+    int lds_ahead;                          // dynamic LDS of the update + next positive phase kernel (0: it does not fit)
 };
 
 // bytes of LDS the down + up pass needs for rpw rows per workgroup (layout: thin_pass_kernel)
@@ -67,6 +68,11 @@ __host__ __device__ inline bool thin_geom(int64_t B, int64_t V, int64_t H, int64
     t.rpu = (int)rpu;
     t.Gu = (int)((V + rpu - 1) / rpu);
     t.lds_upd = t.rpu * 2 * t.Bq * 4;
+    {       // update(t) + positive phase(t + 1) in one pass over W: float32 image of the block | [v0; nv] block | planes of x'
+        const int R16 = (t.rpw + 15) & ~15;
+        const int need = R16 * t.PW * 4 + t.rpw * 2 * t.Bq * 4 + 3 * t.Bq * (R16 + 8) * 2;
+        t.lds_ahead = need <= TH_MAX_LDS ? need : 0;
+    }
     return true;
 }
 
@@ -114,10 +120,18 @@ struct ThinUpdArgs {
     int do_upd;
     UpdEpi upd;                             // W, Ws, W0, lr, l1, l2, wc, mu, inv_bs (Wp: planes of the new W or NULL)
     BiasUpd bu;
+    // thin_update_ahead_kernel only (pass geometry in G / rpw): the positive phase of the NEXT minibatch from the rows of
+    // W this pass has just updated -- x' = data[next_idx], its partials of x' W' (one per workgroup) and v0' into V2 rows 0..B-1
+    const float* data; int64_t n_data, ld_data;
+    const void* next_idx; int idx64;
+    float* part_next;                       // [G][Bq][ldh]
+    float* v0_next;                         // = V2 (rows 0..B-1 are overwritten AFTER this workgroup has read its block of them)
+    int PW;
 };
 
 hipError_t launch_thin_pass(int mode, const ThinPassArgs& a, const ThinGeom& t, hipStream_t s);
 hipError_t launch_thin_act(const ThinActArgs& a, hipStream_t s);
 hipError_t launch_thin_update(const ThinUpdArgs& a, const ThinGeom& t, hipStream_t s);
+hipError_t launch_thin_update_ahead(const ThinUpdArgs& a, const ThinGeom& t, hipStream_t s);
 
 }  // namespace mdbn

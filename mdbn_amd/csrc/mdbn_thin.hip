@@ -694,6 +694,296 @@ __global__ __launch_bounds__(TH_UNT) void thin_update_kernel(ThinUpdArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// update(t) + positive phase(t + 1) in ONE pass over W (the trainers announce the next minibatch:
+// mdbn_cd_args.next_indexes).  thin_update_kernel's row loop on the PASS geometry (G workgroups of 512 threads, rpw rows):
+// every updated row W' goes to global memory and into a float32 LDS image of the block; when the block is done the
+// workgroup multiplies x' = data[next_indexes][:, block] into it exactly as thin_pass_kernel<1>'s upward product does and
+// writes ONE partial of x' W' -- the next step starts at its first activation kernel.  v0' overwrites rows 0..B-1 of V2
+// (this workgroup's columns only, after it has staged its block of [v0; nv]).
+// LDS (bytes): Wf [R16][PW] f32 | x2T [rpw][2 Bq] f32 | xP [3][Bq][R16 + 8] bf16.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NB, bool WC, int NT2>
+__global__ __launch_bounds__(TH_NT) void thin_update_ahead_kernel(ThinUpdArgs a)
+{
+    constexpr int CW = 2, Bq = 4 * NB, R2 = 2 * Bq, NW = TH_NT / 64, PD = NB >= 7 ? 4 : 8;      // (rows in flight: 256 VGPRs)
+    typedef typename ThinVec<CW>::T VT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ln = lane & 31, kh = lane >> 5;
+    const int g = blockIdx.x;
+    const int r0 = g * a.rpw, r1 = min(a.V, r0 + a.rpw), nrows = r1 - r0;
+    const int R16 = (a.rpw + 15) & ~15, PXb = R16 + 8, PW = a.PW;
+    const int K16 = ((int)a.ldh + 15) & ~15;
+    float* Wf = th_smem;
+    float* x2T = Wf + R16 * PW;
+    unsigned short* xP = reinterpret_cast<unsigned short*>(x2T + a.rpw * R2);
+    const int xp_plane = Bq * PXb;
+
+    int ncw = 1;
+    while (ncw * 64 * CW < (int)a.ldh) ncw *= 2;              // 1 | 2 | 4 column chunks of 128
+    const int cc = wave % ncw, rl = wave / ncw, nrl = NW / ncw;
+    const UpdEpi& u = a.upd;
+    const int j = 64 * CW * cc + CW * lane;
+    const bool jok = j < (int)a.ldh;
+    const int jc = jok ? j : 0;
+
+    constexpr int GN = 4;                   // items of the [Bq][R16] tile of x' per thread and round
+    const int items = Bq * R16;
+    int64_t srow[GN];
+#pragma unroll
+    for (int q = 0; q < GN; ++q) srow[q] = thin_src_row(a.next_idx, a.idx64, min((tid + TH_NT * q) / R16, a.B - 1), a.n_data);
+
+    float p2[R2][CW];
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+        const int half = r >= Bq, b = r - half * Bq;
+        float t[CW];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) t[c] = 0.f;
+        if (b < a.B && jok) ThinVec<CW>::get(*reinterpret_cast<const VT*>(a.P2 + (int64_t)(half * a.B + b) * a.ldh + jc), t);
+#pragma unroll
+        for (int c = 0; c < CW; ++c) p2[r][c] = t[c];
+    }
+    for (int e = tid; e < R2 * a.rpw; e += TH_NT) {
+        const int r = e / a.rpw, i = e - r * a.rpw;
+        const int half = r >= Bq, b = r - half * Bq;
+        float v = 0.f;
+        if (b < a.B && i < nrows) v = a.V2[(int64_t)(half * a.B + b) * a.ldv + r0 + i];
+        x2T[i * R2 + r] = v;
+    }
+    // pad rows / pad columns of the image: zeros (the row loop writes columns < ldh of rows < nrows)
+    for (int e = tid; e < R16 * (K16 >> 2); e += TH_NT) {
+        const int row = e / (K16 >> 2), c4 = e - row * (K16 >> 2);
+        if (row >= nrows || 4 * c4 >= (int)a.ldh) *reinterpret_cast<float4*>(Wf + row * PW + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();                        // this workgroup's block of [v0; nv] is in LDS: rows 0..B-1 of V2 may be overwritten
+    // x' = data[next_indexes][:, block]: the loads go out here and land while the first rows of W stream in (consumed after
+    // the row loop); the row indices were requested at the top of the kernel
+    float xv[GN];
+#pragma unroll
+    for (int q = 0; q < GN; ++q) {
+        const int e = tid + TH_NT * q;
+        const int b = e / R16, i = e - b * R16;
+        xv[q] = (e < items && b < a.B && i < nrows) ? a.data[srow[q] * a.ld_data + r0 + i] : 0.f;
+    }
+
+    const float two_lr_l1 = upd_two_lr_l1(u.lr, u.l1);
+    const float decay = upd_decay(u.lr, u.l2);
+    const float* w0base = u.W0 ? u.W0 : u.W;
+    if (jok) {
+        for (int i = rl; i < nrows; i += PD * nrl) {
+            VT w[PD], sp[PD], w0[PD];
+#pragma unroll
+            for (int q = 0; q < PD; ++q) {
+                const int ic = min(i + q * nrl, nrows - 1);
+                const int64_t off = (int64_t)(r0 + ic) * a.ldh + j;
+                w[q] = th_stream_load<VT>(u.W + off);
+                sp[q] = th_stream_load<VT>(u.Ws + off);
+                if (WC) w0[q] = *reinterpret_cast<const VT*>(w0base + off);
+            }
+#pragma unroll
+            for (int q = 0; q < PD; ++q) {
+                const int ii = i + q * nrl;
+                if (ii >= nrows) break;
+                float st[CW];
+#pragma unroll
+                for (int c = 0; c < CW; ++c) st[c] = 0.f;
+                const float* xr = x2T + ii * R2;
+#pragma unroll
+                for (int r4 = 0; r4 < R2 / 4; ++r4) {
+                    const float4 xv = lds_read4(xr + 4 * r4);
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) {
+                        st[c] = fmaf(xv.x, p2[4 * r4 + 0][c], st[c]);
+                        st[c] = fmaf(xv.y, p2[4 * r4 + 1][c], st[c]);
+                        st[c] = fmaf(xv.z, p2[4 * r4 + 2][c], st[c]);
+                        st[c] = fmaf(xv.w, p2[4 * r4 + 3][c], st[c]);
+                    }
+                }
+                const int64_t off = (int64_t)(r0 + ii) * a.ldh + j;
+                float wv[CW], sv[CW], w0v[CW], wn[CW], sn[CW];
+                ThinVec<CW>::get(w[q], wv); ThinVec<CW>::get(sp[q], sv);
+                if (WC) ThinVec<CW>::get(w0[q], w0v);
+#pragma unroll
+                for (int c = 0; c < CW; ++c) {                // update_rule4's arithmetic, element by element (same helpers)
+                    float gr = upd_grad(st[c], u.inv_bs, WC ? u.wc : 0.f, WC ? w0v[c] : 0.f);
+                    float mm = decay;
+                    if (u.l1 != 0.0f) {
+                        const float shrink = upd_shrink(two_lr_l1, wv[c]);
+                        gr = __fdiv_rn(gr, shrink);
+                        mm = __fdiv_rn(decay, shrink);
+                    }
+                    sn[c] = upd_speed(gr, sv[c], u.mu);
+                    wn[c] = upd_param(wv[c], mm, sv[c], u.lr);
+                }
+                th_stream_store<VT>(u.W + off, ThinVec<CW>::make(wn));
+                th_stream_store<VT>(u.Ws + off, ThinVec<CW>::make(sn));
+                *reinterpret_cast<VT*>(Wf + ii * PW + j) = ThinVec<CW>::make(wn);          // the NEW row, for the next positive phase
+                if (u.Wp) {
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) {
+                        unsigned short q1, q2, q3;
+                        split3(wn[c], q1, q2, q3);
+                        u.Wp[off + c] = q1; u.Wp[u.wp_stride + off + c] = q2; u.Wp[2 * u.wp_stride + off + c] = q3;
+                    }
+                }
+            }
+        }
+    }
+
+    auto put_x = [&](int e, float v) {
+        const int b = e / R16, i = e - b * R16;
+        if (b < a.B && i < nrows) a.v0_next[(int64_t)b * a.ldv + r0 + i] = v;
+        unsigned short q1, q2, q3;
+        split3(v, q1, q2, q3);
+        xP[b * PXb + i] = q1; xP[xp_plane + b * PXb + i] = q2; xP[2 * xp_plane + b * PXb + i] = q3;
+    };
+#pragma unroll
+    for (int q = 0; q < GN; ++q)
+        if (tid + TH_NT * q < items) put_x(tid + TH_NT * q, xv[q]);
+    for (int e0 = TH_NT * GN; e0 < items; e0 += TH_NT * GN) {           // (tiles of more than 2048 items: further rounds)
+        int64_t sr[GN];
+#pragma unroll
+        for (int q = 0; q < GN; ++q) sr[q] = thin_src_row(a.next_idx, a.idx64, min((e0 + tid + TH_NT * q) / R16, a.B - 1), a.n_data);
+        float xw[GN];
+#pragma unroll
+        for (int q = 0; q < GN; ++q) {
+            const int e = e0 + tid + TH_NT * q;
+            const int b = e / R16, i = e - b * R16;
+            xw[q] = (e < items && b < a.B && i < nrows) ? a.data[sr[q] * a.ld_data + r0 + i] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < GN; ++q)
+            if (e0 + tid + TH_NT * q < items) put_x(e0 + tid + TH_NT * q, xw[q]);
+    }
+
+    // s_v (rbm.py:417) of this workgroup's visible units and their bias update; workgroup 0: s_h, hidden biases, cost
+    for (int i = tid; i < nrows; i += TH_NT) {
+        float t = 0.f;
+        for (int b = 0; b < a.B; ++b) t += x2T[i * R2 + b] - x2T[i * R2 + Bq + b];
+        const int64_t col = r0 + i;
+        a.s_v[col] = t;
+        const BiasUpd& bu = a.bu;
+        const float sp = bu.vbs[col], p0 = bu.vb[col];
+        bu.vbs[col] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
+        bu.vb[col] = upd_param(p0, 1.0f, sp, bu.lr);
+    }
+    if (g == 0) {
+        if (jok && rl == 0) {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < R2; ++r) t += p2[r][c];
+                const int64_t jj = j + c;
+                if (jj >= a.H) t = 0.f;
+                a.s_h[jj] = t;
+                if (jj < a.H) {
+                    const BiasUpd& bu = a.bu;
+                    const float sp = bu.hbs[jj], p0 = bu.hb[jj];
+                    bu.hbs[jj] = upd_speed(upd_scale(t, bu.inv_rows), sp, bu.mu);
+                    bu.hb[jj] = upd_param(p0, 1.0f, sp, bu.lr);
+                }
+            }
+        }
+        for (int64_t c = a.V + tid; c < a.ldv; c += TH_NT) a.s_v[c] = 0.f;
+        if (wave == NW - 1) {
+            float t = 0.f;
+            for (int k0 = lane; k0 < a.n_cost; k0 += 256) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = k0 + 64 * q < a.n_cost ? a.cost_partials[k0 + 64 * q] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t += v[q];
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+            if (lane == 0) {
+                a.cost[0] = t; a.cost[1] = 0.f; a.cost[2] = 0.f; a.cost[3] = 0.f;
+                if (a.bu.cost_out) a.bu.cost_out[0] = t * a.bu.cost_scale;
+            }
+        }
+    }
+    __syncthreads();                        // the image of the updated block and the planes of x' are complete
+
+    // ---- the next step's positive phase over this block: partial[b][j] = sum_i x'[b][i] W'[r0 + i][j]
+    f32x16 acc2[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+    const int bA = min(ln, Bq - 1);
+    if (32 * wave < (int)a.ldh) {
+        const int nst2 = (nrows + 15) >> 4;
+        for (int s = 0; s < nst2; ++s) {
+            tbf16x8 fa[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fa[pl] = *reinterpret_cast<const tbf16x8*>(xP + pl * xp_plane + bA * PXb + 16 * s + 8 * kh);
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) {
+                if (32 * (wave + 8 * t) < (int)a.ldh) {
+                    const int jt = min(32 * (wave + 8 * t) + ln, (int)a.ldh - 1);
+                    const float* wp = Wf + (16 * s + 8 * kh) * PW + jt;
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = wp[e * PW];
+                    tbf16x8 fb[3];
+                    th_split8(f, fb);
+                    th_mma<3>(acc2[t], fa, fb);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+        const int jj = 32 * (wave + 8 * t) + ln;
+        if (jj < (int)a.ldh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (b < Bq) a.part_next[((int64_t)g * Bq + b) * a.ldh + jj] = acc2[t][r];
+            }
+        }
+    }
+}
+
+template <int NB, int NT2>
+static hipError_t launch_thin_update_ahead_t(const ThinUpdArgs& a, int lds, hipStream_t s)
+{
+    if (a.upd.wc != 0.f) {
+        auto kern = thin_update_ahead_kernel<NB, true, NT2>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, TH_MAX_LDS);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(a.G), dim3(TH_NT), lds, s, a);
+    } else {
+        auto kern = thin_update_ahead_kernel<NB, false, NT2>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, TH_MAX_LDS);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(a.G), dim3(TH_NT), lds, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_thin_update_ahead(const ThinUpdArgs& a, const ThinGeom& t, hipStream_t s)
+{
+    if (!a.do_upd || t.lds_ahead <= 0) return hipErrorInvalidValue;
+#define TH_AHEAD_CASE(NBV) case NBV: return t.nt2 == 1 ? launch_thin_update_ahead_t<NBV, 1>(a, t.lds_ahead, s) : launch_thin_update_ahead_t<NBV, 2>(a, t.lds_ahead, s)
+    switch (t.Bq >> 2) {
+    TH_AHEAD_CASE(1); TH_AHEAD_CASE(2); TH_AHEAD_CASE(3); TH_AHEAD_CASE(4);
+    TH_AHEAD_CASE(5); TH_AHEAD_CASE(6); TH_AHEAD_CASE(7); TH_AHEAD_CASE(8);
+    }
+#undef TH_AHEAD_CASE
+    return hipErrorInvalidValue;
+}
+
 template <int NB, int CW>
 static hipError_t launch_thin_update_t(const ThinUpdArgs& a, int lds, hipStream_t s)
 {

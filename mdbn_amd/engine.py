@@ -83,7 +83,8 @@ class CDScratch(object):
     def alt_planes(self, engine, ldv):
         if self.planes_alt is None:
             n = C.c_int64()
-            _lib.check(engine.lib.mdbn_planes_alt_bytes(self.B, ldv, C.byref(n)), "mdbn_planes_alt_bytes")
+            _lib.check(engine.lib.mdbn_ahead_bytes_ctx(engine.ctx, self.B, self.V, self.H, ldv, self.P2.stride(0), C.byref(n)),
+                       "mdbn_ahead_bytes_ctx")
             self.planes_alt = torch.empty(n.value // 2, dtype=torch.int16, device=engine.device)
         return self.planes_alt
 
@@ -165,6 +166,8 @@ class HipEngine(object):
         self.ctx = ctx
         self._workspace = None
         self._options_epoch = 0         # bumped by set_option: argument structs cached by step functions are then stale
+        self._w_serial = 0              # bumped by every library call that writes parameters (what a positive phase computed
+                                        # ahead of its step was computed FROM: _ahead_valid)
         self._ws_need = {}              # (B, V, H) -> bytes the library asks for (options that change it clear this)
         self._stats = {}
         self._scratch = {}
@@ -488,6 +491,18 @@ class HipEngine(object):
         return (a is b) or (a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.numel() == b.numel()
                             and a.dtype == b.dtype)
 
+    def _ahead_valid(self, ahead, data, idx, W, thin):
+        """Was THIS minibatch prepared by the previous step (CDScratch.ahead)?  Same matrix, unchanged since, same index
+        list; thin-batch path, whose record also covers x W: the same parameters, written by nobody since that step
+        (torch-side writes move W._version, library-side ones _w_serial) under the same options."""
+        if ahead is None or ahead[0].data_ptr() != data.data_ptr() or ahead[1] != data._version or \
+                not self._same_index_tensor(ahead[2], idx) or ahead[4] != idx._version:
+            return False
+        return not thin or (len(ahead) == 9 and ahead[5:] == (W.data_ptr(), W._version, self._w_serial, self._options_epoch))
+
+    def _ahead_record(self, announce, W):
+        return announce + (W.data_ptr(), W._version, self._w_serial, self._options_epoch)
+
     def _cd_args(self, data, indexes, W, hbias, vbias, gauss, k, rng, persistent, add_noise, stats_slot,
                  sample_stats=False, stats=None, comm_cus=0, next_indexes=None):
         data = self.as_matrix(data)
@@ -531,12 +546,14 @@ class HipEngine(object):
         # same index list: the announced tensor has been kept alive, so an equal address means the same list)
         ahead, sc.ahead = sc.ahead, None
         keep = [data, idx, ws]
-        if sc.planes is not None and idx is not None and not self.keep_f32 and not self.trace_chain:
+        # ... on the plane path; on the thin-batch path (B <= 32, ldh <= 512: the library decides and reports) the previous
+        # step's update kernel gathered the rows AND left the partials of x W, so the parameters must be the ones it wrote
+        thin = sc.planes is None and B <= 32 and ldh <= 512 and persistent is None and not sample_stats
+        if (sc.planes is not None or thin) and idx is not None and not self.keep_f32 and not self.trace_chain:
             # (the announcing step keeps the matrix and the index tensor alive, so an equal address is the same object)
             # ... and unchanged: an index buffer refilled IN PLACE between the announcing call and this one has another
             # version counter, and the rows are gathered afresh
-            if ahead is not None and ahead[0].data_ptr() == data.data_ptr() and ahead[1] == data._version and \
-                    self._same_index_tensor(ahead[2], idx) and ahead[4] == idx._version:
+            if self._ahead_valid(ahead, data, idx, W, thin):
                 sc.x_buffer = ahead[3]
                 a.v0_ready = 1
             if sc.planes_alt is not None or next_indexes is not None:
@@ -549,7 +566,7 @@ class HipEngine(object):
                     self._ahead_flag = C.c_int32(0)
                     a.ahead_done = C.pointer(self._ahead_flag)
                     keep.append(nxt)
-                    sc._announce = (data, data._version, nxt, 1 - sc.x_buffer, nxt._version)
+                    sc._announce = (data, data._version, nxt, 0 if thin else 1 - sc.x_buffer, nxt._version)
         if self.trace_chain:
             if sc.trace_h is None or sc.trace_h.shape[0] != k + 1:
                 sc.trace_h = torch.zeros((k + 1, B, ldh), dtype=torch.float32, device=self.device)
@@ -598,9 +615,10 @@ class HipEngine(object):
                    "mdbn_cd_statistics")
         if u is not None:
             self._w_planes_written(W)
+            self._w_serial += 1
         announce = keep[-1]
         if announce is not None and a.ahead_done and self._ahead_flag.value:
-            sc.ahead = announce              # the next call finds its rows in the other X2 buffer
+            sc.ahead = self._ahead_record(announce, W)              # the next call finds its rows in the other X2 buffer
         return stats, sc, cost
 
     def _update_args(self, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, stats, lr, lambda_1,
@@ -636,7 +654,7 @@ class HipEngine(object):
         self._cost_slot = slot + 1
         return self._cost_ring[slot]
 
-    def cd_train_step_cached(self, cache, data, idx, rng_step, lr, momentum):
+    def cd_train_step_cached(self, cache, data, idx, rng_step, lr, momentum, next_indexes=None):
         """The step of ``cd_train_step`` through argument structs a step function keeps from its previous call
         (``cache`` = what ``cd_train_step(..., cache_out=)`` left): for small layers, whose step is two short launches, the
         host side -- building two ctypes structs of ~70 fields, resolving scratch, statistics and workspace buffers -- was
@@ -659,7 +677,21 @@ class HipEngine(object):
         cost = self._next_cost_slot()
         u.cost_out = cost.data_ptr()
         self.last_scratch = sc
+        # thin-batch path: positive phase prepared by the previous step / prepare the next one's (see _cd_args)
+        ahead, sc.ahead = sc.ahead, None
+        announce = None
+        if a.planes_alt:
+            a.v0_ready = int(self._ahead_valid(ahead, data, idx, W, True))
+            a.next_indexes = None
+            if next_indexes is not None:
+                nxt = self.index_tensor(next_indexes, data.shape[0])
+                if nxt.numel() == idx.numel() and nxt.dtype == idx.dtype:
+                    a.next_indexes = nxt.data_ptr()
+                    announce = (data, data._version, nxt, 0, nxt._version)
         _lib.check(self.lib.mdbn_cd_train_step(self.ctx, self._stream(), a_ref, u_ref), "mdbn_cd_train_step")
+        self._w_serial += 1
+        if announce is not None and a.ahead_done and a.ahead_done[0]:
+            sc.ahead = self._ahead_record(announce, W)
         return cost
 
     def cd_train_step(self, data, indexes, W, W_speed, W0, hbias, hbias_speed, vbias, vbias_speed, gauss, k,
@@ -679,13 +711,18 @@ class HipEngine(object):
         _lib.check(self.lib.mdbn_cd_train_step(self.ctx, self._stream(), C.byref(a), C.byref(u)),
                    "mdbn_cd_train_step")
         self._w_planes_written(W)
+        self._w_serial += 1
         if announce is not None and a.ahead_done and self._ahead_flag.value:
-            sc.ahead = announce              # the next call finds its rows in the other X2 buffer
+            sc.ahead = self._ahead_record(announce, W)              # the next call finds its rows ready
         if cache_out is not None:
             del cache_out[:]
             idx = _keep[1]
             if idx is not None and sc.planes is None and not a.W_planes and not self.trace_chain and not sample_stats:
                 dm = _keep[0]
+                if a.B <= 32 and a.ldh <= 512 and not self.keep_f32:
+                    # thin-batch candidates: the cached calls hand the next minibatch to the update kernel (their own flag)
+                    flag = C.c_int32(0)
+                    a.planes_alt, a.x_buffer, a.ahead_done = sc.alt_planes(self, a.ldv).data_ptr(), 0, C.pointer(flag)
                 key = (dm.data_ptr(), dm.shape[0], dm.stride(0), idx.dtype, idx.numel(), self._workspace.data_ptr(), self.keep_f32,
                        self.trace_chain, self._options_epoch, a.rng.seed, a.rng.stream_id,
                        torch._C._cuda_getCurrentRawStream(self.device.index), W.data_ptr(), W_speed.data_ptr(),
@@ -702,6 +739,7 @@ class HipEngine(object):
                                     lambda_1, lambda_2, weightcost, momentum, batch_size, n_rows, cost_scale,
                                     phase, ldv)
         _lib.check(self.lib.mdbn_apply_update(self.ctx, self._stream(), C.byref(u)), "mdbn_apply_update")
+        self._w_serial += 1
         if phase != 1:
             self._w_planes_written(W)
         return cost

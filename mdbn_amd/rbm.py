@@ -343,7 +343,7 @@ class StepFunction(object):
             if len(self._fast) == 8 and idx is not None and staged_slot is None and not self.nan_guard and self._fast[7] == \
                     (batch_size, n_global, rbm.W.tensor.data_ptr(), rbm.hbias.tensor.data_ptr(), rbm.vbias.tensor.data_ptr()):
                 # the argument structs of the previous call (small layers are host-bound: engine.cd_train_step_cached)
-                out = eng.cd_train_step_cached(self._fast, data, idx, step, lr, momentum)
+                out = eng.cd_train_step_cached(self._fast, data, idx, step, lr, momentum, next_indexes)
                 if out is not None:
                     rbm._n_updates += 1
                     return out

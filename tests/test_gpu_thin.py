@@ -147,3 +147,61 @@ def test_thin_training_steps_follow_the_oracle(hip_engine, cls_gauss, hp, fused_
     for name in ("W", "hbias", "vbias", "W_speed", "hbias_speed", "vbias_speed"):
         got, ref = getattr(rbm, name).get_value(), getattr(st, name)
         check("thin training: %s after 4 steps / max" % name, np.abs(got - ref).max() / max(1.0, np.abs(ref).max()), 2e-6, "update")
+
+
+AHEAD = [  # V, H, B, gauss, hyper-parameters
+    (784, 500, 20, False, dict(lr=0.1, weightcost=2e-4)),          # BASELINE configs[0], frozen weight-cost snapshot
+    (19937, 400, 20, True, dict(lr=0.005, lambda_2=0.1)),          # the gene-expression layer
+    (700, 512, 32, True, dict(lr=0.002, lambda_1=0.01, lambda_2=0.05)),   # widest layer at the largest batch (4 rows in flight)
+    (4099, 72, 25, False, dict(lr=0.05)),                          # ragged everything
+    (17, 5, 3, False, dict(lr=0.1)),                               # one workgroup
+]
+
+
+@pytest.mark.parametrize("V,H,B,gauss,hp", AHEAD)
+def test_thin_positive_phase_ahead_is_bit_identical(hip_engine, V, H, B, gauss, hp):
+    """mdbn_cd_args.next_indexes on the thin path: the update kernel of step t also gathers minibatch t + 1 and leaves the
+    partials of its positive phase (thin_update_ahead_kernel).  Same products in the same order as thin_pass_kernel<0>:
+    parameters, speeds and costs must be BIT-identical with and without the hint -- including after a wrong hint, a
+    parameter written from outside between two steps, and a step without a hint in the middle."""
+    import mdbn_amd
+    eng = hip_engine
+    N = 96
+    rs = np.random.RandomState(11)
+    data = rs.normal(size=(N, V)).astype(np.float32) if gauss else (rs.uniform(size=(N, V)) < 0.3).astype(np.float32)
+    cls = mdbn_amd.GRBM if gauss else mdbn_amd.RBM
+    order = [rs.permutation(N)[:B] for _ in range(9)]
+
+    def run(hinted):
+        rbm = cls(n_visible=V, n_hidden=H, numpy_rng=np.random.RandomState(5), theano_rng=mdbn_amd.RandomStreams(3), engine=eng)
+        _, updates = rbm.get_cost_updates(k=1, batch_size=B, **hp)
+        fn = mdbn_amd.function(updates, mdbn_amd.shared(data, engine=eng), data_parallel=None)
+        idx = [eng.index_tensor(o, N) for o in order]
+        costs, taken = [], 0
+        for t in range(8):
+            hint = None
+            if hinted and t != 4:                        # step 4 announces nothing: step 5 gathers for itself
+                hint = idx[t + 1] if t != 2 else idx[0]  # step 2 announces the WRONG minibatch: step 3 must not use it
+            if t == 6:
+                w = rbm.W.get_value()
+                rbm.W.set_value(w * np.float32(0.5))     # parameters written behind the step function's back
+            costs.append(fn(indexes=idx[t], momentum=0.5, next_indexes=hint))
+            sc = eng.last_scratch
+            taken += int(sc.ahead is not None)
+        eng.synchronize()
+        out = {n: getattr(rbm, n).get_value() for n in ("W", "hbias", "vbias", "W_speed", "hbias_speed", "vbias_speed")}
+        out["cost"] = np.array([float(c) for c in costs])
+        return out, taken
+
+    eng.keep_f32 = False                                 # the product default (the fixture keeps the f32 copies for inspection)
+    eng.set_option("small_fused", 0)                     # (an LDS-resident shape would take the one-launch path first)
+    try:
+        plain, n0 = run(False)
+        ahead, n1 = run(True)
+    finally:
+        eng.keep_f32 = True
+        eng.set_option("small_fused", 1)
+    assert n0 == 0
+    assert n1 == 7, "the update kernel prepared %d of the 7 announced minibatches" % n1
+    for name in plain:
+        np.testing.assert_array_equal(ahead[name], plain[name], err_msg=name)
