@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmdbn_hip.so")
-SOURCES = ["mdbn_kernels.hip", "mdbn_planes.hip", "mdbn_small.hip", "mdbn_thin.hip", "mdbn_gchain.hip", "mdbn_capi.hip"]
+SOURCES = ["mdbn_kernels.hip", "mdbn_planes.hip", "mdbn_small.hip", "mdbn_thin.hip", "mdbn_gchain.hip", "mdbn_stream.hip", "mdbn_capi.hip"]
 HEADERS = ["mdbn_kernels.h", "mdbn_device.h", "philox.h", "row_pool.h", "mdbn_small.h", "mdbn_thin.h", "mdbn_gchain.h", "mdbn_bf16x3.h", os.path.join("..", "..", "include", "mdbn_hip.h")]
 HASH_TAG = b"MDBN_SOURCE_HASH_TAG="
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"]

@@ -41,6 +41,10 @@ struct Options {
     int skinny_gemm = 1;
     int skinny_fused_max_k = 1024;
     int64_t skinny_max_macs = 32ll << 20;
+    int stream_x6 = 1;
+    int64_t stream_max_macs = (int64_t)1 << 30;
+    int stream_mi = 0;
+    int stream_ni = 0;
     int gemm_bf16x6 = 3;
     int small_fused = 1;
     int thin_fused = 1;
@@ -178,6 +182,7 @@ struct Plan {
     int tiles_m, tiles_n, splitk, kchunk, bn, bk;
     int skinny = 0;        // skinny_gemm_kernel: tiles_m x tiles_n = (32*mi)-row tiles x 32-column strips
     int mi = 1;
+    int ni = 1;            // streaming bf16x6 kernel: strips per tile
     int cw = 1;            // MFMA (consumer) waves per SIMD of the tiled kernel
     int x6 = 0;            // statistics GEMM on the bf16 pipe (stats_bf16x6_kernel)
     int64_t slab_floats(int64_t M, int64_t ldc) const { return (int64_t)splitk * M * ldc; }
@@ -185,7 +190,7 @@ struct Plan {
     {
         g.kchunk = kchunk; g.splitk = splitk; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.bn = bn; g.bk = bk;
         g.inner_m = tiles_m <= tiles_n;
-        g.skinny = skinny; g.mi = mi; g.fused = 0; g.cw = cw; g.fin_enabled = 0; g.x6 = x6; g.x6_pw = g_opt_x6_pw;
+        g.skinny = skinny; g.mi = mi; g.ni = ni; g.fused = 0; g.cw = cw; g.fin_enabled = 0; g.x6 = x6; g.x6_pw = g_opt_x6_pw;
     }
 };
 
@@ -341,19 +346,59 @@ bool try_bf16x6(Plan& p, int64_t M, int64_t N, int64_t K, bool unsplit = false)
     return true;
 }
 
-// Plan of one forward pass (x[M, K] * op(W) -> [M, N], `ldo` columns stored).
-Plan plan_forward(int64_t M, int64_t N, int64_t K, int64_t ldo)
+// mdbn_set_option("stream_x6") (default 1): mid-size passes at more than 64 rows -- too small for 128 x 128 tiles without a
+// split-K + slab + epilogue-launch round trip -- run UNSPLIT on 32 x 32 (64 x 32) tiles of the register-streaming kernel on
+// the bf16 matrix pipe (mdbn_stream.hip: f32 operands split in registers, six / three piece products, fused epilogue): one
+// launch per pass.  2: the small-layer passes prefer_skinny() sends to the exact-f32 streaming kernel use it as well.
+// "stream_max_macs": largest M * N * K served; "stream_mi": 0 = auto, 1 | 2 = 32-row blocks per tile.
+#define g_opt_stream_x6 (t_opt->stream_x6)
+#define g_opt_stream_max_macs (t_opt->stream_max_macs)
+#define g_opt_stream_mi (t_opt->stream_mi)
+#define g_opt_stream_ni (t_opt->stream_ni)
+constexpr int64_t kStreamMinTiles = 192;
+
+bool stream_ok(int64_t M, int64_t N, int64_t K)
 {
-    if (prefer_skinny(M, N, K)) return plan_skinny(M, K, ldo, M <= 64);
+    return g_opt_stream_x6 && M > 64 && K >= 64 && M * N * K <= g_opt_stream_max_macs;
+}
+
+Plan plan_stream(int64_t M, int64_t K, int64_t ldo)
+{
+    Plan p = plan_skinny(M, K, ldo, false);          // one K range: the epilogue runs on the tile
+    // the largest tile that still leaves about one workgroup per CU: a 64 x 64 tile moves half the operand bytes of four
+    // 32 x 32 ones through L2 and splits every fragment once for two products
+    const int64_t tiles32 = ((M + 31) / 32) * ((ldo + 31) / 32);
+    p.mi = tiles32 >= 2 * kStreamMinTiles ? 2 : 1;
+    p.ni = tiles32 >= 4 * kStreamMinTiles ? 2 : 1;
+    if (g_opt_stream_mi) p.mi = g_opt_stream_mi;
+    if (g_opt_stream_ni) p.ni = g_opt_stream_ni;
+    p.tiles_m = (int)((M + 32 * p.mi - 1) / (32 * p.mi));
+    p.x6 = 1;
+    return p;
+}
+
+// Plan of one forward pass (x[M, K] * op(W) -> [M, N], `ldo` columns stored).
+// stream = false: the plan of the LDS-tiled kernels whatever the streaming option says (the plane path runs on their tiling)
+Plan plan_forward(int64_t M, int64_t N, int64_t K, int64_t ldo, bool stream = true)
+{
+    if (prefer_skinny(M, N, K)) {
+        if (stream && g_opt_stream_x6 >= 2 && stream_ok(M, N, K)) return plan_stream(M, K, ldo);
+        return plan_skinny(M, K, ldo, M <= 64);
+    }
+    if (stream && stream_ok(M, N, K)) return plan_stream(M, K, ldo);
     Plan p = plan_gemm(M, N, K);
     if (g_opt_gemm_bf16x6 & 2) try_bf16x6(p, M, N, K);
     return p;
 }
 
 // Plan of the statistics GEMM S[V, H] = V2^T P2 over K = 2B.
-Plan plan_stats(int64_t V, int64_t H, int64_t K2, int64_t ldh)
+Plan plan_stats(int64_t V, int64_t H, int64_t K2, int64_t ldh, bool stream = true)
 {
-    if (prefer_skinny(V, H, K2) && V > 64) return plan_skinny(V, K2, ldh, false);
+    if (prefer_skinny(V, H, K2) && V > 64) {
+        if (stream && g_opt_stream_x6 >= 2 && stream_ok(V, H, K2)) return plan_stream(V, K2, ldh);
+        return plan_skinny(V, K2, ldh, false);
+    }
+    if (stream && stream_ok(V, H, K2)) return plan_stream(V, K2, ldh);
     Plan p = plan_gemm(V, H, K2);
     if (g_opt_gemm_bf16x6 & 1) try_bf16x6(p, V, H, K2, p.splitk == 1);     // unsplit stays unsplit (fused epilogues)
     return p;
@@ -378,7 +423,7 @@ hipError_t timed_gemm(int la, int lb, const GemmArgs& g_in, hipStream_t s)
         // kind = 100 * pipe (0 exact-f32 MFMA, 1 bf16 pipe with 6 products, 2 bf16 pipe with 3) + 10 * fused
         //        + 2 * la + lb; (la, lb) = (K, MN) propup, (K, K) propdown, (MN, MN) statistics
         const double alg = 2.0 * (double)g.M * (double)g.N * (double)g.K;
-        const int pipe = g.skinny ? 0 : g.x6;
+        const int pipe = g.x6;
         GemmTiming::Meta m{100 * pipe + 10 * g.fused + 2 * la + lb + (g.skinny ? 1000 : 0), alg,
                            alg * (pipe == 1 ? 6.0 : pipe == 2 ? 3.0 : 1.0)};
         if (g_timing.meta.size() <= g_timing.used) g_timing.meta.resize(g_timing.used + 1);
@@ -465,7 +510,7 @@ static WsSizes ws_sizes_dense(int64_t B, int64_t V, int64_t H)
     s.cost = std::max<int64_t>(256, (((B + 3) / 4) * std::max(ldv, ldh) + 63) / 64) + 64;   // worst case: one column per thread, 64-thread blocks
     // fused epilogues write one partial per block: 128 x 64 tiles, or 32-column strips (skinny)
     s.cost = std::max<int64_t>(s.cost, ((B + 127) / 128) * ((std::max(ldv, ldh) + 63) / 64) + 64);
-    s.cost = std::max<int64_t>(s.cost, ((B + 63) / 64) * ((std::max(ldv, ldh) + 31) / 32) + 64);
+    s.cost = std::max<int64_t>(s.cost, ((B + 31) / 32) * ((std::max(ldv, ldh) + 31) / 32) + 64);
     if (small_shape_ok(B, V, H, 0) || small_shape_ok(B, V, H, 1)) s.cost = std::max<int64_t>(s.cost, (int64_t)small_blocks(B) * SM_NW + 64);   // a cost partial per wave
     s.cost = std::max<int64_t>(s.cost, thin_cost + 64);
     s.cost = std::max<int64_t>(s.cost, gc_cost + 64);
@@ -670,8 +715,8 @@ bool plane_shape_ok(int64_t B, int64_t V, int64_t H, int64_t ldv, int64_t ldh)
     if (B <= 0 || B % 128 || V % 128 || ldh % 128 || ldv != V || H > ldh || ldh - H >= 128 || B > 65535) return false;
     const int64_t He = ldh;
     if (g_opt_planes_min_work > 0 && (B * V * He < g_opt_planes_min_work || V * He < ((int64_t)1 << 21))) return false;
-    return plane_plan(plan_forward(B, He, V, He), B, He, V) && plane_plan(plan_forward(B, V, He, V), B, V, He) &&
-           plane_plan(plan_stats(V, He, 2 * B, He), V, He, 2 * B);
+    return plane_plan(plan_forward(B, He, V, He, false), B, He, V) && plane_plan(plan_forward(B, V, He, V, false), B, V, He) &&
+           plane_plan(plan_stats(V, He, 2 * B, He, false), V, He, 2 * B);
 }
 
 bool planes_eligible(const mdbn_cd_args* a)
@@ -717,7 +762,7 @@ int run_affine_planes(mdbn_ctx* ctx, int comm_cus, const unsigned short* A, int6
     g.M = (int)rows; g.N = (int)Ndim; g.K = (int)Kdim;
     g.tiles_m = (int)(rows / 128); g.tiles_n = (int)(Ndim / 128);
     {
-        const Plan p = plan_forward(rows, Ndim, Kdim, e.ld);        // eligibility checked that this is a whole-tile x6 plan
+        const Plan p = plan_forward(rows, Ndim, Kdim, e.ld, false);        // eligibility checked that this is a whole-tile x6 plan
         g.splitk = p.splitk; g.kchunk = p.kchunk;
     }
     // data-parallel mode: P workgroups share tiles x stages evenly; a tile's segments land in slabs, the epilogue launch
@@ -877,7 +922,7 @@ int cd_step_planes(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, const md
     float* s_v = s_h + ldh;
     float* cost = s_v + ldv;
     // S = [v0; nv]^T [ph; -nh]: one GEMM over the stacked batch dimension, both operands used transposed
-    const Plan sp = plan_stats(V, H, 2 * B, ldh);
+    const Plan sp = plan_stats(V, H, 2 * B, ldh, false);
     PlaneGemmArgs g{};
     g.A = pb.Xp; g.lda = ldv; g.pa = pb.px; g.ap = 3;
     g.B = pb.Pp; g.ldb = ldh; g.pb = pb.pp;
@@ -1113,6 +1158,24 @@ int mdbn_set_option(mdbn_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "gemm_cw") == 0) {
         if (value < 0 || value > 2) return fail(MDBN_EINVAL, "gemm_cw must be 0 (auto), 1 or 2");
         ctx->opt.gemm_cw = (int)value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "stream_x6") == 0) {
+        ctx->opt.stream_x6 = (int)value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "stream_max_macs") == 0) {
+        ctx->opt.stream_max_macs = value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "stream_mi") == 0) {
+        REQUIRE(value == 0 || value == 1 || value == 2, "stream_mi must be 0, 1 or 2");
+        ctx->opt.stream_mi = (int)value;
+        return MDBN_OK;
+    }
+    if (strcmp(name, "stream_ni") == 0) {
+        REQUIRE(value == 0 || value == 1 || value == 2, "stream_ni must be 0, 1 or 2");
+        ctx->opt.stream_ni = (int)value;
         return MDBN_OK;
     }
     if (strcmp(name, "skinny_max_macs") == 0) {
@@ -1715,6 +1778,7 @@ static int cd_step_thin(mdbn_ctx* ctx, hipStream_t s, const mdbn_cd_args* a, con
         p.W = a->W; p.part = ws.slabs;
         p.data = a->data; p.n_data = a->n_data; p.ld_data = ldv; p.idx = a->indexes; p.idx64 = a->index_is_64; p.v0_out = v0;
         p.vbias = a->vbias; p.gauss = a->gauss;
+        p.stamps = g_stamps;
         // x = train_set_x[indexes] and the partials of x W                      (dbn.py:307, rbm.py:303)
         if (!ahead_in) HIP_OK(launch_thin_pass(0, p, tg, s));
         ThinActArgs act{};

@@ -341,21 +341,27 @@ __device__ __forceinline__ void store_planes4(unsigned short* P, int64_t plane_s
 }
 
 // MODE >= 0: e.gauss (bit 1) and "a sample is wanted" (bit 0) as compile-time facts; act_quad_dispatch branches once.
-template <int MODE = -1>
-__device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, float x2, float x3, int r0, int col, bool live, float& cost)
+// the cost targets of a quad's four rows (index -> row: two dependent loads each), for a caller that wants them in flight
+// before the pre-activations exist
+__device__ __forceinline__ void act_quad_targets(const EpiArgs& e, int r0, int col, bool live, float (&tg4)[4])
 {
-    const bool is_gauss = MODE < 0 ? e.gauss != 0 : (MODE & 2) != 0;
-    const bool need_u = MODE < 0 ? (e.sample != nullptr || e.sample_plane != nullptr) : (MODE & 1) != 0;
-    const bool need_z = need_u && is_gauss;
-    // the cost targets of the four rows (index -> row: two dependent loads each) requested first, under the Philox rounds --
-    // loaded row by row inside the loop below they were eight memory round trips in a row
-    float tg4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tg4[j] = 0.f;
     if (e.target && live) {
         int64_t srow[4];
         epi_target_rows4(e, r0, srow);
 #pragma unroll
         for (int j = 0; j < 4; ++j) tg4[j] = e.target[srow[j] * e.ld_target + col];
     }
+}
+
+template <int MODE = -1>
+__device__ __forceinline__ void act_quad_tg(const EpiArgs& e, float x0, float x1, float x2, float x3, int r0, int col, bool live, float& cost,
+                                            const float (&tg4)[4])
+{
+    const bool is_gauss = MODE < 0 ? e.gauss != 0 : (MODE & 2) != 0;
+    const bool need_u = MODE < 0 ? (e.sample != nullptr || e.sample_plane != nullptr) : (MODE & 1) != 0;
+    const bool need_z = need_u && is_gauss;
     uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
     if (need_u) {
         const uint64_t g0 = e.rng.row_offset + (uint64_t)r0;
@@ -401,6 +407,16 @@ __device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, f
         }
     }
     if (e.colsum) e.colsum[(int64_t)(r0 >> 2) * e.ld + col] = csum;
+}
+
+template <int MODE = -1>
+__device__ __forceinline__ void act_quad(const EpiArgs& e, float x0, float x1, float x2, float x3, int r0, int col, bool live, float& cost)
+{
+    // the targets requested first, under the Philox rounds -- loaded row by row inside the loop they were eight memory
+    // round trips in a row
+    float tg4[4];
+    act_quad_targets(e, r0, col, live, tg4);
+    act_quad_tg<MODE>(e, x0, x1, x2, x3, r0, col, live, cost, tg4);
 }
 
 // cost_slot: index of this tile's cost partial (default: the block index; a kernel whose reducer blocks are a

@@ -110,6 +110,7 @@ struct GemmArgs {
     int skinny;            // 1: skinny_gemm_kernel (tiles_n = 32-column strips, tiles_m = (32*mi)-row tiles,
                            //    splitk = K ranges, kchunk % 8 == 0)
     int mi;                // skinny: 32-row blocks per tile (1 | 2)
+    int ni;                // streaming bf16x6 kernel (skinny = 1, x6 != 0): 32-column strips per tile (1 | 2)
     int fused;             // no split-K and an epilogue runs on the block's own output tile:
                            //   1 = activation (epi), 2 = parameter update (upd; statistics GEMM, C is not written)
     EpiArgs epi;           // fused == 1 (slabs / nsplit unused; one cost partial per block)

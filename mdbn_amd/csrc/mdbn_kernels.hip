@@ -16,10 +16,10 @@
 #include "philox.h"
 #include "mdbn_kernels.h"
 #include "mdbn_device.h"
+#include "mdbn_skinny.h"
 
 namespace mdbn {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int NTHREADS = 256;            // threads of one role (4 producer waves / 4 consumer waves)
 // KB = slice depth along the reduction index (32 or 64); a K-contiguous LDS tile is [rows][KB + 1]
@@ -338,14 +338,6 @@ __device__ __forceinline__ void gemm_consume(const GemmArgs& g, const float* __r
 // CW: consumer (MFMA) waves per SIMD.  1: four consumers with a 2x2 grid of (32*MI)x(32*NI) wave tiles.
 // 2: eight consumers, 2x4 grid of (32*MI)x(16*NI) wave tiles -- the two MFMA waves of a SIMD cover each
 // other's LDS-return stalls (needs NI == 2; unfused kernels only).
-// The kernel arguments a GEMM kernel needs before its first global access, requested in ONE batch at the top: hipcc loads
-// kernarg fields where they are first used, which put two to four scalar-load round trips in a row at the head of every
-// launch (plane GEMMs: same-box 143.3 -> 141.6 us per headline step, profiles/r04zy_args_early_ab.log).
-#define MDBN_GEMM_ARGS_EARLY(G)                                                                                         \
-    asm volatile("" :: "s"((G).A), "s"((G).B), "s"((G).C), "s"((G).lda), "s"((G).ldb), "s"((G).ldc), "s"((G).slab_stride),   \
-                 "s"((G).M), "s"((G).N), "s"((G).K), "s"((G).Nst), "s"((G).kchunk), "s"((G).splitk), "s"((G).tiles_m),       \
-                 "s"((G).tiles_n), "s"((int)gridDim.x))
-
 template <int LA, int LB, int MI, int NI, int KB, int FUSED, int CW>
 __global__ __launch_bounds__(64 * (4 * CW + 4)) void gemm_splitk_kernel(GemmArgs g)
 {
@@ -897,8 +889,11 @@ hipError_t launch_gemm_bf16x6(int la, int lb, const GemmArgs& g, hipStream_t s)
 
 hipError_t launch_skinny_gemm(int la, int lb, const GemmArgs& g, hipStream_t s);
 
+hipError_t launch_stream_gemm(int la, int lb, const GemmArgs& g, hipStream_t s);     // mdbn_stream.hip
+
 hipError_t launch_gemm(int la, int lb, const GemmArgs& g, hipStream_t s)
 {
+    if (g.skinny && g.x6) return launch_stream_gemm(la, lb, g, s);
     if (g.x6) return launch_gemm_bf16x6(la, lb, g, s);
     if (g.skinny) return launch_skinny_gemm(la, lb, g, s);
     if (g.fused) {      // forward passes fuse the activation, the statistics GEMM the update (separate
@@ -936,7 +931,7 @@ hipError_t launch_gemm(int la, int lb, const GemmArgs& g, hipStream_t s)
 // clamped (valid) address: they only reach accumulator rows / columns that are never stored.  The
 // K tail is zero-filled in both operands.
 // ----------------------------------------------------------------------------------
-constexpr int SKINNY_WAVES = 8, SKINNY_LDT = 33, SKINNY_U = 4;
+constexpr int SKINNY_U = 4;
 
 template <int MI>
 struct SkinnyRegs {
@@ -1050,82 +1045,7 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmArgs
 #undef SKINNY_LOAD
 #undef SKINNY_MMA
 
-    // park the partial accumulators, reduce over the waves in wave order
-    float* T = smem + wave * (BM * LDT);
-#pragma unroll
-    for (int a = 0; a < MI; ++a)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-            T[(32 * a + (e & 3) + 8 * (e >> 2) + 4 * h) * LDT + i] = acc[a][e];
-    __syncthreads();
-
-    const int q = threadIdx.x;                 // quad = (row group, column) of the tile
-    const int rg = q >> 5, c = q & 31;
-    const int col = n0 + c;
-    float cost = 0.f;
-    if (rg < BM / 4) {
-        float x[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) sum += smem[w * (BM * LDT) + (4 * rg + j) * LDT + c];
-            x[j] = sum;
-        }
-        const int r0w = m0 + 4 * rg;
-        if constexpr (FUSED == 1) {
-            const EpiArgs& e = g.epi;
-            const bool live = col < e.cols;
-            if (r0w < e.rows && col < (int)e.ld) {
-                const float bias = live ? e.bias[col] : 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) x[j] += bias;
-                act_quad(e, x[0], x[1], x[2], x[3], r0w, col, live, cost);
-            }
-        } else if constexpr (FUSED == 2) {
-            const UpdEpi& u = g.upd;
-            if (r0w < u.rows && col < (int)u.ld) {
-                float wv[4], sv[4], w0v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool ok = r0w + j < u.rows;
-                    const int64_t off = (int64_t)(ok ? r0w + j : r0w) * u.ld + col;
-                    wv[j] = u.W[off];
-                    sv[j] = u.Ws[off];
-                    w0v[j] = u.W0 ? u.W0[off] : wv[j];
-                    if (col >= g.N) x[j] = 0.f;            // pad columns: S is exactly zero there
-                }
-                float4 wn, sn;
-                update_rule4(make_float4(wv[0], wv[1], wv[2], wv[3]), make_float4(sv[0], sv[1], sv[2], sv[3]),
-                             make_float4(x[0], x[1], x[2], x[3]), make_float4(w0v[0], w0v[1], w0v[2], w0v[3]),
-                             u.inv_bs, u.wc, upd_decay(u.lr, u.l2), u.l1, upd_two_lr_l1(u.lr, u.l1), u.mu, u.lr, wn, sn);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (r0w + j < u.rows) {
-                        const int64_t off = (int64_t)(r0w + j) * u.ld + col;
-                        u.W[off] = comp(wn, j);
-                        u.Ws[off] = comp(sn, j);
-                        if (u.Wp) {
-                            unsigned short p1, p2, p3;
-                            split3(comp(wn, j), p1, p2, p3);
-                            u.Wp[off] = p1; u.Wp[u.wp_stride + off] = p2; u.Wp[2 * u.wp_stride + off] = p3;
-                        }
-                    }
-            }
-        } else {
-            float* C = g.C + (int64_t)ks * g.slab_stride;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (r0w + j < g.M && col < g.Nst) C[(int64_t)(r0w + j) * g.ldc + col] = col < g.N ? x[j] : 0.f;
-        }
-    }
-    if constexpr (FUSED == 1) {
-        if (g.epi.cost_partials) {
-            __syncthreads();
-            const float tot = block_sum(cost, smem);
-            if (threadIdx.x == 0) g.epi.cost_partials[blockIdx.x] = tot;
-        }
-    }
+    skinny_tile_epilogue<MI, FUSED, false>(g, acc, smem, ks, m0, n0, (int)blockIdx.x);
 }
 
 template <int LA, int LB, int MI, int FUSED>

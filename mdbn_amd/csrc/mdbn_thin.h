@@ -81,6 +81,7 @@ __host__ __device__ inline bool thin_geom(int64_t B, int64_t V, int64_t H, int64
 // v1 = act(h W^T + vbias) COMPLETE (it holds whole rows of W), applies the visible activation, and at once the partial
 // sums of v1 W from the same rows in LDS: W is read from HBM once for both products.
 struct ThinPassArgs {
+    unsigned long long* stamps;             // diagnostic builds only (-DMDBN_STAMP): 16 wall-clock stamps per workgroup; else NULL
     int B, Bq, V, H;
     int64_t ldv, ldh;
     int G, rpw, PW;

@@ -57,9 +57,16 @@ __device__ __forceinline__ int64_t thin_src_row(const void* idx, int idx64, int6
 // MODE 0: x is gathered and split into xP once; W streams from global memory straight into the fragments (eight
 //   global_load_dword per lane and 16-row step, two steps in flight), no LDS image of W, no barrier in the loop.
 // ------------------------------------------------------------------------------------------------------------------
+#ifdef MDBN_STAMP   // diagnostic builds (scripts/experiments/thin_stamps.py): wall-clock stamps of every workgroup's phases
+#define TH_STAMP(SLOT) do { if (MODE == 1 && a.stamps && threadIdx.x == 0) a.stamps[(int64_t)blockIdx.x * 16 + (SLOT)] = wall_clock64(); } while (0)
+#else
+#define TH_STAMP(SLOT) do {} while (0)
+#endif
+
 template <int MODE, int NT2, int XP>
 __global__ __launch_bounds__(TH_NT) void thin_pass_kernel(ThinPassArgs a)
 {
+    TH_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Bq = a.Bq, PW = a.PW;
     const int q4 = (int)(a.ldh >> 2);
@@ -135,6 +142,7 @@ __global__ __launch_bounds__(TH_NT) void thin_pass_kernel(ThinPassArgs a)
                 }
             }
         }
+        TH_STAMP(1);
 #pragma unroll
         for (int u = 0; u < HKN; ++u) {         // (bf16 image: the upper halves of the 0/1 floats)
             const int e = tid + TH_NT * u;
@@ -146,7 +154,9 @@ __global__ __launch_bounds__(TH_NT) void thin_pass_kernel(ThinPassArgs a)
                 *reinterpret_cast<uint2*>(hKb + b * PH + 4 * c4) = w;
             }
         }
+        TH_STAMP(2);
         __syncthreads();
+        TH_STAMP(3);
 
         // ---- phase 1: v1_pre[b][i] = sum_j h[b][j] W[r0 + i][j]: work item = (32-row tile of the block, K share)
         f32x16 acc1;
@@ -168,6 +178,7 @@ __global__ __launch_bounds__(TH_NT) void thin_pass_kernel(ThinPassArgs a)
                 th_mma<1>(acc1, fa, fb);
             }
         }
+        TH_STAMP(4);
         __syncthreads();                        // every wave is done reading hKb: red may overwrite it
         if (has1) {
 #pragma unroll
@@ -177,6 +188,7 @@ __global__ __launch_bounds__(TH_NT) void thin_pass_kernel(ThinPassArgs a)
             }
         }
         __syncthreads();
+        TH_STAMP(5);
         // ---- visible activation: thread = 4 rows x 1 column (one Philox block), rbm.py:226-240 / :650-658
         for (int e = tid; e < R32 * (Bq >> 2); e += TH_NT) {
             const int i = e % R32, bq = e / R32;
@@ -222,7 +234,9 @@ __global__ __launch_bounds__(TH_NT) void thin_pass_kernel(ThinPassArgs a)
                 }
             }
         }
+        TH_STAMP(6);
         __syncthreads();
+        TH_STAMP(7);
     } else {
         // ---- MODE 0: (the gather of x and the first steps of W are requested together: below)
     }
@@ -346,6 +360,7 @@ __global__ __launch_bounds__(TH_NT) void thin_pass_kernel(ThinPassArgs a)
         __syncthreads();
     }
 
+    TH_STAMP(8);
     // the workgroup's partial of the upward product: rows 0 .. Bq - 1 (rows >= B are exact zeros)
 #pragma unroll
     for (int t = 0; t < NT2; ++t) {
@@ -364,11 +379,13 @@ __global__ __launch_bounds__(TH_NT) void thin_pass_kernel(ThinPassArgs a)
             a.v0_out[b * a.ldv + a.V + c] = 0.f;
         }
     }
+    TH_STAMP(9);
     if (MODE == 1 && a.cost_partials) {
         __syncthreads();
         const float tot = block_sum(cost, red);
         if (tid == 0) a.cost_partials[g] = tot;
     }
+    TH_STAMP(10);
 }
 
 template <int MODE, int NT2, int XP>

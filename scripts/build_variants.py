@@ -4,7 +4,8 @@ shape; MDBN_AB_SHAPE="V,H,B,k,gauss" selects another, as scripts/step_ab.py).
     python scripts/build_variants.py "-DX6_SCHED=0" "-DX6_SCHED=1" ..."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = [os.path.join(ROOT, "mdbn_amd", "csrc", f) for f in ("mdbn_kernels.hip", "mdbn_planes.hip", "mdbn_small.hip", "mdbn_thin.hip", "mdbn_gchain.hip", "mdbn_capi.hip")]
+src = [os.path.join(ROOT, "mdbn_amd", "csrc", f) for f in ("mdbn_kernels.hip", "mdbn_planes.hip", "mdbn_small.hip", "mdbn_thin.hip", "mdbn_gchain.hip", "mdbn_stream.hip", "mdbn_capi.hip")]
+src = sorted(os.path.join(ROOT, "mdbn_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "mdbn_amd", "csrc")) if f.endswith(".hip"))
 out = os.path.join(ROOT, "gpurun_out"); os.makedirs(out, exist_ok=True)
 for i, flags in enumerate(sys.argv[1:]):
     so = os.path.join(out, "libmdbn_var%d.so" % i)
@@ -47,4 +48,7 @@ eng.kernel_timing(False)
 print("%%-40s median %%.1f us/step   cost %%.6f   %%s" %% (%r, np.median(ts), float(c),
       ", ".join("kind %%d: %%.1f us" %% (k, 1e3 * np.mean(t)) for k, t in sorted(groups.items()))), flush=True)
 ''' % (ROOT, so, flags)
-    subprocess.check_call([sys.executable, "-c", prog])
+    # MDBN_AB_SHAPES="V,H,B,k,gauss;V,H,B,k,gauss;..." times several layers with one build
+    for shape in os.environ.get("MDBN_AB_SHAPES", os.environ.get("MDBN_AB_SHAPE", "4096,1024,512,1,1")).split(";"):
+        print(shape, end="  ", flush=True)
+        subprocess.check_call([sys.executable, "-c", prog], env=dict(os.environ, MDBN_AB_SHAPE=shape))

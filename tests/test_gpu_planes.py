@@ -68,6 +68,7 @@ def _run_steps(eng, gauss, planes, V, H, B, k, steps=3, seed=0, mfma=16):
     import mdbn_amd
     eng.set_option("gemm_planes", int(planes))
     eng.set_option("planes_mfma", mfma)
+    eng.set_option("stream_x6", 0)      # (the f32-operand side of these comparisons: the LDS-tiled kernels whose plans the planes follow)
     if planes:          # a shape the library does not serve on planes would compare the f32-operand path with itself
         assert eng.plane_shape(B, V, H, V, H), "test shape is not on the plane path: %r" % ((B, V, H),)
     keep, eng.keep_f32 = eng.keep_f32, bool(seed & 1)        # the product default (no float32 copies) on even seeds
@@ -85,6 +86,7 @@ def _run_steps(eng, gauss, planes, V, H, B, k, steps=3, seed=0, mfma=16):
     wp, valid = eng.w_planes(rbm.W.tensor)
     eng.set_option("gemm_planes", 1)
     eng.set_option("planes_mfma", 16)
+    eng.set_option("stream_x6", 1)
     eng.keep_f32 = keep
     return out, rbm, wp, valid
 
