@@ -178,12 +178,12 @@ int  mdbn_ctx_destroy(mdbn_ctx *ctx);
  * "skinny_gemm" (default 1): GEMMs of <= 64 output rows, and tiny GEMMs at any row count, use the
  *   register-streaming kernel (no LDS staging); "skinny_fused_max_k" (default 1024) largest K one
  *   block streams alone, "skinny_max_macs" (default 32 Mi) size limit above 64 rows.
- * "stream_x6" (default 1): mid-size passes at more than 64 rows (M * N * K <= "stream_max_macs", default 2^30: the
+ * "stream_x6" (default 2): mid-size passes at more than 64 rows (M * N * K <= "stream_max_macs", default 2^30: the
  *   layers 1024 -> 256 and 2048 -> 400 of BASELINE configs 4 / 5 at B = 512) run UNSPLIT on 32 x 32 / 64 x 32 tiles of the
  *   register-streaming kernel on the bf16 matrix pipe (f32 operands split in registers into their three exact bf16
  *   pieces; six piece products, three when the row operand holds 0/1 samples) with the activation / update epilogue on
  *   the tile: one launch per pass instead of split-K GEMM + slabs + epilogue launch.  2: the small-layer passes of
- *   "skinny_gemm" above 64 rows too; 0: off.  "stream_mi": 0 = auto, 1 | 2 = 32-row blocks per tile.
+ *   "skinny_gemm" above 64 rows too; 1: only the passes the LDS-tiled kernels served; 0: off.  "stream_mi": 0 = auto, 1 | 2 = 32-row blocks per tile.
  * "gemm_planes" (default 1): use the bf16 plane path of mdbn_cd_args when its buffers are given and the
  *   shape qualifies.  "planes_mfma" (default 16): its MFMA shape, 16 = v_mfma_f32_16x16x32_bf16, 32 =
  *   v_mfma_f32_32x32x16_bf16 (bit-identical to the f32-operand path). 

@@ -41,7 +41,7 @@ struct Options {
     int skinny_gemm = 1;
     int skinny_fused_max_k = 1024;
     int64_t skinny_max_macs = 32ll << 20;
-    int stream_x6 = 1;
+    int stream_x6 = 2;
     int64_t stream_max_macs = (int64_t)1 << 30;
     int stream_mi = 0;
     int stream_ni = 0;
@@ -172,7 +172,8 @@ inline int64_t ru4(int64_t x) { return (x + 3) & ~int64_t(3); }
 // Leading-dimension policy (mdbn_padded_ld).  Padding 1-KiB-multiple rows by 64 floats (to spread
 // a GEMM slice's rows over the L2 channels) gained ~10% in the isolated GEMM microbenchmark
 // (scripts/gemm_ldpad.py) but LOST 2% on the whole CD step (K1 42.3 vs 40.6 us, update 17.0 vs
-// 13.5 us, profiles r01e vs r01d), so the policy is plain round_up(cols, 4); every entry point
+// 13.5 us, profiles r01e vs r01d), and does nothing for the streaming kernel of the mid-size layers either
+// (profiles/r05zc_ldpad.log), so the policy is plain round_up(cols, 4); every entry point
 // accepts any ld % 4 == 0, ld >= cols.
 inline int64_t padded_ld(int64_t cols) { return ru4(cols); }
 inline int64_t ru64(int64_t x) { return (x + 63) & ~int64_t(63); }
@@ -346,10 +347,12 @@ bool try_bf16x6(Plan& p, int64_t M, int64_t N, int64_t K, bool unsplit = false)
     return true;
 }
 
-// mdbn_set_option("stream_x6") (default 1): mid-size passes at more than 64 rows -- too small for 128 x 128 tiles without a
+// mdbn_set_option("stream_x6") (default 2): mid-size passes at more than 64 rows -- too small for 128 x 128 tiles without a
 // split-K + slab + epilogue-launch round trip -- run UNSPLIT on 32 x 32 (64 x 32) tiles of the register-streaming kernel on
 // the bf16 matrix pipe (mdbn_stream.hip: f32 operands split in registers, six / three piece products, fused epilogue): one
-// launch per pass.  2: the small-layer passes prefer_skinny() sends to the exact-f32 streaming kernel use it as well.
+// launch per pass.  2: the small-layer passes prefer_skinny() sends to the exact-f32 streaming kernel use it as well
+// (256 -> 200 at B = 512: CD-1 37.9 -> 30.1 us, CD-5 100.1 -> 71.6: profiles/r05za_configs_ab.log); 1: only the passes
+// the LDS-tiled kernels served.
 // "stream_max_macs": largest M * N * K served; "stream_mi": 0 = auto, 1 | 2 = 32-row blocks per tile.
 #define g_opt_stream_x6 (t_opt->stream_x6)
 #define g_opt_stream_max_macs (t_opt->stream_max_macs)
@@ -1940,6 +1943,9 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
     if (mode != 2 && !use_gchain) {
 
     // x = train_set_x[indexes]                                        (dbn.py:307)
+    // (its own launch: read through the index list inside the first propup of the streaming kernel, the rows come from HBM
+    //  at HBM latency into every workgroup's operand stream -- bit-identical and 3 - 10 us per step SLOWER,
+    //  profiles/r05zi_stream_gather_ab.log)
     HIP_OK(launch_gather(a->data, a->n_data, ldv, ldv, a->indexes, a->index_is_64, B, v0, ldv, s));
 
     // positive phase: ph_mean, ph_sample                              (rbm.py:303)

@@ -23,6 +23,12 @@ constexpr int SKINNY_WAVES = 8, SKINNY_LDT = 33;
 // FUSED 0: split-K slab / plain C; 1: bias + activation + sampling (act_quad); 2: the parameter update (statistics GEMM,
 // update_rule4).  smem: [SKINNY_WAVES][32 MI][SKINNY_LDT] floats (+ 8).  slot: where a FUSED 1 launch with a cost target
 // leaves this tile's cost partial.
+#ifdef MDBN_STAMP   // diagnostic builds: the epilogue's own phases, slots 8.. of the workgroup's 16 (stream_stamps.py)
+#define SK_STAMP(SLOT) do { if (HOIST && g.stamps && threadIdx.x == 0 && n0 == sk_first_n0) g.stamps[(int64_t)blockIdx.x * 16 + (SLOT)] = wall_clock64(); } while (0)
+#else
+#define SK_STAMP(SLOT) do {} while (0)
+#endif
+
 template <int MI, int FUSED, bool HOIST>
 __device__ __forceinline__ void skinny_tile_epilogue(const GemmArgs& g, const f32x16 (&acc)[MI], float* smem, int ks, int m0, int n0, int slot)
 {
@@ -38,7 +44,7 @@ __device__ __forceinline__ void skinny_tile_epilogue(const GemmArgs& g, const f3
     // tiles and the barrier instead of behind them (streaming bf16x6 kernel: -1 .. -3 us per step; the exact-f32 kernel of
     // the small layers loses 3.6 us per CD-5 step at 256 -> 200 with it: profiles/r05y_stream_variants.log)
     float bias = 0.f, tg4[4] = {0.f, 0.f, 0.f, 0.f};
-    float wv[4], sv[4], w0v[4];
+    float wv[4] = {}, sv[4] = {}, w0v[4] = {};
     bool on = false;
     auto request = [&]() {
     if constexpr (FUSED == 1) {
@@ -64,6 +70,10 @@ __device__ __forceinline__ void skinny_tile_epilogue(const GemmArgs& g, const f3
         }
     }
     };
+#ifdef MDBN_STAMP
+    const int sk_first_n0 = g.stamps ? (int)g.stamps[(int64_t)blockIdx.x * 16 + 7] : -1;     // (set by the kernel: strip 0's n0)
+#endif
+    SK_STAMP(8);
     if (HOIST) request();
 
     // park the partial accumulators, reduce over the waves in wave order
@@ -73,8 +83,21 @@ __device__ __forceinline__ void skinny_tile_epilogue(const GemmArgs& g, const f3
 #pragma unroll
         for (int e = 0; e < 16; ++e)
             T[(32 * a + (e & 3) + 8 * (e >> 2) + 4 * h) * LDT + i] = acc[a][e];
+    SK_STAMP(9);
     __syncthreads();
+    SK_STAMP(10);
     if (!HOIST) request();
+    if (HOIST) {
+        // (complete here -- the barrier waited for them -- but hipcc does not carry that across the per-row branches below
+        // and would wait for ALL memory operations, the previous row's stores included, before every row: see
+        // stream_tile_epilogue2)
+        asm volatile("" : "+v"(bias));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            asm volatile("" : "+v"(tg4[j]));
+            if constexpr (FUSED == 2) asm volatile("" : "+v"(wv[j]), "+v"(sv[j]), "+v"(w0v[j]));
+        }
+    }
 
     float cost = 0.f;
     if (rg < BM / 4) {
@@ -86,6 +109,7 @@ __device__ __forceinline__ void skinny_tile_epilogue(const GemmArgs& g, const f3
             for (int w = 0; w < NW; ++w) sum += smem[w * (BM * LDT) + (4 * rg + j) * LDT + c];
             x[j] = sum;
         }
+        SK_STAMP(11);
         if constexpr (FUSED == 1) {
             const EpiArgs& e = g.epi;
             if (on) {
@@ -125,6 +149,7 @@ __device__ __forceinline__ void skinny_tile_epilogue(const GemmArgs& g, const f3
                 if (r0w + j < g.M && col < g.Nst) C[(int64_t)(r0w + j) * g.ldc + col] = col < g.N ? x[j] : 0.f;
         }
     }
+    SK_STAMP(12);
     if constexpr (FUSED == 1) {
         if (g.epi.cost_partials) {
             __syncthreads();

@@ -17,6 +17,7 @@
 // one being multiplied (a register array indexed by the step's residue would serialise the loads).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "philox.h"
 #include "mdbn_kernels.h"
 #include "mdbn_device.h"
@@ -52,6 +53,153 @@ __device__ __forceinline__ void stream_load8_tail(const float* p, int64_t ld, in
     }
 }
 
+// The tile epilogue of a 64-column tile (NI = 2) in ONE pass: both strips' partial tiles are parked together (one barrier
+// instead of two park / barrier / reduce rounds: ~2 us per launch at the 2048 -> 400 propdown, profiles/r05zb), a thread
+// owns the same (row group, column) quad in each strip.  Arithmetic per quad: skinny_tile_epilogue's.
+// smem: [SKINNY_WAVES][2][32 MI][SKINNY_LDT] floats (+ 8).  One cost partial per tile, in strip 0's slot (strip 1's: zero).
+#ifdef MDBN_STAMP
+#define E2_STAMP(SLOT) do { if (g.stamps && threadIdx.x == 0) g.stamps[(int64_t)blockIdx.x * 16 + (SLOT)] = wall_clock64(); } while (0)
+#else
+#define E2_STAMP(SLOT) do {} while (0)
+#endif
+template <int MI, int FUSED>
+__device__ __forceinline__ void stream_tile_epilogue2(const GemmArgs& g, const f32x16 (&acc)[MI][2], float* smem, int ks, int m0, int n0, int slot0)
+{
+    constexpr int NW = SKINNY_WAVES, LDT = SKINNY_LDT, BM = 32 * MI, ST = BM * LDT;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int q = threadIdx.x;
+    const int rg = q >> 5, c = q & 31;
+    const int r0w = m0 + 4 * rg;
+    const bool strip1 = n0 + 32 < g.Nst;                   // (block-uniform: the last column tile may hold one strip)
+
+    E2_STAMP(8);
+    float bias[2] = {0.f, 0.f}, tg4[2][4];
+    float wv[2][4] = {}, sv[2][4] = {}, w0v[2][4] = {};
+    bool on[2] = {false, false};
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = n0 + 32 * b + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tg4[b][j] = 0.f;
+        if constexpr (FUSED == 1) {
+            const EpiArgs& e = g.epi;
+            on[b] = rg < BM / 4 && r0w < e.rows && col < (int)e.ld;
+            if (on[b]) {
+                const bool live = col < e.cols;
+                bias[b] = live ? e.bias[col] : 0.f;
+                act_quad_targets(e, r0w, col, live, tg4[b]);
+            }
+        } else if constexpr (FUSED == 2) {
+            const UpdEpi& u = g.upd;
+            on[b] = rg < BM / 4 && r0w < u.rows && col < (int)u.ld;
+            if (on[b]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = r0w + j < u.rows;
+                    const int64_t off = (int64_t)(ok ? r0w + j : r0w) * u.ld + col;
+                    wv[b][j] = u.W[off];
+                    sv[b][j] = u.Ws[off];
+                    w0v[b][j] = u.W0 ? u.W0[off] : 0.f;
+                }
+            }
+        }
+    }
+
+    float* T = smem + wave * (2 * ST);
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                T[b * ST + (32 * a + (e & 3) + 8 * (e >> 2) + 4 * h) * LDT + i] = acc[a][b][e];
+    E2_STAMP(9);
+    __syncthreads();
+    E2_STAMP(10);
+    // The requested operands are complete here (the barrier waited for them), but hipcc does not carry that fact across
+    // the per-row branches of the epilogue: it put s_waitcnt vmcnt(0) in front of every row's use of them -- which also
+    // waits for the PREVIOUS row's stores to be acknowledged, ~0.5 us per row (4.6 of the 11.3 us of the 2048 -> 400
+    // propdown).  Re-defining the registers through an empty asm cuts them loose from their loads.
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        asm volatile("" : "+v"(bias[b]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            asm volatile("" : "+v"(tg4[b][j]));
+            if constexpr (FUSED == 2) asm volatile("" : "+v"(wv[b][j]), "+v"(sv[b][j]), "+v"(w0v[b][j]));
+        }
+    }
+
+    float cost = 0.f;
+    if (rg < BM / 4) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (b == 1 && !strip1) break;
+            const int col = n0 + 32 * b + c;
+            float x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += smem[w * (2 * ST) + b * ST + (4 * rg + j) * LDT + c];
+                x[j] = sum;
+            }
+            E2_STAMP(b == 0 ? 11 : 14);
+            if constexpr (FUSED == 1) {
+                const EpiArgs& e = g.epi;
+                if (on[b]) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j] += bias[b];
+                    act_quad_tg(e, x[0], x[1], x[2], x[3], r0w, col, col < e.cols, cost, tg4[b]);
+                }
+            } else if constexpr (FUSED == 2) {
+                const UpdEpi& u = g.upd;
+                if (on[b]) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!u.W0) w0v[b][j] = wv[b][j];
+                        if (col >= g.N) x[j] = 0.f;            // pad columns: S is exactly zero there
+                    }
+                    float4 wn, sn;
+                    update_rule4(make_float4(wv[b][0], wv[b][1], wv[b][2], wv[b][3]), make_float4(sv[b][0], sv[b][1], sv[b][2], sv[b][3]),
+                                 make_float4(x[0], x[1], x[2], x[3]), make_float4(w0v[b][0], w0v[b][1], w0v[b][2], w0v[b][3]),
+                                 u.inv_bs, u.wc, upd_decay(u.lr, u.l2), u.l1, upd_two_lr_l1(u.lr, u.l1), u.mu, u.lr, wn, sn);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (r0w + j < u.rows) {
+                            const int64_t off = (int64_t)(r0w + j) * u.ld + col;
+                            u.W[off] = comp(wn, j);
+                            u.Ws[off] = comp(sn, j);
+                            if (u.Wp) {
+                                unsigned short p1, p2, p3;
+                                split3(comp(wn, j), p1, p2, p3);
+                                u.Wp[off] = p1; u.Wp[u.wp_stride + off] = p2; u.Wp[2 * u.wp_stride + off] = p3;
+                            }
+                        }
+                }
+            } else {
+                float* C = g.C + (int64_t)ks * g.slab_stride;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (r0w + j < g.M && col < g.Nst) C[(int64_t)(r0w + j) * g.ldc + col] = col < g.N ? x[j] : 0.f;
+            }
+            if (b == 0) E2_STAMP(13);
+        }
+    }
+    E2_STAMP(12);
+    if constexpr (FUSED == 1) {
+        if (g.epi.cost_partials) {
+            __syncthreads();
+            const float tot = block_sum(cost, smem);
+            if (threadIdx.x == 0) {
+                g.epi.cost_partials[slot0] = tot;
+                if (strip1) g.epi.cost_partials[slot0 + 1] = 0.f;
+            }
+        }
+    }
+}
+
 #ifdef MDBN_STAMP   // diagnostic builds (scripts/experiments/stream_stamps.py): wall-clock stamps of every workgroup's phases;
                     // -DSTREAM_STAMP_SEL = 0 propup (default) | 1 propdown | 2 statistics GEMM
 #ifndef STREAM_STAMP_SEL
@@ -62,7 +210,7 @@ __device__ __forceinline__ void stream_load8_tail(const float* p, int64_t ld, in
         if ((STREAM_STAMP_SEL == 0 ? (LA == LAY_K && LB == LAY_MN) : STREAM_STAMP_SEL == 1 ? (LA == LAY_K && LB == LAY_K)   \
                                                                                            : (LA == LAY_MN && LB == LAY_MN)) && \
             g.stamps && threadIdx.x == 0)                                                                                   \
-            g.stamps[(int64_t)blockIdx.x * 8 + (SLOT)] = wall_clock64();                                                    \
+            g.stamps[(int64_t)blockIdx.x * 16 + (SLOT)] = wall_clock64();                                                    \
     } while (0)
 #else
 #define ST_STAMP(SLOT) do {} while (0)
@@ -75,15 +223,28 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void stream_gemm_kernel(GemmArgs
     MDBN_GEMM_ARGS_EARLY(g);
     ST_STAMP(0);
     constexpr int NW = SKINNY_WAVES, BM = 32 * MI;
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // [NW][BM][SKINNY_LDT] (+ 8)
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [NW][NI][BM][SKINNY_LDT] (+ 8)
+    const int tn = (g.tiles_n + NI - 1) / NI;             // column tiles (g.tiles_n counts 32-column strips)
+    const int per_split = tn * g.tiles_m;
+    const int nb = per_split * g.splitk;                  // tile workgroups
+    if constexpr (LA == LAY_MN && LB == LAY_MN) {
+        // statistics GEMM: the bias statistics / cost total / bias update units (finalize_unit: the functions and order of
+        // finalize_stats_kernel) run on EXTRA workgroups behind the tile workgroups -- ahead of the operand stream inside
+        // the tile workgroups they held some of them up by 3 - 6 us (profiles/r05w_stream_stamps.log)
+        if ((int)blockIdx.x >= nb) {
+            if (g.fin_enabled) {
+                const int nu = fin_units(g.fin), nx = (int)gridDim.x - nb, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                for (int unit = wv * nx + ((int)blockIdx.x - nb); unit <= nu; unit += SKINNY_WAVES * nx)
+                    finalize_unit(g.fin, unit, threadIdx.x & 63);
+            }
+            return;
+        }
+    }
     // workgroup -> tile, XCD-aware: consecutive workgroup ids go round the 8 XCDs, each with its own L2; XCD x takes a
     // CONTIGUOUS range of the row-major tile list (a few row tiles x all column strips), so its L2 holds those rows of the
     // row operand + the column operand once, instead of every XCD streaming both operands whole (7 MB through 4 MB of L2)
-    const int nb = (int)gridDim.x;
     const int xcd = (int)blockIdx.x & 7, xq = (int)blockIdx.x >> 3;
     const int bid = xcd * (nb >> 3) + min(xcd, nb & 7) + xq;
-    const int tn = (g.tiles_n + NI - 1) / NI;             // column tiles (g.tiles_n counts 32-column strips)
-    const int per_split = tn * g.tiles_m;
     const int ks = bid / per_split, rem = bid - ks * per_split;
     const int tm = rem / tn, st = rem - tm * tn;
     const int m0 = tm * BM, n0 = st * 32 * NI;
@@ -113,16 +274,6 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void stream_gemm_kernel(GemmArgs
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    if constexpr (LA == LAY_MN && LB == LAY_MN) {
-        // statistics GEMM: the bias statistics / cost total / bias update units spread over the waves of all workgroups,
-        // ahead of the operand stream (as skinny_gemm_kernel; behind the first loads they cost 60 registers and 6 - 13 us
-        // per step: profiles/r05y_stream_variants.log)
-        if (g.fin_enabled) {
-            const int nu = fin_units(g.fin);
-            for (int unit = wave * (int)gridDim.x + (int)blockIdx.x; unit <= nu; unit += NW * (int)gridDim.x)
-                finalize_unit(g.fin, unit, lane);
-        }
-    }
     ST_STAMP(1);
     float fa0[MI][8], fa1[MI][8], fa2[MI][8], fb0[NI][8], fb1[NI][8], fb2[NI][8];
     const int nfull = (kend - kbeg) >> 4;                              // whole 16-deep steps; wave w: steps w, w + 8, ...
@@ -188,25 +339,26 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void stream_gemm_kernel(GemmArgs
         consume(fa0, fb0);
     }
     ST_STAMP(3);
-    // the epilogue runs strip by strip (the partial tiles of one 32-column strip are parked, reduced, consumed)
-#pragma unroll
-    for (int b = 0; b < NI; ++b) {
-        if (b > 0) {
-            if (n0 + 32 * b >= g.Nst) break;                       // (block-uniform: the last column tile may hold one strip)
-            __syncthreads();                                        // every thread has read the previous strip's partials
-        }
+#ifdef MDBN_STAMP
+    if (g.stamps && threadIdx.x == 0) g.stamps[(int64_t)blockIdx.x * 16 + 7] = (unsigned long long)n0;
+    __syncthreads();
+#endif
+    if constexpr (NI == 2) {
+        stream_tile_epilogue2<MI, FUSED>(g, acc, smem, ks, m0, n0, (ks * g.tiles_m + tm) * g.tiles_n + NI * st);
+        ST_STAMP(4);
+    } else {
         f32x16 t[MI];
 #pragma unroll
-        for (int a = 0; a < MI; ++a) t[a] = acc[a][b];
-        skinny_tile_epilogue<MI, FUSED, true>(g, t, smem, ks, m0, n0 + 32 * b, (ks * g.tiles_m + tm) * g.tiles_n + NI * st + b);
-        ST_STAMP(4 + b);
+        for (int a = 0; a < MI; ++a) t[a] = acc[a][0];
+        skinny_tile_epilogue<MI, FUSED, true>(g, t, smem, ks, m0, n0, (ks * g.tiles_m + tm) * g.tiles_n + st);
+        ST_STAMP(4);
     }
 }
 
 template <int LA, int LB, int MI, int NI, int FUSED, int AP>
 static hipError_t launch_stream_t(const GemmArgs& g, hipStream_t s)
 {
-    constexpr int lds_bytes = (SKINNY_WAVES * 32 * MI * SKINNY_LDT + 8) * (int)sizeof(float);
+    constexpr int lds_bytes = (SKINNY_WAVES * NI * 32 * MI * SKINNY_LDT + 8) * (int)sizeof(float);
     static bool attr_set = false;
     auto kern = stream_gemm_kernel<LA, LB, MI, NI, FUSED, AP>;
     if (!attr_set && lds_bytes > 64 * 1024) {
@@ -214,7 +366,12 @@ static hipError_t launch_stream_t(const GemmArgs& g, hipStream_t s)
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(((g.tiles_n + NI - 1) / NI) * g.tiles_m * g.splitk), dim3(64 * SKINNY_WAVES), lds_bytes, s, g);
+    int blocks = ((g.tiles_n + NI - 1) / NI) * g.tiles_m * g.splitk;
+    if (LA == LAY_MN && LB == LAY_MN && g.fin_enabled) {
+        const int units = (int)((g.fin.ldh + g.fin.ldv + 15) / 16) + 1;                   // fin_units() + the cost unit
+        blocks += std::min(32, (units + SKINNY_WAVES - 1) / SKINNY_WAVES);                // one unit per wave, <= 32 workgroups
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * SKINNY_WAVES), lds_bytes, s, g);
     return hipGetLastError();
 }
 

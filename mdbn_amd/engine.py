@@ -10,6 +10,7 @@ Matrix convention: a device matrix is a torch view [rows, cols] over storage
 [rows, ld] with ld = padded_ld(cols) (a multiple of 4) and zero padding (``alloc_matrix``).
 """
 import ctypes as C
+import os as _os
 
 import numpy
 import torch
@@ -174,6 +175,11 @@ class HipEngine(object):
         self._cost_ring = torch.zeros(1024, dtype=torch.float32, device=self.device)
         self._cost_slot = 0
         self.last_scratch = None        # CDScratch of the most recent CD step (inspection / chain taps)
+        # MDBN_OPTIONS="name=value,name=value": library knobs of every context this process creates (A/B runs of the
+        # bench scripts without editing them; unknown names fail as mdbn_set_option does)
+        for item in filter(None, _os.environ.get("MDBN_OPTIONS", "").split(",")):
+            name, _, value = item.partition("=")
+            self.set_option(name.strip(), int(value))
 
     def __del__(self):
         try:
@@ -314,7 +320,6 @@ class HipEngine(object):
                 return He
         return None
 
-    import os as _os
     weight_ld_min_elems = int(_os.environ.get("MDBN_WEIGHT_LD_MIN", 1 << 21))      # smallest V * padded H that is padded
 
     def plane_shape(self, B, V, H, ldv, ldh):

@@ -16,10 +16,10 @@ def gpu_steps(cls, V, H, B, k, hp, N, steps=300):
     fn = mdbn_amd.function(up, mdbn_amd.shared(data))
     perm = torch.from_numpy(rs.permutation(N)).to(eng.device)
     nmb = N // B
-    def run(n):
+    def run(n):           # (the trainers announce the next minibatch: dbn.py's epoch order is drawn up front)
         for it in range(n):
-            mb = it % nmb
-            fn(indexes=perm[mb * B:(mb + 1) * B], momentum=0.5)
+            mb, nx = it % nmb, (it + 1) % nmb
+            fn(indexes=perm[mb * B:(mb + 1) * B], momentum=0.5, next_indexes=perm[nx * B:(nx + 1) * B])
     run(20); eng.synchronize()
     t0 = time.perf_counter(); run(steps); eng.synchronize()
     return steps / (time.perf_counter() - t0)
@@ -42,9 +42,11 @@ cases = [
     ("c2 GRBM 4096->1024 B=512 k=1 (headline)", G, 4096, 1024, 512, 1, dict(lr=0.001, lambda_2=0.1), 8192),
     ("c4 L1 RBM 1024->256 B=512 k=1", R, 1024, 256, 512, 1, dict(lr=0.1, weightcost=2e-4), 8192),
     ("c5 GE GRBM 2048->400 B=512 k=1", G, 2048, 400, 512, 1, dict(lr=0.002, lambda_2=0.1), 8192),
+    ("c5 GE GRBM 2048->400 B=512 k=5", G, 2048, 400, 512, 5, dict(lr=0.002, lambda_2=0.1), 8192),
     ("c5 GE L1 RBM 400->40 B=512 k=1", R, 400, 40, 512, 1, dict(lr=0.1, weightcost=2e-4), 8192),
     ("c5 miRNA GRBM 512->40 B=512 k=5", G, 512, 40, 512, 5, dict(lr=0.002, lambda_2=0.1), 8192),
     ("c5 SM GRBM 256->200 B=512 k=1", G, 256, 200, 512, 1, dict(lr=0.002, lambda_2=0.1), 8192),
+    ("c5 SM GRBM 256->200 B=512 k=5", G, 256, 200, 512, 5, dict(lr=0.002, lambda_2=0.1), 8192),
     ("c5 joint RBM 100->128 B=512 k=1", R, 100, 128, 512, 1, dict(lr=0.1, weightcost=2e-4), 8192),
     ("real GE shape GRBM 19937->400 B=20 k=1", G, 19937, 400, 20, 1, dict(lr=0.0005, lambda_2=0.1), 170),
 ]
@@ -52,12 +54,14 @@ gpu = {}
 for name, cls, V, H, B, k, hp, N in cases:          # all GPU runs first: the BLAS-threaded CPU
     gpu[name] = gpu_steps(cls, V, H, B, k, hp, max(N, B))   # baseline disturbs host-bound shapes
 out = []
+NO_CPU = "--no-cpu" in sys.argv
+F32_MFMA_PEAK_TF = 157.3          # dense f32 MFMA peak (MI355X_MICROARCH.md): the roof of the north-star metric's arithmetic
 for name, cls, V, H, B, k, hp, N in cases:
     g = gpu[name]
-    c = cpu_steps(cls is G, V, H, B, k, hp)
+    c = float("nan") if NO_CPU else cpu_steps(cls is G, V, H, B, k, hp)
     flops = 2.0 * B * V * H * (2 * k + 3)
     row = dict(config=name, gpu_steps_per_s=g, gpu_us_per_step=1e6 / g, gpu_samples_per_s=g * B, gpu_tflops=flops * g / 1e12,
-               cpu_steps_per_s=c, speedup=g / c)
+               frac_of_f32_mfma_peak=flops * g / 1e12 / F32_MFMA_PEAK_TF, cpu_steps_per_s=c, speedup=g / c)
     out.append(row)
     print("%-46s GPU %8.0f steps/s (%7.1f us, %6.2f TF)   CPU oracle %8.1f steps/s   x%.0f" %
           (name, g, 1e6 / g, row["gpu_tflops"], c, g / c), flush=True)

@@ -35,14 +35,14 @@ def run(n, it0=0):
         mb = it % (N // B)
         fn(indexes=perm[mb * B:(mb + 1) * B], momentum=0.0)
 run(20); eng.synchronize()
-stamps = torch.zeros(2048 * 8, dtype=torch.int64, device=eng.device)
+stamps = torch.zeros(2048 * 16, dtype=torch.int64, device=eng.device)
 names = ["setup (+ finalize units)", "main loop", "drain", "park + reduce + epilogue (strip 0)", "strip 1"]
 for rep in range(3):
     stamps.zero_()
     eng.lib.mdbn_debug_set_stamps(C.c_void_p(stamps.data_ptr()))
     run(1, 20 + rep); eng.synchronize()
     eng.lib.mdbn_debug_set_stamps(C.c_void_p(0))
-st = stamps.cpu().numpy().reshape(2048, 8).astype(np.int64)
+st = stamps.cpu().numpy().reshape(2048, 16).astype(np.int64)
 st = st[st[:, 0] > 0]
 last = 5 if (st[:, 5] > 0).any() else 4
 t0 = st[:, 0].min()
@@ -54,5 +54,15 @@ for i in range(last):
     print("  %-38s mean %6.2f us  (min %5.2f  max %5.2f)" % (names[i], col.mean(), col.min(), col.max()))
 life = (st[:, 4] - st[:, 0]) / 100.0
 print("  workgroup lifetime (to strip 0 done) mean %.2f us (min %.2f max %.2f)" % (life.mean(), life.min(), life.max()))
+if (st[:, 12] > 0).any():
+    cols = [8, 9, 10, 11, 12] if (st[:, 11] > 0).any() else [8, 9, 10, 12]
+    names2 = ["request + park", "barrier", "reduce (LDS reads)", "epilogue arithmetic + stores"] if len(cols) == 5 else \
+             ["request + park", "barrier", "reduce + epilogue arithmetic + stores"]
+    e = np.diff(st[:, cols], axis=1) / 100.0
+    print("    loop end -> epilogue entry              mean %5.2f us" % ((st[:, 8] - st[:, 3]).mean() / 100.0))
+    for i, nm in enumerate(names2):
+        print("    %-39s mean %5.2f us (min %5.2f max %5.2f)" % (nm, e[:, i].mean(), e[:, i].min(), e[:, i].max()))
+    print("    after the stores (cost sum, end stamp)  mean %5.2f us" % ((st[:, 4] - st[:, 12]).mean() / 100.0))
 for w in (0, len(st) // 2, len(st) - 1):
-    print("  wg %4d: " % w + " ".join("%6.2f" % ((x - t0) / 100.0) for x in st[w, :last + 1]))
+    print("  wg %4d: " % w + " ".join("%6.2f" % ((x - t0) / 100.0) for x in st[w, :last + 1]) + "  | epilogue slots 8.. " +
+          " ".join("%6.2f" % ((x - t0) / 100.0) if x > t0 else "     -" for x in st[w, 8:15]))

@@ -86,7 +86,7 @@ def _run_steps(eng, gauss, planes, V, H, B, k, steps=3, seed=0, mfma=16):
     wp, valid = eng.w_planes(rbm.W.tensor)
     eng.set_option("gemm_planes", 1)
     eng.set_option("planes_mfma", 16)
-    eng.set_option("stream_x6", 1)
+    eng.set_option("stream_x6", 2)
     eng.keep_f32 = keep
     return out, rbm, wp, valid
 

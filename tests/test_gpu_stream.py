@@ -53,7 +53,7 @@ def _step(eng, V, H, B, k, gauss, indexed, mode, tiles, seed):
         eng.kernel_timing(False)
         eng.trace_chain = False
         eng.set_option("small_fused", 1)
-        eng.set_option("stream_x6", 1)
+        eng.set_option("stream_x6", 2)
         eng.set_option("stream_mi", 0); eng.set_option("stream_ni", 0)
         eng.set_planes_min_work(0)
     x = data[idx] if idx is not None else data
@@ -159,7 +159,8 @@ def test_stream_training_steps_follow_the_oracle(hip_engine, V, H, B, cls_gauss,
         eng.kernel_timing(False)
         eng.trace_chain = False
         eng.set_planes_min_work(0)
-        eng.set_option("stream_x6", 1)
+        eng.set_option("stream_x6", 2)
     for name in ("W", "hbias", "vbias", "W_speed", "hbias_speed", "vbias_speed"):
         got, ref = getattr(rbm, name).get_value(), getattr(st, name)
         check("stream training: %s after 4 steps / max" % name, np.abs(got - ref).max() / max(1.0, np.abs(ref).max()), 2e-6, "update")
+
