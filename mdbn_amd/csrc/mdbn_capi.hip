@@ -1945,7 +1945,9 @@ static int cd_step_impl(mdbn_ctx* ctx, void* stream, const mdbn_cd_args* a, cons
     // x = train_set_x[indexes]                                        (dbn.py:307)
     // (its own launch: read through the index list inside the first propup of the streaming kernel, the rows come from HBM
     //  at HBM latency into every workgroup's operand stream -- bit-identical and 3 - 10 us per step SLOWER,
-    //  profiles/r05zi_stream_gather_ab.log)
+    //  profiles/r05zi_stream_gather_ab.log; gathered AHEAD by extra workgroups of the previous step's statistics launch
+    //  into a second V2 buffer: bit-identical too, and that launch grows by more than the gather launch it saves,
+    //  profiles/r05zm_gather_ahead_dense_ab.log, r05zl_*)
     HIP_OK(launch_gather(a->data, a->n_data, ldv, ldv, a->indexes, a->index_is_64, B, v0, ldv, s));
 
     // positive phase: ph_mean, ph_sample                              (rbm.py:303)
