@@ -275,20 +275,27 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void stream_gemm_kernel(GemmArgs
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
     ST_STAMP(1);
-    float fa0[MI][8], fa1[MI][8], fa2[MI][8], fb0[NI][8], fb1[NI][8], fb2[NI][8];
+    // D register sets: D - 1 steps of loads in flight behind the one being multiplied.  Deeper does not help (D = 4 / 5 / 6
+    // on the 32 x 32 tiles: +0 .. +4 % per step, profiles/r05zo_stream_depth.log): the stream moves ~11 TB/s from L2 into
+    // the CUs, it is not short of requests in flight.
+#ifndef STREAM_DEPTH
+#define STREAM_DEPTH 3
+#endif
+    constexpr int D = MI * NI == 1 ? STREAM_DEPTH : 3;
+    float fa[D][MI][8], fb[D][NI][8];               // (indexed by unrolled loop counters only)
     const int nfull = (kend - kbeg) >> 4;                              // whole 16-deep steps; wave w: steps w, w + 8, ...
     const int n = wave < nfull ? (nfull - wave + NW - 1) / NW : 0;     // (wave-uniform)
-    auto issue = [&](int j, float (&fa)[MI][8], float (&fb)[NI][8]) {
+    auto issue = [&](int j, float (&xa)[MI][8], float (&xb)[NI][8]) {
         const int k16 = kbeg + 16 * (wave + NW * j) + 8 * h;
 #pragma unroll
-        for (int a = 0; a < MI; ++a) stream_load8<LA>(aptr[a], g.lda, k16, fa[a]);
+        for (int a = 0; a < MI; ++a) stream_load8<LA>(aptr[a], g.lda, k16, xa[a]);
 #pragma unroll
-        for (int b = 0; b < NI; ++b) stream_load8<LB>(bptr[b], g.ldb, k16, fb[b]);
+        for (int b = 0; b < NI; ++b) stream_load8<LB>(bptr[b], g.ldb, k16, xb[b]);
     };
-    auto consume = [&](const float (&fa)[MI][8], const float (&fb)[NI][8]) {
+    auto consume = [&](const float (&xa)[MI][8], const float (&xb)[NI][8]) {
         tbf16x8 pb[NI][3];
 #pragma unroll
-        for (int b = 0; b < NI; ++b) th_split8(fb[b], pb[b]);
+        for (int b = 0; b < NI; ++b) th_split8(xb[b], pb[b]);
 #pragma unroll
         for (int a = 0; a < MI; ++a) {
             tbf16x8 pa[3];
@@ -296,47 +303,49 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void stream_gemm_kernel(GemmArgs
                 tu32x4 q;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    q[e] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, fa[a][2 * e + 1]), __builtin_bit_cast(unsigned, fa[a][2 * e]),
+                    q[e] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, xa[a][2 * e + 1]), __builtin_bit_cast(unsigned, xa[a][2 * e]),
                                                  0x07060302u);
                 pa[0] = __builtin_bit_cast(tbf16x8, q); pa[1] = pa[0]; pa[2] = pa[0];
             } else {
-                th_split8(fa[a], pa);
+                th_split8(xa[a], pa);
             }
 #pragma unroll
             for (int b = 0; b < NI; ++b) th_mma<AP>(acc[a][b], pa, pb[b]);
         }
     };
     int j = 0;
-    if (n >= 6) {
-        // steady state: straight-line code, two steps of loads in flight behind the one being multiplied
-        issue(0, fa0, fb0); issue(1, fa1, fb1); issue(2, fa2, fb2);
-        for (; j + 6 <= n; j += 3) {        // (the scheduling fences keep hipcc from sinking all three issues to the loop's end)
-            consume(fa0, fb0); __builtin_amdgcn_sched_barrier(0); issue(j + 3, fa0, fb0); __builtin_amdgcn_sched_barrier(0);
-            consume(fa1, fb1); __builtin_amdgcn_sched_barrier(0); issue(j + 4, fa1, fb1); __builtin_amdgcn_sched_barrier(0);
-            consume(fa2, fb2); __builtin_amdgcn_sched_barrier(0); issue(j + 5, fa2, fb2); __builtin_amdgcn_sched_barrier(0);
+    if (n >= 2 * D) {
+        // steady state: straight-line code (loads under data-dependent branches would cost the wait-count precision)
+#pragma unroll
+        for (int d = 0; d < D; ++d) issue(d, fa[d], fb[d]);
+        for (; j + 2 * D <= n; j += D) {     // (the scheduling fences keep hipcc from sinking all the issues to the loop's end)
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                consume(fa[d], fb[d]); __builtin_amdgcn_sched_barrier(0);
+                issue(j + D + d, fa[d], fb[d]); __builtin_amdgcn_sched_barrier(0);
+            }
         }
     } else {
-        if (n > 0) issue(0, fa0, fb0);
-        if (n > 1) issue(1, fa1, fb1);
-        if (n > 2) issue(2, fa2, fb2);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (n > d) issue(d, fa[d], fb[d]);
     }
     ST_STAMP(2);
-    // drain (and short ranges): the sets hold steps j, j + 1, j + 2
-    for (; j < n; j += 3) {
-        consume(fa0, fb0);
-        if (j + 3 < n) issue(j + 3, fa0, fb0);
-        if (j + 1 < n) consume(fa1, fb1);
-        if (j + 4 < n) issue(j + 4, fa1, fb1);
-        if (j + 2 < n) consume(fa2, fb2);
-        if (j + 5 < n) issue(j + 5, fa2, fb2);
+    // drain (and short ranges): the sets hold steps j .. j + D - 1
+    for (; j < n; j += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (j + d < n) consume(fa[d], fb[d]);
+            if (j + D + d < n) issue(j + D + d, fa[d], fb[d]);
+        }
     }
     if (((kend - kbeg) & 15) && wave == nfull % NW) {                  // the partial last step: one wave
         const int k16 = kbeg + 16 * nfull + 8 * h;
 #pragma unroll
-        for (int a = 0; a < MI; ++a) stream_load8_tail<LA>(aptr[a], g.lda, k16, kend, fa0[a]);
+        for (int a = 0; a < MI; ++a) stream_load8_tail<LA>(aptr[a], g.lda, k16, kend, fa[0][a]);
 #pragma unroll
-        for (int b = 0; b < NI; ++b) stream_load8_tail<LB>(bptr[b], g.ldb, k16, kend, fb0[b]);
-        consume(fa0, fb0);
+        for (int b = 0; b < NI; ++b) stream_load8_tail<LB>(bptr[b], g.ldb, k16, kend, fb[0][b]);
+        consume(fa[0], fb[0]);
     }
     ST_STAMP(3);
 #ifdef MDBN_STAMP
