@@ -32,9 +32,9 @@ fn = mdbn_amd.function(up, data)
 perm = torch.from_numpy(np.random.RandomState(1).permutation(N)).to(eng.device)
 def run(n):
     c = None
-    for it in range(n):
-        mb = it %% (N // B)
-        c = fn(indexes=perm[mb * B:(mb + 1) * B], momentum=0.0)
+    for it in range(n):           # (the next minibatch announced, as the trainers do)
+        mb, nx = it %% (N // B), (it + 1) %% (N // B)
+        c = fn(indexes=perm[mb * B:(mb + 1) * B], momentum=0.0, next_indexes=perm[nx * B:(nx + 1) * B])
     return c
 run(30); eng.synchronize()
 ts = []
