@@ -65,3 +65,20 @@ def test_a_whole_step_between_forward_and_statistics_ends_the_hand_over(hip_engi
     token = eng.cd_forward(dx, None, dW, dhb, dvb, False, 1, RngAddr(1, 0, 2, 0, 0))
     eng.cd_statistics(token)
     eng.synchronize()
+
+
+def test_environment_knobs_reach_every_new_context(built_lib, monkeypatch):
+    """MDBN_OPTIONS="name=value,..." (A/B runs of the bench scripts): applied by every HipEngine created afterwards, to its own
+    context only; an unknown name fails as mdbn_set_option does."""
+    import mdbn_amd
+    from mdbn_amd import _lib
+    plain = mdbn_amd.HipEngine()
+    monkeypatch.setenv("MDBN_OPTIONS", "stream_x6=0, small_fused=0")
+    tuned = mdbn_amd.HipEngine()
+    monkeypatch.delenv("MDBN_OPTIONS")
+    ka, kb = _kinds(plain, 1000, 300, 200), _kinds(tuned, 1000, 300, 200)
+    assert ka and all(1100 <= k < 2000 for k in ka), ka            # the default: the streaming bf16x6 kernel
+    assert kb and not any(1100 <= k < 2000 for k in kb), kb        # stream_x6 = 0 on this context: LDS-tiled / exact kernels
+    monkeypatch.setenv("MDBN_OPTIONS", "no_such_knob=1")
+    with pytest.raises(_lib.MdbnError):
+        mdbn_amd.HipEngine()
